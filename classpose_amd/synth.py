@@ -1,0 +1,267 @@
+"""Procedural synthetic slide, analytic network fields and seeded weights.
+
+There is no network in the build/bench environment, so neither a real slide nor
+the reference's checkpoints (HF ``classpose/classpose``,
+/root/reference/src/classpose/model_configs.py:23-109) can be fetched.  This
+module provides
+
+* ``SyntheticSlide`` -- an OpenSlide-protocol reader (the protocol ``WSIReader``
+  hands to ``SlideLoader``, /root/reference/src/classpose/__init__.py:39-41 and
+  wsi_utils.py:10-143) whose pixels are a pure function of (x, y, seed), so any
+  region is reproducible on any rank without storage;
+* ``analytic_fields`` -- flow / cellprob / class-logit tensors rendered from
+  the same nuclei ("flow-injection" mode: random weights give no meaningful
+  cells, so cells/s is measured on these while the network still runs);
+* ``make_state_dict`` -- seeded random weights in the exact state-dict key
+  layout ``net.load_model`` / ``infer_structure`` expect
+  (/root/reference/src/classpose/entrypoints/predict_wsi.py:1393-1405,
+  vit_sam.py:127-144, unet.py:146-171; cellpose/SAM layout SURVEY A.1).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+PITCH = 28            # jittered-grid pitch (px): ~1.28e-3 nuclei / px^2
+R_MIN, R_MAX = 5.0, 9.0
+JITTER = 4.5          # |offset| <= JITTER  => centre distance >= 19 > 2*R_MAX
+BG = np.array([230.0, 200.0, 220.0])
+FG = np.array([90.0, 60.0, 140.0])
+NOISE_SIGMA = 8.0
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays."""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _hash(seed: int, *keys) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        h = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
+        for k in keys:
+            h = _mix(h ^ (np.asarray(k).astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)))
+    return h
+
+
+def _u01(h: np.ndarray) -> np.ndarray:
+    return ((h >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def nuclei_in_region(seed: int, x0: int, y0: int, w: int, h: int, margin: float = R_MAX + 1):
+    """Centres (cx, cy), radii and ids of all nuclei that can touch the region."""
+    gx0 = int(np.floor((x0 - margin - JITTER) / PITCH)) - 1
+    gx1 = int(np.floor((x0 + w + margin + JITTER) / PITCH)) + 1
+    gy0 = int(np.floor((y0 - margin - JITTER) / PITCH)) - 1
+    gy1 = int(np.floor((y0 + h + margin + JITTER) / PITCH)) + 1
+    gx, gy = np.meshgrid(np.arange(gx0, gx1 + 1), np.arange(gy0, gy1 + 1), indexing="xy")
+    gx = gx.ravel().astype(np.int64)
+    gy = gy.ravel().astype(np.int64)
+    kx = gx + (1 << 20)
+    ky = gy + (1 << 20)
+    cx = (gx + 0.5) * PITCH + (_u01(_hash(seed, kx, ky, 1)) * 2 - 1) * JITTER
+    cy = (gy + 0.5) * PITCH + (_u01(_hash(seed, kx, ky, 2)) * 2 - 1) * JITTER
+    r = R_MIN + _u01(_hash(seed, kx, ky, 3)) * (R_MAX - R_MIN)
+    ident = _hash(seed, kx, ky, 4)
+    keep = (cx + r >= x0 - margin) & (cx - r <= x0 + w + margin) & \
+           (cy + r >= y0 - margin) & (cy - r <= y0 + h + margin)
+    return cx[keep], cy[keep], r[keep], ident[keep]
+
+
+def _owner_map(seed, x0, y0, w, h):
+    """Per pixel: index of the nucleus containing the pixel centre, else -1."""
+    cx, cy, r, ident = nuclei_in_region(seed, x0, y0, w, h)
+    owner = np.full((h, w), -1, np.int64)
+    ys = np.arange(y0, y0 + h)[:, None].astype(np.float64)
+    xs = np.arange(x0, x0 + w)[None, :].astype(np.float64)
+    for k in range(len(cx)):
+        ya = max(int(np.floor(cy[k] - r[k])) - y0, 0)
+        yb = min(int(np.ceil(cy[k] + r[k])) + 1 - y0, h)
+        xa = max(int(np.floor(cx[k] - r[k])) - x0, 0)
+        xb = min(int(np.ceil(cx[k] + r[k])) + 1 - x0, w)
+        if ya >= yb or xa >= xb:
+            continue
+        d2 = (ys[ya:yb] - cy[k]) ** 2 + (xs[:, xa:xb] - cx[k]) ** 2
+        sub = owner[ya:yb, xa:xb]
+        sub[d2 <= r[k] ** 2] = k
+    return owner, cx, cy, r, ident
+
+
+def render_region(seed: int, x0: int, y0: int, w: int, h: int) -> np.ndarray:
+    """uint8 (h, w, 3) H&E-like pixels, pure function of absolute coordinates."""
+    owner, *_ = _owner_map(seed, x0, y0, w, h)
+    base = np.where((owner >= 0)[..., None], FG, BG)
+    ys = np.arange(y0, y0 + h, dtype=np.int64)[:, None, None] + (1 << 20)
+    xs = np.arange(x0, x0 + w, dtype=np.int64)[None, :, None] + (1 << 20)
+    cs = np.arange(3, dtype=np.int64)[None, None, :]
+    u1 = _u01(_hash(seed, xs, ys, cs, 11))
+    u2 = _u01(_hash(seed, xs, ys, cs, 12))
+    noise = np.sqrt(-2.0 * np.log(u1)) * np.cos(2 * np.pi * u2) * NOISE_SIGMA
+    return np.clip(np.rint(base + noise), 0, 255).astype(np.uint8)
+
+
+def analytic_fields(seed: int, x0: int, y0: int, w: int, h: int, n_classes: int):
+    """Flow-injection tensors for the region, as the network would emit them.
+
+    Returns dP (2,h,w) float32 [dY,dX] (x5 scale like the network output),
+    cellprob (h,w) float32 (+6 inside, -6 outside), logits (n_classes,h,w)
+    float32 (one-hot x4, class = id % (n_classes-1) + 1 inside, 0 outside) and
+    the number of nuclei whose discs lie fully inside the region.
+    """
+    owner, cx, cy, r, ident = _owner_map(seed, x0, y0, w, h)
+    inside = owner >= 0
+    oc = np.where(inside, owner, 0)
+    ys = np.arange(y0, y0 + h)[:, None].astype(np.float64)
+    xs = np.arange(x0, x0 + w)[None, :].astype(np.float64)
+    vy = np.where(inside, cy[oc] - ys, 0.0) if len(cx) else np.zeros((h, w))
+    vx = np.where(inside, cx[oc] - xs, 0.0) if len(cx) else np.zeros((h, w))
+    nrm = np.maximum(np.sqrt(vy * vy + vx * vx), 1.0)
+    dP = np.stack((5.0 * vy / nrm, 5.0 * vx / nrm)).astype(np.float32)
+    cellprob = np.where(inside, 6.0, -6.0).astype(np.float32)
+    logits = np.zeros((n_classes, h, w), np.float32)
+    if len(cx):
+        cls = (ident % np.uint64(max(n_classes - 1, 1))).astype(np.int64) + 1
+        cl_px = np.where(inside, cls[oc], 0)
+    else:
+        cl_px = np.zeros((h, w), np.int64)
+    for c in range(n_classes):
+        logits[c][cl_px == c] = 4.0
+    full = (cx - r >= x0) & (cx + r <= x0 + w - 1) & (cy - r >= y0) & (cy + r <= y0 + h - 1)
+    return dP, cellprob, logits, int(full.sum())
+
+
+class SyntheticSlide:
+    """OpenSlide-protocol reader over the procedural image (level 0 only)."""
+
+    def __init__(self, width: int, height: int | None = None, mpp: float = 0.5,
+                 seed: int = 1234, bounds: tuple[float, float] | None = None):
+        self.width = int(width)
+        self.height = int(height if height is not None else width)
+        self.seed = int(seed)
+        self.properties = {"openslide.mpp-x": str(mpp), "openslide.mpp-y": str(mpp)}
+        if bounds is not None:
+            self.properties["openslide.bounds-x"] = str(bounds[0])
+            self.properties["openslide.bounds-y"] = str(bounds[1])
+        self.level_count = 1
+        self.level_dimensions = [(self.width, self.height)]
+        self.level_downsamples = [1.0]
+        self.dimensions = self.level_dimensions[0]
+
+    @classmethod
+    def from_uri(cls, uri: str) -> "SyntheticSlide":
+        """``synthetic://<W>x<H>?mpp=0.5&seed=1234`` (or ``synthetic://<W>``)."""
+        body = uri.split("://", 1)[1]
+        dims, _, query = body.partition("?")
+        dims = dims.rstrip("/").split(".")[0]
+        w, _, h = dims.partition("x")
+        kw = dict(p.split("=", 1) for p in query.split("&") if "=" in p)
+        return cls(int(w), int(h) if h else None, float(kw.get("mpp", 0.5)),
+                   int(kw.get("seed", 1234)))
+
+    def get_best_level_for_downsample(self, downsample: float) -> int:
+        return 0
+
+    def read_region(self, location, level: int, size) -> np.ndarray:
+        x0, y0 = int(location[0]), int(location[1])
+        w, h = int(size[0]), int(size[1])
+        rgb = render_region(self.seed, x0, y0, w, h)
+        return np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], axis=-1)
+
+    def get_thumbnail(self, size) -> np.ndarray:
+        w, h = int(size[0]), int(size[1])
+        sx, sy = self.width / w, self.height / h
+        out = np.empty((h, w, 3), np.uint8)
+        for j in range(h):       # nearest-pixel subsample; thumbnails are tiny
+            row = render_region(self.seed, 0, int(j * sy), self.width, 1)[0]
+            out[j] = row[(np.arange(w) * sx).astype(np.int64)]
+        return out
+
+    def close(self) -> None:
+        pass
+
+
+# --------------------------------------------------------------------------
+# seeded weights with the reference's key layout
+# --------------------------------------------------------------------------
+def make_state_dict(n_classes: int = 7, fts: list[int] | None = None, depth: int = 24,
+                    seed: int = 0, embed: int = 1024, mlp_ratio: int = 4):
+    """Random-init ClassTransformer state dict (float32 torch tensors).
+
+    Scales are chosen so activations stay O(1) through ``depth`` blocks (LN'd
+    residual stream, small residual branches), which keeps bf16-vs-fp32
+    comparisons meaningful.  rel_pos table heights follow SAM ViT-L: 127 rows
+    in the originally-global blocks (5, 11, 17, 23), 27 elsewhere.
+    """
+    import torch
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    hd = 64
+    sd = {}
+    sd["encoder.patch_embed.proj.weight"] = rn(embed, 3, 8, 8, std=1.0 / np.sqrt(192))
+    sd["encoder.patch_embed.proj.bias"] = rn(embed, std=0.02)
+    sd["encoder.pos_embed"] = rn(1, 32, 32, embed, std=0.2)
+    for i in range(depth):
+        p = f"encoder.blocks.{i}."
+        sd[p + "norm1.weight"] = 1.0 + rn(embed, std=0.05)
+        sd[p + "norm1.bias"] = rn(embed, std=0.02)
+        sd[p + "attn.qkv.weight"] = rn(3 * embed, embed, std=1.0 / np.sqrt(embed))
+        sd[p + "attn.qkv.bias"] = rn(3 * embed, std=0.02)
+        sd[p + "attn.proj.weight"] = rn(embed, embed, std=0.5 / np.sqrt(embed))
+        sd[p + "attn.proj.bias"] = rn(embed, std=0.02)
+        nrel = 127 if i in (5, 11, 17, 23) else 27
+        sd[p + "attn.rel_pos_h"] = rn(nrel, hd, std=0.15)
+        sd[p + "attn.rel_pos_w"] = rn(nrel, hd, std=0.15)
+        sd[p + "norm2.weight"] = 1.0 + rn(embed, std=0.05)
+        sd[p + "norm2.bias"] = rn(embed, std=0.02)
+        sd[p + "mlp.lin1.weight"] = rn(mlp_ratio * embed, embed, std=1.0 / np.sqrt(embed))
+        sd[p + "mlp.lin1.bias"] = rn(mlp_ratio * embed, std=0.02)
+        sd[p + "mlp.lin2.weight"] = rn(embed, mlp_ratio * embed, std=0.5 / np.sqrt(mlp_ratio * embed))
+        sd[p + "mlp.lin2.bias"] = rn(embed, std=0.02)
+    sd["encoder.neck.0.weight"] = rn(256, embed, 1, 1, std=1.0 / np.sqrt(embed))
+    sd["encoder.neck.1.weight"] = 1.0 + rn(256, std=0.05)
+    sd["encoder.neck.1.bias"] = rn(256, std=0.02)
+    sd["encoder.neck.2.weight"] = rn(256, 256, 3, 3, std=1.0 / np.sqrt(256 * 9))
+    sd["encoder.neck.3.weight"] = 1.0 + rn(256, std=0.05)
+    sd["encoder.neck.3.bias"] = rn(256, std=0.02)
+    sd["out.weight"] = rn(192, 256, 1, 1, std=1.0 / np.sqrt(256))
+    sd["out.bias"] = rn(192, std=0.1)
+    sd["W2"] = torch.eye(192).reshape(192, 3, 8, 8)
+    sd["diam_labels"] = torch.tensor([30.0])
+    sd["diam_mean"] = torch.tensor([30.0])
+    oc = n_classes * 64
+    if fts is None:
+        sd["out_class.weight"] = rn(oc, 256, 1, 1, std=1.0 / np.sqrt(256))
+        sd["out_class.bias"] = rn(oc, std=0.1)
+    else:
+        def conv(pfx, cin, cout, k):
+            sd[pfx + ".weight"] = rn(cout, cin, k, k, std=1.0 / np.sqrt(cin * k * k))
+            sd[pfx + ".bias"] = rn(cout, std=0.05)
+
+        def convT(pfx, cin, cout, k):
+            sd[pfx + ".weight"] = rn(cin, cout, k, k, std=1.0 / np.sqrt(cin))
+            sd[pfx + ".bias"] = rn(cout, std=0.05)
+
+        ins = [256, *fts]
+        outs = [*fts[::-1], oc]
+        for n, (ci, co) in enumerate(zip(ins[:-1], ins[1:])):
+            p = f"out_class.encoder_blocks.{n}."
+            conv(p + "block.conv1", ci, co, 3)
+            conv(p + "block.conv2", co, co, 3)
+            conv(p + "downconv", co, co, 2)
+        for n, (ci, co) in enumerate(zip(outs[:-1], outs[1:])):
+            p = f"out_class.decoder_blocks.{n}."
+            conv(p + "block.conv1", 2 * ci, co, 3)
+            conv(p + "block.conv2", co, co, 3)
+            convT(p + "upconv", co, co, 2)
+        c = ins[-1]
+        conv("out_class.bottleneck_down.block.conv1", c, c, 3)
+        conv("out_class.bottleneck_down.block.conv2", c, c, 3)
+        conv("out_class.bottleneck_down.downconv", c, c, 2)
+        conv("out_class.bottleneck_up.block.conv1", c, c, 3)
+        conv("out_class.bottleneck_up.block.conv2", c, c, 3)
+        convT("out_class.bottleneck_up.upconv", c, c, 2)
+    sd["W3"] = torch.eye(oc).reshape(oc, n_classes, 8, 8)
+    return sd

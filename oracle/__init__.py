@@ -1,0 +1,33 @@
+"""CPU oracle for the classpose WSI hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is a CPU restatement (numpy / scipy / torch-CPU) of the algorithm
+the reference runs on the ``classpose-predict-wsi`` tile path.  It exists to
+CHECK the HIP implementation in ``classpose_amd``; it is never the thing that
+is shipped or measured.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under
+``classpose_amd/`` imports it, and the product path raises if the HIP library
+is missing instead of falling back to this code.
+
+Parity status
+-------------
+* PINNED against the reference's own importable functions (golden vectors in
+  ``tests/golden/``, minted by ``tests/golden/make_golden.py`` from
+  ``/root/reference`` under a stub importer for the absent third-party wheels):
+  ``compute_class_masks`` (models.py:191), ``remove_border_instances``
+  (metrics/pq.py:65, incl. the 9 known-answer cases of
+  tests/test_remove_border_instances.py), ``unaugment_class_tiles``
+  (transforms/transforms.py:4), ``UNet`` (unet.py:121), ``deduplicate``
+  (predict_wsi.py:896), ``SlideLoader._get_coords`` (predict_wsi.py:366),
+  ``to_geojson_polygon`` / ``polygons_to_centroids`` (predict_wsi.py:813,1336).
+* PARITY UNPINNED (no reference test holds a golden value, and the arithmetic
+  lives in wheels that are absent from /root/reference and from this image):
+  everything restated from ``cellpose==4.0.8`` (uv.lock:352) --
+  ``transforms.normalize_img/get_pad_yx/make_tiles/average_tiles/
+  unaugment_tiles``, ``dynamics.steps_interp/get_masks_torch/
+  remove_bad_flow_masks/masks_to_flows_gpu``,
+  ``utils.fill_holes_and_remove_small_masks`` -- and from
+  ``segment-anything==1.0`` (``ImageEncoderViT``, ``get_rel_pos``).  Where the
+  reference's call bottoms out in a library that IS in this image
+  (``torch.nn.functional.grid_sample``, ``np.percentile``, ``scipy.ndimage``),
+  the oracle calls that library itself rather than restating it.
+"""

@@ -1,0 +1,259 @@
+"""Oracle (test infrastructure): tile grid, normalisation, sub-tiling, blending.
+
+CPU restatement of
+
+* ``SlideLoader._get_coords``           /root/reference/src/classpose/entrypoints/predict_wsi.py:366-391
+* ``core.run_net`` control flow         /root/reference/src/classpose/core.py:75-231
+* ``unaugment_class_tiles``             /root/reference/src/classpose/transforms/transforms.py:4-21
+* cellpose==4.0.8 ``transforms.normalize_img / normalize99 / get_pad_yx /
+  make_tiles / _taper_mask / average_tiles / unaugment_tiles`` (third-party,
+  absent from /root/reference; call sites models.py:642-666, core.py:130-221).
+  PARITY UNPINNED for the cellpose pieces (see oracle/__init__.py).
+
+Not imported by anything under ``classpose_amd/``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# a2: tile grid  (predict_wsi.py:366-391)
+# --------------------------------------------------------------------------
+def get_coords(tile_size: int, overlap: int, slide_dim: tuple[int, int], ts: float):
+    """x outer / y inner, stride tile-overlap, edge remainder dropped."""
+    out = []
+    for i in range(0, slide_dim[0], tile_size - overlap):
+        if (i + tile_size) > slide_dim[0]:
+            break
+        for j in range(0, slide_dim[1], tile_size - overlap):
+            if (j + tile_size) > slide_dim[1]:
+                break
+            out.append(((int(i * ts), int(j * ts)), tile_size))
+    return out
+
+
+# --------------------------------------------------------------------------
+# a6: normalisation  (models.py:615-666 -> cellpose transforms.normalize_img)
+# --------------------------------------------------------------------------
+def normalize99(Y: np.ndarray, lower: float = 1, upper: float = 99) -> np.ndarray:
+    """cellpose.transforms.normalize99 (copy=False semantics on a float32 view)."""
+    X = Y
+    x01 = np.percentile(X, lower)
+    x99 = np.percentile(X, upper)
+    if x99 - x01 > 1e-3:
+        X -= x01
+        X /= x99 - x01
+    else:
+        X[:] = 0
+    return X
+
+
+def normalize_img(img: np.ndarray) -> np.ndarray:
+    """cellpose.transforms.normalize_img with ``normalize_default`` params
+    (percentile None -> (1, 99), no sharpen/smooth/tile-norm, invert False).
+
+    img: (nimg, H, W, C) any dtype.  Returns float32 copy, channels with
+    ``ptp == 0`` left untouched (quirk kept).
+    """
+    img_norm = img.astype(np.float32) if img.dtype != np.float32 else img.copy()
+    nchan = img_norm.shape[-1]
+    for c in range(nchan):
+        if np.ptp(img_norm[..., c]) > 0.0:
+            for z in range(img_norm.shape[0]):
+                # normalize99(copy=False) on the strided channel view
+                ch = np.ascontiguousarray(img_norm[z, ..., c])
+                img_norm[z, ..., c] = normalize99(ch)
+    return img_norm
+
+
+# --------------------------------------------------------------------------
+# a7: padding / sub-tiles / taper blending (cellpose.transforms)
+# --------------------------------------------------------------------------
+def get_pad_yx(Ly: int, Lx: int, div: int = 16, extra: int = 1, min_size=None):
+    if min_size is None or Ly >= min_size[-2]:
+        Lpad = int(div * np.ceil(Ly / div) - Ly)
+    else:
+        Lpad = min_size[-2] - Ly
+    ypad1 = extra * div // 2 + Lpad // 2
+    ypad2 = extra * div // 2 + Lpad - Lpad // 2
+    if min_size is None or Lx >= min_size[-1]:
+        Lpad = int(div * np.ceil(Lx / div) - Lx)
+    else:
+        Lpad = min_size[-1] - Lx
+    xpad1 = extra * div // 2 + Lpad // 2
+    xpad2 = extra * div // 2 + Lpad - Lpad // 2
+    return ypad1, ypad2, xpad1, xpad2
+
+
+def tile_grid(Ly: int, Lx: int, bsize: int, augment: bool, tile_overlap: float):
+    """ny, nx, ystart, xstart exactly as core.py:136-149 + make_tiles compute them."""
+    if augment:
+        ny = max(2, int(np.ceil(2.0 * Ly / bsize)))
+        nx = max(2, int(np.ceil(2.0 * Lx / bsize)))
+        bY = bX = bsize
+    else:
+        tile_overlap = min(0.5, max(0.05, tile_overlap))
+        bY, bX = min(bsize, Ly), min(bsize, Lx)
+        ny = 1 if Ly <= bsize else int(np.ceil((1.0 + 2 * tile_overlap) * Ly / bsize))
+        nx = 1 if Lx <= bsize else int(np.ceil((1.0 + 2 * tile_overlap) * Lx / bsize))
+    ystart = np.linspace(0, Ly - bY, ny).astype(int)
+    xstart = np.linspace(0, Lx - bX, nx).astype(int)
+    return ny, nx, ystart, xstart, bY, bX
+
+
+def make_tiles(imgi: np.ndarray, bsize: int = 224, augment: bool = False,
+               tile_overlap: float = 0.1):
+    """imgi (C, Ly, Lx) -> IMG (ny, nx, C, b, b), ysub, xsub, Ly, Lx."""
+    nchan, Ly, Lx = imgi.shape
+    if augment:
+        if Ly < bsize:
+            imgi = np.concatenate((imgi, np.zeros((nchan, bsize - Ly, Lx))), axis=1)
+            Ly = bsize
+        if Lx < bsize:
+            imgi = np.concatenate((imgi, np.zeros((nchan, Ly, bsize - Lx))), axis=2)
+        Ly, Lx = imgi.shape[-2:]
+    ny, nx, ystart, xstart, bY, bX = tile_grid(Ly, Lx, bsize, augment, tile_overlap)
+    ysub, xsub = [], []
+    IMG = np.zeros((ny, nx, nchan, bY, bX), np.float32)
+    for j in range(ny):
+        for i in range(nx):
+            ysub.append([ystart[j], ystart[j] + bY])
+            xsub.append([xstart[i], xstart[i] + bX])
+            IMG[j, i] = imgi[:, ysub[-1][0]:ysub[-1][1], xsub[-1][0]:xsub[-1][1]]
+            if augment:
+                if j % 2 == 0 and i % 2 == 1:
+                    IMG[j, i] = IMG[j, i, :, ::-1, :]
+                elif j % 2 == 1 and i % 2 == 0:
+                    IMG[j, i] = IMG[j, i, :, :, ::-1]
+                elif j % 2 == 1 and i % 2 == 1:
+                    IMG[j, i] = IMG[j, i, :, ::-1, ::-1]
+    return IMG, ysub, xsub, Ly, Lx
+
+
+def unaugment_tiles(y: np.ndarray) -> np.ndarray:
+    """cellpose.transforms.unaugment_tiles: undo flips, negate flipped flow axis."""
+    for j in range(y.shape[0]):
+        for i in range(y.shape[1]):
+            if j % 2 == 0 and i % 2 == 1:
+                y[j, i] = y[j, i, :, ::-1, :]
+                y[j, i, 0] *= -1
+            elif j % 2 == 1 and i % 2 == 0:
+                y[j, i] = y[j, i, :, :, ::-1]
+                y[j, i, 1] *= -1
+            elif j % 2 == 1 and i % 2 == 1:
+                y[j, i] = y[j, i, :, ::-1, ::-1]
+                y[j, i, 0] *= -1
+                y[j, i, 1] *= -1
+    return y
+
+
+def unaugment_class_tiles(y: np.ndarray) -> np.ndarray:
+    """transforms/transforms.py:4-21 (flips only, no sign change)."""
+    for j in range(y.shape[0]):
+        for i in range(y.shape[1]):
+            if j % 2 == 0 and i % 2 == 1:
+                y[j, i] = y[j, i, :, ::-1, :]
+            elif j % 2 == 1 and i % 2 == 0:
+                y[j, i] = y[j, i, :, :, ::-1]
+            elif j % 2 == 1 and i % 2 == 1:
+                y[j, i] = y[j, i, :, ::-1, ::-1]
+    return y
+
+
+def taper_mask_1d(bsize_tile: int = 224, sig: float = 7.5) -> np.ndarray:
+    """1-D factor of cellpose ``_taper_mask`` (float64), already centre-cropped."""
+    ly = bsize_tile
+    bsize = max(224, ly)
+    xm = np.arange(bsize)
+    xm = np.abs(xm - xm.mean())
+    m = 1 / (1 + np.exp((xm - (bsize / 2 - 20)) / sig))
+    return m[bsize // 2 - ly // 2: bsize // 2 + ly // 2 + ly % 2]
+
+
+def taper_mask(ly: int = 224, lx: int = 224, sig: float = 7.5) -> np.ndarray:
+    bsize = max(224, max(ly, lx))
+    xm = np.arange(bsize)
+    xm = np.abs(xm - xm.mean())
+    mask = 1 / (1 + np.exp((xm - (bsize / 2 - 20)) / sig))
+    mask = mask * mask[:, np.newaxis]
+    mask = mask[bsize // 2 - ly // 2: bsize // 2 + ly // 2 + ly % 2,
+                bsize // 2 - lx // 2: bsize // 2 + lx // 2 + lx % 2]
+    return mask
+
+
+def average_tiles(y: np.ndarray, ysub, xsub, Ly: int, Lx: int) -> np.ndarray:
+    """y (ntiles, C, b, b) float32 -> (C, Ly, Lx) float32, taper-weighted."""
+    Navg = np.zeros((Ly, Lx))
+    yf = np.zeros((y.shape[1], Ly, Lx), np.float32)
+    mask = taper_mask(ly=y.shape[-2], lx=y.shape[-1])
+    for j in range(len(ysub)):
+        yf[:, ysub[j][0]:ysub[j][1], xsub[j][0]:xsub[j][1]] += y[j] * mask
+        Navg[ysub[j][0]:ysub[j][1], xsub[j][0]:xsub[j][1]] += mask
+    yf /= Navg
+    return yf
+
+
+# --------------------------------------------------------------------------
+# a7/a8: run_net (core.py:75-231), 2-D branch, one image (Lz == 1 per call,
+# exactly how worker() drives it: one WSI tile per eval, predict_wsi.py:750).
+# --------------------------------------------------------------------------
+def subtile_batch(x: np.ndarray, bsize: int = 256, augment: bool = False,
+                  tile_overlap: float = 0.1):
+    """x (1, Ly0, Lx0, C) float32 -> IMGa (ntiles, C, b, b) + blend geometry."""
+    Lz, Ly0, Lx0, nchan = x.shape
+    assert Lz == 1
+    ypad1, ypad2, xpad1, xpad2 = get_pad_yx(Ly0, Lx0, min_size=(bsize, bsize))
+    Ly, Lx = Ly0 + ypad1 + ypad2, Lx0 + xpad1 + xpad2
+    pads = np.array([[0, 0], [ypad1, ypad2], [xpad1, xpad2]])
+    imgb = np.pad(x[0].transpose(2, 0, 1), pads, mode="constant")
+    IMG, ysub, xsub, Lyt, Lxt = make_tiles(imgb, bsize=bsize, augment=augment,
+                                           tile_overlap=tile_overlap)
+    ny, nx = IMG.shape[:2]
+    IMGa = np.reshape(IMG, (ny * nx, nchan, IMG.shape[-2], IMG.shape[-1]))
+    geom = dict(ny=ny, nx=nx, ysub=ysub, xsub=xsub, Lyt=Lyt, Lxt=Lxt, Ly=Ly, Lx=Lx,
+                pads=(ypad1, ypad2, xpad1, xpad2), imgb_shape=imgb.shape)
+    return IMGa, geom
+
+
+def blend_subtiles(ya: np.ndarray, y_classa: np.ndarray, geom: dict, augment: bool):
+    """Inverse of subtile_batch for network outputs (core.py:197-231)."""
+    ny, nx = geom["ny"], geom["nx"]
+    ly, lx = ya.shape[-2:]
+    y = ya.copy()
+    y_class = y_classa.copy()
+    if augment:
+        y = np.reshape(y, (ny, nx, 3, ly, lx))
+        y = unaugment_tiles(y)
+        y = np.reshape(y, (-1, 3, ly, lx))
+        ncls = y_class.shape[1]
+        y_class = np.reshape(y_class, (ny, nx, ncls, ly, lx))
+        y_class = unaugment_class_tiles(y_class)
+        y_class = np.reshape(y_class, (-1, ncls, ly, lx))
+    H, W = geom["imgb_shape"][-2:]
+    yf = average_tiles(y, geom["ysub"], geom["xsub"], geom["Lyt"], geom["Lxt"])[:, :H, :W]
+    ycf = average_tiles(y_class, geom["ysub"], geom["xsub"], geom["Lyt"], geom["Lxt"])[:, :H, :W]
+    ypad1, ypad2, xpad1, xpad2 = geom["pads"]
+    Ly, Lx = geom["Ly"], geom["Lx"]
+    yf = yf[:, ypad1:Ly - ypad2, xpad1:Lx - xpad2]
+    ycf = ycf[:, ypad1:Ly - ypad2, xpad1:Lx - xpad2]
+    return yf, ycf  # (3, H0, W0) [dY, dX, cellprob], (ncls, H0, W0)
+
+
+def run_net(forward, x: np.ndarray, batch_size: int = 8, augment: bool = False,
+            tile_overlap: float = 0.1, bsize: int = 256):
+    """core.run_net for one 2-D image.  ``forward(IMG) -> (y[B,3,b,b], y_class[B,ncls,b,b])``.
+
+    Returns dP (2, H, W), cellprob (H, W), y_class (ncls, H, W), all float32
+    (the layout ClassposeModel._run_net hands to compute_masks, models.py:406-416).
+    """
+    IMGa, geom = subtile_batch(x, bsize, augment, tile_overlap)
+    ys, ycs = [], []
+    for j in range(0, IMGa.shape[0], batch_size):
+        y0, yc0 = forward(IMGa[j:j + batch_size])
+        ys.append(np.asarray(y0, np.float32))
+        ycs.append(np.asarray(yc0, np.float32))
+    ya = np.concatenate(ys, 0)
+    yca = np.concatenate(ycs, 0)
+    yf, ycf = blend_subtiles(ya, yca, geom, augment)
+    return yf[:2].copy(), yf[2].copy(), ycf
