@@ -1,0 +1,132 @@
+"""ctypes binding of libclasspose_hip.so (the C ABI in include/classpose_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a
+symbol is absent this module raises, it never routes to another implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclasspose_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ABI_VERSION = 1
+
+
+class CpxTiling(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("ypad1", C.c_int), ("xpad1", C.c_int),
+                ("Ly", C.c_int), ("Lx", C.c_int), ("ny", C.c_int), ("nx", C.c_int),
+                ("bsize", C.c_int), ("augment", C.c_int),
+                ("ystart", C.c_int * 16), ("xstart", C.c_int * 16)]
+
+
+class CpxBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "rel_h", "rel_w",
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class CpxNetWeights(C.Structure):
+    _fields_ = [("depth", C.c_int), ("ncls", C.c_int), ("n_head_cols", C.c_int),
+                ("ld_head", C.c_int), ("dtype", C.c_int),
+                ("pe_w", C.c_void_p), ("pe_b", C.c_void_p), ("pos", C.c_void_p),
+                ("blocks", C.POINTER(CpxBlockWeights)),
+                ("neck0_w", C.c_void_p), ("neck_ln1_w", C.c_void_p), ("neck_ln1_b", C.c_void_p),
+                ("neck2_w", C.c_void_p), ("neck_ln2_w", C.c_void_p), ("neck_ln2_b", C.c_void_p),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+
+
+class CpxRecord(C.Structure):
+    _fields_ = [("tile", C.c_int32), ("label", C.c_int32), ("cls", C.c_int32), ("area", C.c_int32),
+                ("y0", C.c_int32), ("x0", C.c_int32), ("y1", C.c_int32), ("x1", C.c_int32),
+                ("sum_y", C.c_int64), ("sum_x", C.c_int64)]
+
+
+_p, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/classpose_hip.h declares
+SIGNATURES = {
+    "cpx_abi_version": (_i, []),
+    "cpx_last_error": (C.c_char_p, []),
+    "cpx_normalize_stats_u8": (_i, [_p, _i, _i, _i, _i, _f, _i, _f, _p, _p, _p]),
+    "cpx_normalize_apply_u8": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "cpx_make_subtiles": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
+    "cpx_make_subtiles_f32": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
+    "cpx_blend_subtiles": (_i, [_p, _i, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
+    "cpx_blend_subtiles_nchw": (_i, [_p, _p, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
+    "cpx_net_workspace_bytes": (_sz, [_i]),
+    "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
+    "cpx_gemm_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "cpx_layernorm_bf16": (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
+    "cpx_attention_relpos": (_i, [_p, _p, _p, _i, _p, _p, _p]),
+    "cpx_postproc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "cpx_postproc_max_labels": (_i, [_i, _i]),
+    "cpx_follow_flows": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
+    "cpx_get_masks": (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p]),
+    "cpx_remove_bad_flow_masks": (_i, [_p, _p, _i, _i, _i, _d, _p, _p, _p]),
+    "cpx_fill_holes_and_remove_small_masks": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "cpx_compute_class_masks": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "cpx_remove_border_instances": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "cpx_compute_masks": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _d, _i, _i, _d, _p, _p, _p, _p, _p]),
+    "cpx_instance_records": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+}
+# not part of the public header (debug / A-B switches)
+_PRIVATE = {
+    "cpx_gemm_set_variant": (None, [_i]),
+    "cpx_set_half_dtype": (None, [_i]),
+}
+
+_lib = None
+
+
+class CpxError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into classpose_amd/libclasspose_hip.so."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean", "-s"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CpxError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in {**SIGNATURES, **_PRIVATE}.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is absent -> loud
+            fn.restype = res
+            fn.argtypes = args
+        if L.cpx_abi_version() != ABI_VERSION:
+            raise CpxError("libclasspose_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().cpx_last_error()
+        raise CpxError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor / numpy array; None -> NULL."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

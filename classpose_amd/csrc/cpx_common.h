@@ -1,0 +1,50 @@
+// Shared helpers for libclasspose_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/classpose_hip.h"
+
+extern thread_local char cpx_err_buf[256];
+
+#define CPX_CHECK_LAUNCH()                                                        \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            snprintf(cpx_err_buf, sizeof(cpx_err_buf), "%s:%d: %s", __FILE__,     \
+                     __LINE__, hipGetErrorString(e__));                           \
+            return CPX_EHIP;                                                      \
+        }                                                                         \
+    } while (0)
+
+#define CPX_HIP(call)                                                             \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            snprintf(cpx_err_buf, sizeof(cpx_err_buf), "%s:%d: %s", __FILE__,     \
+                     __LINE__, hipGetErrorString(e__));                           \
+            return CPX_EHIP;                                                      \
+        }                                                                         \
+    } while (0)
+
+#define CPX_REQUIRE(cond)                                                         \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            snprintf(cpx_err_buf, sizeof(cpx_err_buf), "%s:%d: invalid argument: %s", \
+                     __FILE__, __LINE__, #cond);                                  \
+            return CPX_EINVAL;                                                    \
+        }                                                                         \
+    } while (0)
+
+static inline size_t cpx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cpx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// bf16 helpers (round-to-nearest-even, NaN preserved via the compiler's cast)
+typedef __bf16 bf16_t;
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) {
+    return __uint_as_float(((unsigned int)u) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    bf16_t b = (bf16_t)f;
+    return *reinterpret_cast<unsigned short *>(&b);
+}

@@ -1,0 +1,403 @@
+// ClassTransformer forward on gfx950 (vit_sam.py:148-197 + flash_forward :15-65):
+// LayerNorm, global attention with the decomposed relative-position bias fused
+// into the flash loop, 3x3 im2col for the neck, and the launch sequence that
+// strings them together with the MFMA GEMM of cpx_gemm.hip.
+//
+// Attention design (T = 32x32 tokens, 16 heads x 64):
+//   * one wave owns one IMAGE ROW of queries (32 tokens, same qh) and walks the
+//     keys one image row (32 keys, same kh) at a time, so the bias
+//        rel_h[q, kh] + rel_w[q, kw]
+//     is   Gh[q][qh-kh+31]  (one scalar per lane per key tile)
+//        + Gw[q][qw-kw+31]  (16 per-lane constants for the whole loop)
+//     where G = Q . table^T is two small MFMA products per wave; the dense
+//     [T x T] bias of the reference is never materialised;
+//   * S^T = K . Q^T is computed with the accumulator pre-loaded with the bias
+//     ("row constants as the initial accumulator"), softmax is per lane (the
+//     query is the MFMA column = the lane), and P^T feeds the P.V MFMA straight
+//     from the accumulator registers: the key rows of the K operand are loaded
+//     in the permuted order pi(r) = swap bits 2,3 so that the accumulator's
+//     register order is the natural key order of the V^T operand.
+#include "cpx_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+extern "C" int cpx_get_half_dtype(void);
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const uint4 &a, const uint4 &b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a),
+                                                      *reinterpret_cast<const f16x8 *>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a),
+                                                       *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned short h_from_f32(float f) {
+    if constexpr (F16) { _Float16 h = (_Float16)f; return *reinterpret_cast<unsigned short *>(&h); }
+    else return f32_to_bf16(f);
+}
+template <bool F16>
+__device__ __forceinline__ float f32_from_h(unsigned short u) {
+    if constexpr (F16) return (float)*reinterpret_cast<_Float16 *>(&u);
+    else return bf16_to_f32(u);
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dim (C = 1024 or 256), one wave per row
+// ---------------------------------------------------------------------------
+template <int C, bool F16>
+__global__ void __launch_bounds__(256) k_layernorm(const unsigned short *__restrict__ x,
+                                                   const float *__restrict__ w,
+                                                   const float *__restrict__ b, int rows, float eps,
+                                                   unsigned short *__restrict__ out) {
+    constexpr int PER = C / 64;          // elements per lane: 16 or 4
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned short *xr = x + (size_t)row * C + lane * PER;
+    float v[PER];
+    if constexpr (PER == 16) {
+        uint4 a = *reinterpret_cast<const uint4 *>(xr), c = *reinterpret_cast<const uint4 *>(xr + 8);
+        unsigned u[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[2 * i] = f32_from_h<F16>(u[i] & 0xFFFF); v[2 * i + 1] = f32_from_h<F16>(u[i] >> 16); }
+    } else {
+        uint2 a = *reinterpret_cast<const uint2 *>(xr);
+        v[0] = f32_from_h<F16>(a.x & 0xFFFF); v[1] = f32_from_h<F16>(a.x >> 16);
+        v[2] = f32_from_h<F16>(a.y & 0xFFFF); v[3] = f32_from_h<F16>(a.y >> 16);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { float d = v[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / C) + eps);
+    unsigned short o16[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        float y = (v[i] - mean) * rstd * w[lane * PER + i] + b[lane * PER + i];
+        o16[i] = h_from_f32<F16>(y);
+    }
+    unsigned short *orow = out + (size_t)row * C + lane * PER;
+    if constexpr (PER == 16) {
+        uint4 a, c;
+        a.x = o16[0] | (o16[1] << 16); a.y = o16[2] | (o16[3] << 16); a.z = o16[4] | (o16[5] << 16); a.w = o16[6] | (o16[7] << 16);
+        c.x = o16[8] | (o16[9] << 16); c.y = o16[10] | (o16[11] << 16); c.z = o16[12] | (o16[13] << 16); c.w = o16[14] | (o16[15] << 16);
+        *reinterpret_cast<uint4 *>(orow) = a;
+        *reinterpret_cast<uint4 *>(orow + 8) = c;
+    } else {
+        uint2 a;
+        a.x = o16[0] | (o16[1] << 16); a.y = o16[2] | (o16[3] << 16);
+        *reinterpret_cast<uint2 *>(orow) = a;
+    }
+}
+
+extern "C" int cpx_layernorm_bf16(const void *x, const float *w, const float *b, int rows, int C,
+                                  float eps, void *out, void *stream) {
+    CPX_REQUIRE(x && w && b && out && rows > 0 && (C == 1024 || C == 256));
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(cpx_cdiv(rows, 4)), block(256);
+    const bool f16 = cpx_get_half_dtype();
+    if (C == 1024) {
+        if (f16) hipLaunchKernelGGL((k_layernorm<1024, true>), grid, block, 0, s, (const unsigned short *)x, w, b, rows, eps, (unsigned short *)out);
+        else hipLaunchKernelGGL((k_layernorm<1024, false>), grid, block, 0, s, (const unsigned short *)x, w, b, rows, eps, (unsigned short *)out);
+    } else {
+        if (f16) hipLaunchKernelGGL((k_layernorm<256, true>), grid, block, 0, s, (const unsigned short *)x, w, b, rows, eps, (unsigned short *)out);
+        else hipLaunchKernelGGL((k_layernorm<256, false>), grid, block, 0, s, (const unsigned short *)x, w, b, rows, eps, (unsigned short *)out);
+    }
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// V transpose: qkv[., 2048 + h*64 + d] -> vT[s][h][d][t]   (LDS tile transpose)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_v_transpose(const unsigned short *__restrict__ qkv,
+                                                     unsigned short *__restrict__ vT) {
+    __shared__ unsigned short tile[64][66];
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, s = blockIdx.z;
+    const int tid = threadIdx.x;
+    {   // 64 tokens x 64 d: thread -> (token = tid>>2, 16 d)
+        int tok = tid >> 2, c = (tid & 3) * 16;
+        const unsigned short *src = qkv + ((size_t)s * 1024 + t0 + tok) * 3072 + 2048 + h * 64 + c;
+        uint4 a = *reinterpret_cast<const uint4 *>(src), b = *reinterpret_cast<const uint4 *>(src + 8);
+        unsigned u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { tile[tok][c + 2 * i] = u[i] & 0xFFFF; tile[tok][c + 2 * i + 1] = u[i] >> 16; }
+    }
+    __syncthreads();
+    {   // thread -> (d = tid>>2, 16 tokens)
+        int d = tid >> 2, c = (tid & 3) * 16;
+        unsigned u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = tile[c + 2 * i][d] | ((unsigned)tile[c + 2 * i + 1][d] << 16);
+        unsigned short *dst = vT + (((size_t)s * 16 + h) * 64 + d) * 1024 + t0 + c;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(u[4], u[5], u[6], u[7]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// flash attention with decomposed rel-pos bias
+// ---------------------------------------------------------------------------
+#define ATT_THREADS 256
+#define GS_LD 65                       // padded row of the per-wave G scratch (floats)
+__device__ __forceinline__ int pi_perm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <bool F16>
+__global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short *__restrict__ qkv,
+                                                           const unsigned short *__restrict__ vT,
+                                                           const unsigned short *__restrict__ relh,
+                                                           const unsigned short *__restrict__ relw,
+                                                           unsigned short *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[2][32 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned short sV[2][64 * 32];
+    __shared__ float sG[4][32 * GS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int head = blockIdx.y, s = blockIdx.z;
+    const int qh = blockIdx.x * 4 + wave;                 // image row of this wave's queries
+    const size_t tok0 = (size_t)s * 1024;
+    const unsigned short *qrow = qkv + (tok0 + qh * 32 + r) * 3072 + head * 64;
+
+    // Q fragments (MFMA B operand): d = 16*ks + 8*h2 + j
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(qrow + 16 * ks + 8 * h2);
+
+    // G = Q . table^T  (tables hold rel_pos / scale, row 63 = 0) -> LDS scratch [q][j]
+    float *G = sG[wave];
+    float gw[16];
+    auto compute_G = [&](const unsigned short *table) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 tf = *reinterpret_cast<const uint4 *>(table + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+                acc = mfma32<F16>(tf, qf[ks], acc);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int j = jb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                G[r * GS_LD + j] = acc[i];
+            }
+        }
+    };
+    compute_G(relw);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int kw = pi_perm((i & 3) + 8 * (i >> 2) + 4 * h2);
+        gw[i] = G[r * GS_LD + (r - kw + 31)];
+    }
+    compute_G(relh);                                       // G now holds Gh for the key loop
+
+    // staging maps
+    const int k_key = tid >> 3, k_c = tid & 7;            // K tile: 32 keys x 8 chunks
+    const int v_d = tid >> 2, v_c = tid & 3;              // V^T tile: 64 d x 4 chunks
+    const unsigned short *kbase = qkv + (tok0 + k_key) * 3072 + 1024 + head * 64 + k_c * 8;
+    const unsigned short *vbase = vT + (((size_t)s * 16 + head) * 64 + v_d) * 1024 + v_c * 8;
+    const int k_dst = k_key * 64 + ((k_c ^ (k_key & 7)) * 8);
+    const int v_dst = v_d * 32 + ((v_c ^ ((v_d >> 2) & 3)) * 8);
+    uint4 kreg = *reinterpret_cast<const uint4 *>(kbase);
+    uint4 vreg = *reinterpret_cast<const uint4 *>(vbase);
+    *reinterpret_cast<uint4 *>(&sK[0][k_dst]) = kreg;
+    *reinterpret_cast<uint4 *>(&sV[0][v_dst]) = vreg;
+    __syncthreads();
+
+    f32x16 O[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    const float cexp = 0.125f * 1.44269504088896340736f;   // softmax scale (64^-0.5) * log2(e)
+    const int krow = pi_perm(r);                            // key row this lane feeds to the K operand
+
+    for (int kh = 0; kh < 32; ++kh) {
+        const int buf = kh & 1;
+        if (kh + 1 < 32) {
+            kreg = *reinterpret_cast<const uint4 *>(kbase + (size_t)(kh + 1) * 32 * 3072);
+            vreg = *reinterpret_cast<const uint4 *>(vbase + (kh + 1) * 32);
+        }
+        // S^T = K . Q^T, accumulator pre-loaded with the bias
+        const float gh = G[r * GS_LD + (qh - kh + 31)];
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = gw[i] + gh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 kf = *reinterpret_cast<const uint4 *>(&sK[buf][krow * 64 + (((2 * ks + h2) ^ (krow & 7)) * 8)]);
+            S = mfma32<F16>(kf, qf[ks], S);
+        }
+        // online softmax (per lane = per query; the two half-waves hold different keys)
+        float mx = S[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, S[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * cexp);
+        float psum = 0.f;
+        float p[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { p[i] = exp2f((S[i] - m_new) * cexp); psum += p[i]; }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+        // P^T (accumulator layout) -> B operand of the P.V product, natural key order
+        uint4 pf[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            unsigned u[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                u[jj] = (unsigned)h_from_f32<F16>(p[8 * st + 2 * jj]) | ((unsigned)h_from_f32<F16>(p[8 * st + 2 * jj + 1]) << 16);
+            pf[st] = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int d = db * 32 + r;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 vf = *reinterpret_cast<const uint4 *>(&sV[buf][d * 32 + (((2 * st + h2) ^ ((d >> 2) & 3)) * 8)]);
+                O[db] = mfma32<F16>(vf, pf[st], O[db]);
+            }
+        }
+        if (kh + 1 < 32) {
+            *reinterpret_cast<uint4 *>(&sK[buf ^ 1][k_dst]) = kreg;
+            *reinterpret_cast<uint4 *>(&sV[buf ^ 1][v_dst]) = vreg;
+        }
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    unsigned short *orow = out + (tok0 + qh * 32 + r) * 1024 + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = db * 32 + 8 * g4 + 4 * h2;
+            uint2 o;
+            o.x = (unsigned)h_from_f32<F16>(O[db][4 * g4 + 0] * inv) | ((unsigned)h_from_f32<F16>(O[db][4 * g4 + 1] * inv) << 16);
+            o.y = (unsigned)h_from_f32<F16>(O[db][4 * g4 + 2] * inv) | ((unsigned)h_from_f32<F16>(O[db][4 * g4 + 3] * inv) << 16);
+            *reinterpret_cast<uint2 *>(orow + d) = o;
+        }
+}
+
+extern "C" int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w,
+                                    int n_subtiles, void *vT_ws, void *out, void *stream) {
+    CPX_REQUIRE(qkv && rel_h && rel_w && vT_ws && out && n_subtiles > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
+                       (const unsigned short *)qkv, (unsigned short *)vT_ws);
+    dim3 grid(8, 16, n_subtiles);
+    if (cpx_get_half_dtype())
+        hipLaunchKernelGGL(k_attention<true>, grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
+                           (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
+                           (const unsigned short *)rel_w, (unsigned short *)out);
+    else
+        hipLaunchKernelGGL(k_attention<false>, grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
+                           (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
+                           (const unsigned short *)rel_w, (unsigned short *)out);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// im2col for the neck's 3x3 conv: [S*1024][256] -> [S*1024][9*256], k = tap*256 + c
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_im2col3(const unsigned short *__restrict__ x, size_t n_chunks,
+                                                 unsigned short *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // 16-byte chunk index of the output
+    if (i >= n_chunks) return;
+    size_t row = i / 288;
+    int rem = (int)(i - row * 288);
+    int tap = rem >> 5, c8 = rem & 31;
+    int tok = (int)(row & 1023);
+    int ph = tok >> 5, pw = tok & 31;
+    int yy = ph + tap / 3 - 1, xx = pw + tap % 3 - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((unsigned)yy < 32u && (unsigned)xx < 32u)
+        v = *reinterpret_cast<const uint4 *>(x + ((row & ~(size_t)1023) + yy * 32 + xx) * 256 + c8 * 8);
+    *reinterpret_cast<uint4 *>(out + row * 2304 + tap * 256 + c8 * 8) = v;
+}
+
+// ---------------------------------------------------------------------------
+// forward driver
+// ---------------------------------------------------------------------------
+struct NetWs {
+    size_t off_x, off_xn, off_qkv, off_vt, off_ao, off_h, off_neck, off_neck2, off_col, total;
+};
+static NetWs net_ws(int nS) {
+    NetWs w; size_t o = 0; const size_t M = (size_t)nS * 1024;
+    auto take = [&](size_t b) { size_t r = o; o = cpx_align_up(o + b, 256); return r; };
+    w.off_x = take(M * 1024 * 2);
+    w.off_xn = take(M * 1024 * 2);
+    w.off_qkv = take(M * 3072 * 2);
+    w.off_vt = take(M * 1024 * 2);
+    w.off_ao = take(M * 1024 * 2);
+    w.off_h = take(M * 4096 * 2);
+    w.off_neck = take(M * 256 * 2);
+    w.off_neck2 = take(M * 256 * 2);
+    w.off_col = take(M * 2304 * 2);
+    w.total = o;
+    return w;
+}
+extern "C" size_t cpx_net_workspace_bytes(int n_subtiles) {
+    return n_subtiles > 0 ? net_ws(n_subtiles).total : 0;
+}
+
+extern "C" void cpx_set_half_dtype(int f16);
+
+extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, int nS, float *head,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    CPX_REQUIRE(w && patches && head && workspace && nS > 0);
+    CPX_REQUIRE(w->depth > 0 && w->blocks && w->ld_head % 128 == 0 && w->ld_head >= w->n_head_cols);
+    NetWs L = net_ws(nS);
+    CPX_REQUIRE(workspace_bytes >= L.total);
+    cpx_set_half_dtype(w->dtype == 1);
+    char *ws = (char *)workspace;
+    const int M = nS * 1024;
+    void *x = ws + L.off_x, *xn = ws + L.off_xn, *qkv = ws + L.off_qkv, *vt = ws + L.off_vt,
+         *ao = ws + L.off_ao, *hb = ws + L.off_h, *nk = ws + L.off_neck, *nk2 = ws + L.off_neck2,
+         *col = ws + L.off_col;
+    int rc;
+#define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+    // patch embed (+bias +pos_embed)
+    RUN(cpx_gemm_bf16(patches, w->pe_w, M, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024, stream));
+    for (int i = 0; i < w->depth; ++i) {
+        const cpx_block_weights &b = w->blocks[i];
+        RUN(cpx_layernorm_bf16(x, b.ln1_w, b.ln1_b, M, 1024, 1e-6f, xn, stream));
+        RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, CPX_EPI_BF16, b.qkv_b, nullptr, qkv, 3072, stream));
+        RUN(cpx_attention_relpos(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream));
+        RUN(cpx_gemm_bf16(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, stream));
+        RUN(cpx_layernorm_bf16(x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
+        RUN(cpx_gemm_bf16(xn, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, stream));
+        RUN(cpx_gemm_bf16(hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, stream));
+    }
+    // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d
+    RUN(cpx_gemm_bf16(x, w->neck0_w, M, 256, 1024, CPX_EPI_BF16, nullptr, nullptr, nk, 256, stream));
+    RUN(cpx_layernorm_bf16(nk, w->neck_ln1_w, w->neck_ln1_b, M, 256, 1e-6f, nk2, stream));
+    {
+        size_t n_chunks = (size_t)M * 288;
+        hipLaunchKernelGGL(k_im2col3, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const unsigned short *)nk2, n_chunks, (unsigned short *)col);
+        CPX_CHECK_LAUNCH();
+    }
+    RUN(cpx_gemm_bf16(col, w->neck2_w, M, 256, 2304, CPX_EPI_BF16, nullptr, nullptr, nk, 256, stream));
+    RUN(cpx_layernorm_bf16(nk, w->neck_ln2_w, w->neck_ln2_b, M, 256, 1e-6f, nk2, stream));
+    // heads: out (192) | out_class (ncls*64), f32 token-major
+    RUN(cpx_gemm_bf16(nk2, w->head_w, M, w->ld_head, 256, CPX_EPI_F32, w->head_b, nullptr, head, w->ld_head, stream));
+#undef RUN
+    return CPX_OK;
+}

@@ -1,0 +1,1077 @@
+// Per-pixel post-processing of the classpose WSI tile path on gfx950:
+// flows -> Euler integration -> instance ids -> flow-error filter -> hole fill /
+// size filter -> class vote -> border removal -> per-instance records.
+//
+// Every kernel follows the CPU oracle (oracle/dynamics.py, oracle/classmask.py)
+// operation for operation; integer results are bit-exact, the float paths use the
+// same rounding sequence (this file is built with -ffp-contract=off and spells
+// out every fused multiply-add the reference's torch CPU kernels perform).
+//
+// Layout: all kernels are batched over tiles with blockIdx.y = tile and read /
+// write planar [tile][...][H][W] arrays, one thread per pixel along x so loads
+// and stores are coalesced; small per-label tables live in the caller's
+// workspace (no hidden allocation).
+#include "cpx_common.h"
+
+#define RPAD 20
+#define NTHR 256
+
+// ---------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------
+struct PPLayout {
+    int H, W, HW, Hp, Wp, HWp, L, TW, TH, THW;
+    size_t off_h1, off_M1, off_tmp, off_im, off_T, off_e, off_seed_pos, off_seed_cnt,
+        off_rank, off_cnt, off_first, off_remap, off_flag, off_bbox, off_sumy, off_sumx,
+        off_d2, off_center, off_err, off_cls, off_scal, per_tile;
+};
+#define PP_NSCAL 16
+#define SC_NSEEDS 0
+#define SC_NLAB 1
+#define SC_NITER 2
+#define SC_CONFLICT 3
+#define SC_HASBIG 4
+#define SC_HASBG 5
+#define SC_VMAX 6
+#define PP_MAXCLS 32
+
+static PPLayout pp_layout(int H, int W) {
+    PPLayout p;
+    p.H = H; p.W = W; p.HW = H * W; p.Hp = H + 2 * RPAD; p.Wp = W + 2 * RPAD;
+    p.HWp = p.Hp * p.Wp; p.L = p.HW / 11 + 2; p.TH = H + 2; p.TW = W + 2; p.THW = p.TH * p.TW;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = cpx_align_up(o + bytes, 256); return r; };
+    p.off_h1 = take(sizeof(int) * p.HWp);
+    p.off_M1 = take(sizeof(int) * p.HWp);
+    p.off_tmp = take(sizeof(int) * p.HW);
+    p.off_im = take(sizeof(float) * 2 * p.HW);
+    p.off_T = take(sizeof(double) * 2 * p.THW);
+    p.off_e = take(sizeof(double) * 2 * p.HW);
+    p.off_seed_pos = take(sizeof(int) * p.L);
+    p.off_seed_cnt = take(sizeof(int) * p.L);
+    p.off_rank = take(sizeof(int) * p.L);
+    p.off_cnt = take(sizeof(int) * p.L);
+    p.off_first = take(sizeof(int) * p.L);
+    p.off_remap = take(sizeof(int) * p.L);
+    p.off_flag = take(sizeof(int) * p.L);
+    p.off_bbox = take(sizeof(int) * 4 * p.L);
+    p.off_sumy = take(sizeof(unsigned long long) * p.L);
+    p.off_sumx = take(sizeof(unsigned long long) * p.L);
+    p.off_d2 = take(sizeof(unsigned long long) * p.L);
+    p.off_center = take(sizeof(int) * p.L);
+    p.off_err = take(sizeof(double) * p.L);
+    p.off_cls = take(sizeof(int) * (size_t)p.L * PP_MAXCLS);
+    p.off_scal = take(sizeof(int) * PP_NSCAL);
+    p.per_tile = o;
+    return p;
+}
+
+// workspace = [dense: masks32 nT*HW | p_final nT*HW] + nT per-tile blocks
+static size_t pp_dense_bytes(int nT, int H, int W) {
+    return cpx_align_up(sizeof(int) * (size_t)nT * H * W, 256) * 2;
+}
+static void *pp_tiles(void *workspace, int nT, int H, int W) {
+    return (char *)workspace + pp_dense_bytes(nT, H, W);
+}
+extern "C" size_t cpx_postproc_workspace_bytes(int nT, int H, int W) {
+    if (nT <= 0 || H <= 0 || W <= 0) return 0;
+    return pp_dense_bytes(nT, H, W) + pp_layout(H, W).per_tile * (size_t)nT;
+}
+extern "C" int cpx_postproc_max_labels(int H, int W) { return H * W / 11 + 2; }
+
+#define WS(T, field) ((T *)((char *)ws + (size_t)blockIdx.y * lay.per_tile + lay.field))
+
+// ---------------------------------------------------------------------------
+// a11  follow_flows
+// ---------------------------------------------------------------------------
+// im = (dP * (cellprob > thr) / 5) * (2 / (size-1))   [numpy fp32 ops, then torch fp32 scalar mul]
+__global__ void k_prep_flow(const float *__restrict__ dP, const float *__restrict__ cp, float thr,
+                            float kx, float ky, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    float m = cp[t * lay.HW + idx] > thr ? 1.0f : 0.0f;
+    float dy = dP[(t * 2 + 0) * lay.HW + idx];
+    float dx = dP[(t * 2 + 1) * lay.HW + idx];
+    float *im = WS(float, off_im);
+    im[idx] = __fdiv_rn(dx * m, 5.0f) * kx;               // im[0] = dX
+    im[lay.HW + idx] = __fdiv_rn(dy * m, 5.0f) * ky;      // im[1] = dY
+}
+
+__device__ __forceinline__ float tap(const float *im, int H, int W, int y, int x) {
+    return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? im[y * W + x] : 0.0f;
+}
+
+__global__ void k_follow(const float *__restrict__ cp, float thr, int niter, float shx, float shy,
+                         float hw, float hh, int32_t *__restrict__ p_final,
+                         float *__restrict__ p_float, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    const int H = lay.H, W = lay.W;
+    if (!(cp[t * lay.HW + idx] > thr)) {
+        p_final[t * lay.HW + idx] = -1;
+        if (p_float) { p_float[(t * 2) * lay.HW + idx] = -1.f; p_float[(t * 2 + 1) * lay.HW + idx] = -1.f; }
+        return;
+    }
+    const float *imx = WS(float, off_im);
+    const float *imy = imx + lay.HW;
+    int y = idx / W, x = idx - y * W;
+    float px = __fdiv_rn((float)x, shx);
+    float py = __fdiv_rn((float)y, shy);
+    px = px * 2.0f; px = px - 1.0f;
+    py = py * 2.0f; py = py - 1.0f;
+    for (int it = 0; it < niter; ++it) {
+        float fx = __fmaf_rn(px + 1.0f, hw, -0.5f);
+        float fy = __fmaf_rn(py + 1.0f, hh, -0.5f);
+        float x_w = floorf(fx), y_n = floorf(fy);
+        float w = fx - x_w, e = 1.0f - w, n = fy - y_n, s = 1.0f - n;
+        float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+        int x0 = (int)x_w, y0 = (int)y_n;
+        float dx = __fmaf_rn(tap(imx, H, W, y0 + 1, x0 + 1), se,
+                   __fmaf_rn(tap(imx, H, W, y0 + 1, x0), sw,
+                   __fmaf_rn(tap(imx, H, W, y0, x0 + 1), ne, tap(imx, H, W, y0, x0) * nw)));
+        float dy = __fmaf_rn(tap(imy, H, W, y0 + 1, x0 + 1), se,
+                   __fmaf_rn(tap(imy, H, W, y0 + 1, x0), sw,
+                   __fmaf_rn(tap(imy, H, W, y0, x0 + 1), ne, tap(imy, H, W, y0, x0) * nw)));
+        px = px + dx; px = px < -1.0f ? -1.0f : (px > 1.0f ? 1.0f : px);
+        py = py + dy; py = py < -1.0f ? -1.0f : (py > 1.0f ? 1.0f : py);
+    }
+    px = px + 1.0f; px = px * 0.5f; px = px * shx;
+    py = py + 1.0f; py = py * 0.5f; py = py * shy;
+    if (p_float) { p_float[(t * 2) * lay.HW + idx] = py; p_float[(t * 2 + 1) * lay.HW + idx] = px; }
+    int iy = (int)py, ix = (int)px;            // .int(): truncation toward zero
+    p_final[t * lay.HW + idx] = (iy << 16) | (ix & 0xFFFF);
+}
+
+// ---------------------------------------------------------------------------
+// a12  get_masks
+// ---------------------------------------------------------------------------
+__global__ void k_zero_i32(int *p, size_t per_tile_stride_bytes, size_t off, int n) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= n) return;
+    ((int *)((char *)p + (size_t)blockIdx.y * per_tile_stride_bytes + off))[idx] = 0;
+}
+
+__global__ void k_hist(const int32_t *__restrict__ p_final, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int p = p_final[(size_t)blockIdx.y * lay.HW + idx];
+    if (p == -1) return;
+    int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
+    py = max(py, 0); px = max(px, 0);
+    py = min(py, lay.H + RPAD - 1); px = min(px, lay.W + RPAD - 1);
+    atomicAdd(&WS(int, off_h1)[py * lay.Wp + px], 1);
+}
+
+// seeds = (h == 5x5 max) & (h > 10); collected unordered, ranked afterwards
+__global__ void k_seeds(PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HWp) return;
+    const int *h1 = WS(int, off_h1);
+    int h = h1[idx];
+    if (h <= 10) return;
+    int y = idx / lay.Wp, x = idx - y * lay.Wp;
+    int mx = 0;
+    for (int dy = -2; dy <= 2; ++dy) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= lay.Hp) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            int xx = x + dx;
+            if (xx < 0 || xx >= lay.Wp) continue;
+            mx = max(mx, h1[yy * lay.Wp + xx]);
+        }
+    }
+    if (h == mx) {
+        int slot = atomicAdd(&WS(int, off_scal)[SC_NSEEDS], 1);
+        if (slot < lay.L) {
+            WS(int, off_seed_pos)[slot] = idx;
+            WS(int, off_seed_cnt)[slot] = h;
+        }
+    }
+}
+
+// rank = position in the stable ascending sort by (count, raster index)
+__global__ void k_seed_rank(PPLayout lay, void *ws) {
+    int n = min(WS(int, off_scal)[SC_NSEEDS], lay.L);
+    int k = blockIdx.x * NTHR + threadIdx.x;
+    if (k >= n) return;
+    const int *pos = WS(int, off_seed_pos);
+    const int *cnt = WS(int, off_seed_cnt);
+    int c = cnt[k], p = pos[k], r = 0;
+    for (int j = 0; j < n; ++j) {
+        int cj = cnt[j], pj = pos[j];
+        r += (cj < c) || (cj == c && pj < p);
+    }
+    WS(int, off_rank)[k] = r;
+}
+
+// 11x11 window, 5 x (3x3 dilation & (h > 2)); label = rank+1, later (larger) wins
+__global__ void k_seed_grow(PPLayout lay, void *ws) {
+    int n = min(WS(int, off_scal)[SC_NSEEDS], lay.L);
+    int k = blockIdx.x * NTHR + threadIdx.x;
+    if (k >= n) return;
+    const int *h1 = WS(int, off_h1);
+    int p = WS(int, off_seed_pos)[k];
+    int label = WS(int, off_rank)[k] + 1;
+    int sy = p / lay.Wp, sx = p - sy * lay.Wp;
+    unsigned allowed[11], m[11];
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+        unsigned a = 0;
+        int yy = sy - 5 + r;
+        for (int c = 0; c < 11; ++c) {
+            int xx = sx - 5 + c;
+            int h = ((unsigned)yy < (unsigned)lay.Hp && (unsigned)xx < (unsigned)lay.Wp) ? h1[yy * lay.Wp + xx] : 0;
+            a |= (h > 2 ? 1u : 0u) << c;
+        }
+        allowed[r] = a;
+        m[r] = 0;
+    }
+    m[5] = 1u << 5;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        unsigned hrow[11];
+#pragma unroll
+        for (int r = 0; r < 11; ++r) hrow[r] = (m[r] | (m[r] << 1) | (m[r] >> 1)) & 0x7FFu;
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {
+            unsigned v = hrow[r];
+            if (r > 0) v |= hrow[r - 1];
+            if (r < 10) v |= hrow[r + 1];
+            m[r] = v & allowed[r];
+        }
+    }
+    int *M1 = WS(int, off_M1);
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+        unsigned v = m[r];
+        while (v) {
+            int c = __ffs(v) - 1;
+            v &= v - 1;
+            atomicMax(&M1[(sy - 5 + r) * lay.Wp + (sx - 5 + c)], label);
+        }
+    }
+}
+
+// label gather + per-label pixel count (label 0 not counted)
+__global__ void k_gather(const int32_t *__restrict__ p_final, int32_t *__restrict__ masks,
+                         PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int p = p_final[t * lay.HW + idx];
+    int lab = 0;
+    if (p != -1) {
+        int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
+        py = min(max(py, 0), lay.H + RPAD - 1); px = min(max(px, 0), lay.W + RPAD - 1);
+        lab = WS(int, off_M1)[py * lay.Wp + px];
+    }
+    masks[t * lay.HW + idx] = lab;
+    if (lab > 0) atomicAdd(&WS(int, off_cnt)[lab], 1);
+}
+
+// big-mask removal (count > H*W*fraction) + first raster index per surviving label
+__global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    if (lab <= 0) return;
+    if ((double)WS(int, off_cnt)[lab] > big) { masks[t * lay.HW + idx] = 0; return; }
+    atomicMin(&WS(int, off_first)[lab], idx);
+}
+
+// generic: first raster index per label (labels < L)
+__global__ void k_first(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
+    if (lab > 0) atomicMin(&WS(int, off_first)[lab], idx);
+}
+
+__global__ void k_fill_i32(size_t off, int n, int value, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= n) return;
+    ((int *)((char *)ws + (size_t)blockIdx.y * lay.per_tile + off))[idx] = value;
+}
+
+// fastremap.renumber: new id = 1 + #labels whose first appearance is earlier.
+// vmax_slot: scalar holding the largest label value that can occur (exclusive bound = value+1)
+__global__ void k_renumber_rank(int vmax_slot, PPLayout lay, void *ws) {
+    int vmax = min(WS(int, off_scal)[vmax_slot], lay.L - 1);
+    int v = blockIdx.x * NTHR + threadIdx.x + 1;
+    if (v > vmax) return;
+    const int *first = WS(int, off_first);
+    int f = first[v];
+    int *remap = WS(int, off_remap);
+    if (f == 0x7FFFFFFF) { remap[v] = 0; return; }
+    int r = 1;
+    for (int j = 1; j <= vmax; ++j) r += first[j] < f;
+    remap[v] = r;
+    atomicMax(&WS(int, off_scal)[SC_NLAB], r);
+}
+
+__global__ void k_relabel(int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    if (lab > 0) masks[t * lay.HW + idx] = WS(int, off_remap)[lab];
+}
+
+__global__ void k_store_scalar(int slot, int32_t *__restrict__ out, PPLayout lay, void *ws) {
+    if (threadIdx.x == 0) out[blockIdx.y] = WS(int, off_scal)[slot];
+}
+__global__ void k_copy_scalar(int dst, int src, PPLayout lay, void *ws) {
+    if (threadIdx.x == 0) WS(int, off_scal)[dst] = WS(int, off_scal)[src];
+}
+
+// ---------------------------------------------------------------------------
+// a13  flow-error filter
+// ---------------------------------------------------------------------------
+// per-label bbox / count / coordinate sums
+__global__ void k_lab_stats(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
+    if (lab <= 0) return;
+    int y = idx / lay.W, x = idx - y * lay.W;
+    int *bb = WS(int, off_bbox) + 4 * lab;
+    atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x);
+    atomicAdd(&WS(int, off_cnt)[lab], 1);
+    atomicAdd(&WS(unsigned long long, off_sumy)[lab], (unsigned long long)y);
+    atomicAdd(&WS(unsigned long long, off_sumx)[lab], (unsigned long long)x);
+}
+
+__global__ void k_init_stats(PPLayout lay, void *ws) {
+    int v = blockIdx.x * NTHR + threadIdx.x;
+    if (v >= lay.L) return;
+    int *bb = WS(int, off_bbox) + 4 * v;
+    bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
+    WS(int, off_cnt)[v] = 0;
+    WS(unsigned long long, off_sumy)[v] = 0;
+    WS(unsigned long long, off_sumx)[v] = 0;
+    WS(unsigned long long, off_d2)[v] = 0xFFFFFFFFFFFFFFFFull;
+    WS(int, off_center)[v] = 0x7FFFFFFF;
+    WS(int, off_flag)[v] = 0;
+    WS(int, off_first)[v] = 0x7FFFFFFF;
+}
+
+__device__ __forceinline__ double center_d2(int y, int x, const int *bb, int n,
+                                            unsigned long long sy, unsigned long long sx) {
+    // yi, xi are bbox-relative; ymed = yi.mean(), xmed = xi.mean() (exact int sums / n)
+    double ymed = (double)((long long)sy - (long long)n * bb[0]) / (double)n;
+    double xmed = (double)((long long)sx - (long long)n * bb[1]) / (double)n;
+    double dx = (double)(x - bb[1]) - xmed;
+    double dy = (double)(y - bb[0]) - ymed;
+    double a = dx * dx;
+    double b = dy * dy;
+    return a + b;
+}
+
+__global__ void k_center_d2(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
+    if (lab <= 0) return;
+    int y = idx / lay.W, x = idx - y * lay.W;
+    double d2 = center_d2(y, x, WS(int, off_bbox) + 4 * lab, WS(int, off_cnt)[lab],
+                          WS(unsigned long long, off_sumy)[lab], WS(unsigned long long, off_sumx)[lab]);
+    atomicMin(&WS(unsigned long long, off_d2)[lab], (unsigned long long)__double_as_longlong(d2));
+}
+
+__global__ void k_center_pick(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
+    if (lab <= 0) return;
+    int y = idx / lay.W, x = idx - y * lay.W;
+    int *bb = WS(int, off_bbox) + 4 * lab;
+    double d2 = center_d2(y, x, bb, WS(int, off_cnt)[lab],
+                          WS(unsigned long long, off_sumy)[lab], WS(unsigned long long, off_sumx)[lab]);
+    if ((unsigned long long)__double_as_longlong(d2) == WS(unsigned long long, off_d2)[lab])
+        atomicMin(&WS(int, off_center)[lab], idx);
+}
+
+__global__ void k_niter(PPLayout lay, void *ws) {
+    int v = blockIdx.x * NTHR + threadIdx.x + 1;
+    if (v >= lay.L) return;
+    if (WS(int, off_cnt)[v] <= 0) return;
+    const int *bb = WS(int, off_bbox) + 4 * v;
+    int ext = (bb[2] - bb[0] + 1) + (bb[3] - bb[1] + 1) + 2;
+    atomicMax(&WS(int, off_scal)[SC_NITER], 2 * ext);
+    atomicMax(&WS(int, off_scal)[SC_VMAX], v);
+}
+
+// heat diffusion from the centre inside one label (fp64 Jacobi, 9-neighbour mean
+// summed in neighbour order 0..8 then / 9).  One workgroup per (label, tile).
+#define DIFF_LDS_CELLS 3584     // (bh+2)*(bw+2) <= this -> T ping-pong in LDS (56 KB) + flags
+__global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ masks, PPLayout lay,
+                                                  void *ws) {
+    __shared__ double sT[2 * DIFF_LDS_CELLS];
+    __shared__ unsigned char sL[DIFF_LDS_CELLS];
+    int lab = blockIdx.x + 1;
+    if (lab >= lay.L) return;
+    int n = WS(int, off_cnt)[lab];
+    if (n <= 0) return;
+    const int *bb = WS(int, off_bbox) + 4 * lab;
+    const int y0 = bb[0], x0 = bb[1];
+    const int bh = bb[2] - y0 + 1, bw = bb[3] - x0 + 1;
+    const int ph = bh + 2, pw = bw + 2, cells = ph * pw;
+    const int niter = WS(int, off_scal)[SC_NITER];
+    const int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const int cidx = WS(int, off_center)[lab];
+    const int cy = cidx / lay.W - y0 + 1, cx = cidx % lay.W - x0 + 1;
+    double *Tg = WS(double, off_T);                      // [THW] final T (shared by all labels)
+    const int off9[9] = {0, -pw, pw, -1, 1, -pw - 1, -pw + 1, pw - 1, pw + 1};
+    if (cells <= DIFF_LDS_CELLS) {
+        for (int c = threadIdx.x; c < cells; c += NTHR) {
+            int ly = c / pw, lx = c - ly * pw;
+            int gy = y0 + ly - 1, gx = x0 + lx - 1;
+            bool in = ly >= 1 && ly <= bh && lx >= 1 && lx <= bw && m[gy * lay.W + gx] == lab;
+            sL[c] = in;
+            sT[c] = 0.0;
+            sT[DIFF_LDS_CELLS + c] = 0.0;
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int it = 0; it < niter; ++it) {
+            double *To = sT + cur * DIFF_LDS_CELLS, *Tn = sT + (cur ^ 1) * DIFF_LDS_CELLS;
+            if (threadIdx.x == 0) To[cy * pw + cx] += 1.0;
+            __syncthreads();
+            for (int c = threadIdx.x; c < cells; c += NTHR) {
+                if (!sL[c]) continue;
+                double s = To[c];
+#pragma unroll
+                for (int k = 1; k < 9; ++k) {
+                    int q = c + off9[k];
+                    if (sL[q]) s = s + To[q];
+                }
+                Tn[c] = s / 9.0;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        const double *Tf = sT + cur * DIFF_LDS_CELLS;
+        for (int c = threadIdx.x; c < cells; c += NTHR) {
+            if (!sL[c]) continue;
+            int ly = c / pw, lx = c - ly * pw;
+            Tg[(y0 + ly) * lay.TW + (x0 + lx)] = Tf[c];     // padded coords: (gy+1, gx+1)
+        }
+    } else {
+        // big bbox: ping-pong directly in the global padded T planes (own pixels only)
+        double *T0 = Tg, *T1 = Tg + lay.THW;
+        int cur = 0;
+        for (int it = 0; it < niter; ++it) {
+            double *To = cur ? T1 : T0, *Tn = cur ? T0 : T1;
+            if (threadIdx.x == 0) To[(y0 + cy) * lay.TW + (x0 + cx)] += 1.0;
+            __syncthreads();
+            for (int c = threadIdx.x; c < bh * bw; c += NTHR) {
+                int ly = c / bw, lx = c - ly * bw;
+                int gy = y0 + ly, gx = x0 + lx;
+                if (m[gy * lay.W + gx] != lab) continue;
+                const int dyv[9] = {0, -1, 1, 0, 0, -1, -1, 1, 1};
+                const int dxv[9] = {0, 0, 0, -1, 1, -1, 1, -1, 1};
+                double s = To[(gy + 1) * lay.TW + gx + 1];
+#pragma unroll
+                for (int k = 1; k < 9; ++k) {
+                    int yy = gy + dyv[k], xx = gx + dxv[k];
+                    if ((unsigned)yy < (unsigned)lay.H && (unsigned)xx < (unsigned)lay.W &&
+                        m[yy * lay.W + xx] == lab)
+                        s = s + To[(yy + 1) * lay.TW + xx + 1];
+                }
+                Tn[(gy + 1) * lay.TW + gx + 1] = s / 9.0;
+            }
+            __threadfence_block();
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (cur == 1) {     // final values sit in T1: copy own pixels to plane 0
+            for (int c = threadIdx.x; c < bh * bw; c += NTHR) {
+                int ly = c / bw, lx = c - ly * bw;
+                int gy = y0 + ly, gx = x0 + lx;
+                if (m[gy * lay.W + gx] == lab) T0[(gy + 1) * lay.TW + gx + 1] = T1[(gy + 1) * lay.TW + gx + 1];
+            }
+        }
+    }
+}
+
+// per-pixel squared error between mask-derived unit flows and network flows / 5
+__global__ void k_flow_err_pix(const int32_t *__restrict__ masks, const float *__restrict__ dP,
+                               PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    if (lab <= 0) return;
+    int y = idx / lay.W, x = idx - y * lay.W;
+    const double *T = WS(double, off_T);
+    int c = (y + 1) * lay.TW + (x + 1);
+    double dy = T[c + lay.TW] - T[c - lay.TW];
+    double dx = T[c + 1] - T[c - 1];
+    double a = dy * dy;
+    double b = dx * dx;
+    double den = 1e-60 + sqrt(a + b);
+    double muy = dy / den, mux = dx / den;
+    double vy = (double)__fdiv_rn(dP[(t * 2 + 0) * lay.HW + idx], 5.0f);
+    double vx = (double)__fdiv_rn(dP[(t * 2 + 1) * lay.HW + idx], 5.0f);
+    double ey = muy - vy, ex = mux - vx;
+    double *e = WS(double, off_e);
+    e[idx] = ey * ey;
+    e[lay.HW + idx] = ex * ex;
+}
+
+// scipy.ndimage.mean: per-label sums accumulated in raster order (np.bincount), / count
+__global__ void k_flow_err_label(const int32_t *__restrict__ masks, double thr,
+                                 double *__restrict__ errs_out, PPLayout lay, void *ws) {
+    int v = blockIdx.x * NTHR + threadIdx.x + 1;
+    if (v >= lay.L) return;
+    int n = WS(int, off_cnt)[v];
+    if (n <= 0) { if (errs_out) errs_out[(size_t)blockIdx.y * lay.L + v - 1] = 0.0; return; }
+    const int *bb = WS(int, off_bbox) + 4 * v;
+    const int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const double *e = WS(double, off_e);
+    double sy = 0.0, sx = 0.0;
+    for (int y = bb[0]; y <= bb[2]; ++y)
+        for (int x = bb[1]; x <= bb[3]; ++x)
+            if (m[y * lay.W + x] == v) { sy = sy + e[y * lay.W + x]; sx = sx + e[lay.HW + y * lay.W + x]; }
+    double err = 0.0;
+    err = err + sy / (double)n;
+    err = err + sx / (double)n;
+    WS(double, off_err)[v] = err;
+    if (errs_out) errs_out[(size_t)blockIdx.y * lay.L + v - 1] = err;
+    WS(int, off_flag)[v] = err > thr ? 1 : 0;
+}
+
+__global__ void k_zero_flagged(int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    if (lab > 0 && WS(int, off_flag)[lab]) masks[t * lay.HW + idx] = 0;
+}
+
+__global__ void k_zero_f64(size_t off, int n, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= n) return;
+    ((double *)((char *)ws + (size_t)blockIdx.y * lay.per_tile + off))[idx] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// a14  fill_holes_and_remove_small_masks
+// ---------------------------------------------------------------------------
+__global__ void k_count_labels(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
+    if (lab > 0) {
+        atomicAdd(&WS(int, off_cnt)[lab], 1);
+        atomicMax(&WS(int, off_scal)[SC_VMAX], lab);
+    } else {
+        WS(int, off_scal)[SC_HASBG] = 1;
+    }
+}
+
+// counts = unique(masks, return_counts=True)[1][1:]; remove label VALUE (i+1) where
+// counts[i] < min_size  -- positional indexing, reference quirk kept (see oracle).
+// One workgroup per tile (serial prefix over <= L labels, L is small).
+__global__ void __launch_bounds__(1024) k_size_filter(int min_size, PPLayout lay, void *ws) {
+    __shared__ int s_part[1024];
+    const int vmax = min(WS(int, off_scal)[SC_VMAX], lay.L - 1);
+    const int hasbg = WS(int, off_scal)[SC_HASBG];
+    const int *cnt = WS(int, off_cnt);
+    int *flag = WS(int, off_flag);
+    const int per = (vmax + 1024) / 1024;          // labels per thread
+    const int lo = 1 + threadIdx.x * per, hi = min(lo + per - 1, vmax);
+    int c = 0;
+    for (int v = lo; v <= hi; ++v) c += cnt[v] > 0;
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { int t = s_part[i]; s_part[i] = run; run += t; }
+    }
+    __syncthreads();
+    int rank = s_part[threadIdx.x];               // #present nonzero labels below lo
+    for (int v = lo; v <= hi; ++v) {
+        if (cnt[v] <= 0) continue;
+        ++rank;                                    // 1-based rank among present nonzero labels
+        int pos = hasbg ? rank - 1 : rank - 2;     // index into counts[1:]
+        if (pos >= 0 && cnt[v] < min_size) atomicExch(&flag[pos + 1], 1);
+    }
+}
+
+// 64-bit Kogge-Stone flood along a row: spread set bits of o through runs of `fr`
+__device__ __forceinline__ unsigned long long hfill(unsigned long long o, unsigned long long fr) {
+    unsigned long long x = o, f = fr;
+    x |= f & (x << 1); f &= (f << 1);
+    x |= f & (x << 2); f &= (f << 2);
+    x |= f & (x << 4); f &= (f << 4);
+    x |= f & (x << 8); f &= (f << 8);
+    x |= f & (x << 16); f &= (f << 16);
+    x |= f & (x << 32);
+    unsigned long long y = o | x; f = fr;
+    y |= f & (y >> 1); f &= (f >> 1);
+    y |= f & (y >> 2); f &= (f >> 2);
+    y |= f & (y >> 4); f &= (f >> 4);
+    y |= f & (y >> 8); f &= (f >> 8);
+    y |= f & (y >> 16); f &= (f >> 16);
+    y |= f & (y >> 32);
+    return y;
+}
+
+// Parallel hole fill: one wave per label, lanes = bbox rows, 64-bit row masks.
+// Reads `src` (pre-fill copy), writes holes into `masks`.  Exact w.r.t. the
+// sequential reference loop iff no hole contains a pixel of another label; that
+// case (and bboxes > 64) is flagged and redone sequentially by k_fill_serial.
+__global__ void __launch_bounds__(NTHR) k_fill_parallel(int32_t *__restrict__ masks, PPLayout lay,
+                                                        void *ws) {
+    const int lane = threadIdx.x & 63;
+    const int lab = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6) + 1;
+    const int nlab = WS(int, off_scal)[SC_NLAB];
+    if (lab > nlab) return;
+    const int *bb = WS(int, off_bbox) + 4 * lab;
+    if (WS(int, off_cnt)[lab] <= 0) return;
+    const int y0 = bb[0], x0 = bb[1], bh = bb[2] - y0 + 1, bw = bb[3] - x0 + 1;
+    if (bh > 64 || bw > 64) { if (lane == 0) WS(int, off_scal)[SC_HASBIG] = 1; return; }
+    const int32_t *src = WS(int32_t, off_tmp);
+    int32_t *dst = masks + (size_t)blockIdx.y * lay.HW;
+    unsigned long long m = 0, other = 0;
+    const unsigned long long wmask = bw == 64 ? ~0ull : ((1ull << bw) - 1);
+    if (lane < bh) {
+        const int32_t *row = src + (y0 + lane) * lay.W + x0;
+        for (int c = 0; c < bw; ++c) {
+            int v = row[c];
+            m |= (unsigned long long)(v == lab) << c;
+            other |= (unsigned long long)(v != lab && v != 0) << c;
+        }
+    }
+    unsigned long long fr = lane < bh ? (~m & wmask) : 0;
+    unsigned long long o = 0;
+    if (lane < bh) {
+        o = (lane == 0 || lane == bh - 1) ? fr : (fr & (1ull | (1ull << (bw - 1))));
+        o = hfill(o, fr);
+    }
+    while (true) {
+        unsigned long long up = __shfl_up(o, 1), dn = __shfl_down(o, 1);
+        if (lane == 0) up = 0;
+        if (lane >= bh - 1) dn = 0;
+        unsigned long long nn = hfill(o | ((up | dn) & fr), fr);
+        bool ch = nn != o;
+        o = nn;
+        if (!__any(ch)) break;
+    }
+    unsigned long long holes = fr & ~o;
+    if (holes & other) WS(int, off_scal)[SC_CONFLICT] = 1;
+    if (lane < bh) {
+        int32_t *row = dst + (y0 + lane) * lay.W + x0;
+        while (holes) {
+            int c = __ffsll((long long)holes) - 1;
+            holes &= holes - 1;
+            row[c] = lab;
+        }
+    }
+}
+
+// Sequential exact fallback (one workgroup per tile), only when flagged.
+// scratch `out`side map lives in h1 (int per pixel of the padded frame, >= HW ints).
+__global__ void __launch_bounds__(NTHR) k_fill_serial(int32_t *__restrict__ masks, PPLayout lay,
+                                                      void *ws) {
+    __shared__ int s_changed;
+    if (!(WS(int, off_scal)[SC_CONFLICT] || WS(int, off_scal)[SC_HASBIG])) return;
+    const int nlab = WS(int, off_scal)[SC_NLAB];
+    int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const int32_t *src = WS(int32_t, off_tmp);
+    int *outm = WS(int, off_h1);
+    for (int i = threadIdx.x; i < lay.HW; i += NTHR) m[i] = src[i];   // restart from pre-fill map
+    __threadfence_block();
+    __syncthreads();
+    for (int lab = 1; lab <= nlab; ++lab) {
+        const int *bb = WS(int, off_bbox) + 4 * lab;      // find_objects() taken before the loop
+        if (WS(int, off_cnt)[lab] <= 0) continue;
+        const int y0 = bb[0], x0 = bb[1], bh = bb[2] - y0 + 1, bw = bb[3] - x0 + 1;
+        for (int c = threadIdx.x; c < bh * bw; c += NTHR) {
+            int ly = c / bw, lx = c - ly * bw;
+            bool isl = m[(y0 + ly) * lay.W + x0 + lx] == lab;
+            bool edge = ly == 0 || lx == 0 || ly == bh - 1 || lx == bw - 1;
+            outm[c] = (!isl && edge) ? 1 : 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        while (true) {
+            if (threadIdx.x == 0) s_changed = 0;
+            __syncthreads();
+            int changed = 0;
+            for (int r = threadIdx.x; r < bh; r += NTHR) {       // row sweeps, both directions
+                const int32_t *mr = m + (y0 + r) * lay.W + x0;
+                int *orow = outm + r * bw;
+                int prev = 0;
+                for (int c = 0; c < bw; ++c) {
+                    bool fr = mr[c] != lab;
+                    if (fr && !orow[c] && prev) { orow[c] = 1; changed = 1; }
+                    prev = fr ? orow[c] : 0;
+                }
+                prev = 0;
+                for (int c = bw - 1; c >= 0; --c) {
+                    bool fr = mr[c] != lab;
+                    if (fr && !orow[c] && prev) { orow[c] = 1; changed = 1; }
+                    prev = fr ? orow[c] : 0;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int c = threadIdx.x; c < bw; c += NTHR) {       // column sweeps
+                int prev = 0;
+                for (int r = 0; r < bh; ++r) {
+                    bool fr = m[(y0 + r) * lay.W + x0 + c] != lab;
+                    int *o = outm + r * bw + c;
+                    if (fr && !*o && prev) { *o = 1; changed = 1; }
+                    prev = fr ? *o : 0;
+                }
+                prev = 0;
+                for (int r = bh - 1; r >= 0; --r) {
+                    bool fr = m[(y0 + r) * lay.W + x0 + c] != lab;
+                    int *o = outm + r * bw + c;
+                    if (fr && !*o && prev) { *o = 1; changed = 1; }
+                    prev = fr ? *o : 0;
+                }
+            }
+            if (changed) s_changed = 1;
+            __threadfence_block();
+            __syncthreads();
+            int again = s_changed;
+            __syncthreads();
+            if (!again) break;
+        }
+        for (int c = threadIdx.x; c < bh * bw; c += NTHR) {
+            int ly = c / bw, lx = c - ly * bw;
+            int32_t *px = m + (y0 + ly) * lay.W + x0 + lx;
+            if (*px != lab && !outm[c]) *px = lab;           // hole -> label
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ void k_copy_to_tmp(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    WS(int32_t, off_tmp)[idx] = masks[(size_t)blockIdx.y * lay.HW + idx];
+}
+
+// ---------------------------------------------------------------------------
+// a15  class vote     a16  border removal     records
+// ---------------------------------------------------------------------------
+__global__ void k_class_count(const int32_t *__restrict__ masks, const float *__restrict__ logits,
+                              int ncls, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    if (lab <= 0) return;
+    const float *lg = logits + t * ncls * lay.HW + idx;
+    float best = lg[0];
+    int bi = 0;
+    for (int c = 1; c < ncls; ++c) {
+        float v = lg[(size_t)c * lay.HW];
+        if (v > best) { best = v; bi = c; }        // first maximum wins (np.argmax)
+    }
+    atomicAdd(&WS(int, off_cls)[lab * PP_MAXCLS + bi], 1);
+}
+
+__global__ void k_class_pick(int ncls, PPLayout lay, void *ws) {
+    int v = blockIdx.x * NTHR + threadIdx.x;
+    if (v >= lay.L) return;
+    const int *c = WS(int, off_cls) + v * PP_MAXCLS;
+    int best = c[0], bi = 0;
+    for (int k = 1; k < ncls; ++k) if (c[k] > best) { best = c[k]; bi = k; }
+    WS(int, off_remap)[v] = v == 0 ? 0 : bi;
+}
+
+__global__ void k_class_write(const int32_t *__restrict__ masks, uint8_t *__restrict__ cm,
+                              PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    cm[t * lay.HW + idx] = lab > 0 ? (uint8_t)WS(int, off_remap)[lab] : 0;
+}
+
+__global__ void k_border_flag(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int i = blockIdx.x * NTHR + threadIdx.x;
+    const int H = lay.H, W = lay.W;
+    if (i >= 2 * (H + W)) return;
+    int y, x;
+    if (i < W) { y = 0; x = i; }
+    else if (i < 2 * W) { y = H - 1; x = i - W; }
+    else if (i < 2 * W + H) { y = i - 2 * W; x = 0; }
+    else { y = i - 2 * W - H; x = W - 1; }
+    int lab = masks[(size_t)blockIdx.y * lay.HW + y * W + x];
+    if (lab > 0 && lab < lay.L) WS(int, off_flag)[lab] = 1;
+}
+
+__global__ void k_border_zero(int32_t *__restrict__ masks, uint8_t *__restrict__ cm, PPLayout lay,
+                              void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    size_t t = blockIdx.y;
+    int lab = masks[t * lay.HW + idx];
+    if (lab > 0 && WS(int, off_flag)[lab]) {
+        masks[t * lay.HW + idx] = 0;
+        if (cm) cm[t * lay.HW + idx] = 0;
+    }
+}
+
+__global__ void k_to_u16(const int32_t *__restrict__ masks, uint16_t *__restrict__ out, size_t n) {
+    size_t idx = (size_t)blockIdx.x * NTHR + threadIdx.x;
+    if (idx < n) out[idx] = (uint16_t)masks[idx];
+}
+
+__global__ void k_rec_stats(const uint16_t *__restrict__ masks, PPLayout lay, void *ws) {
+    int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx >= lay.HW) return;
+    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
+    if (lab <= 0 || lab >= lay.L) return;
+    int y = idx / lay.W, x = idx - y * lay.W;
+    int *bb = WS(int, off_bbox) + 4 * lab;
+    atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x);
+    atomicAdd(&WS(int, off_cnt)[lab], 1);
+    atomicAdd(&WS(unsigned long long, off_sumy)[lab], (unsigned long long)y);
+    atomicAdd(&WS(unsigned long long, off_sumx)[lab], (unsigned long long)x);
+    atomicMin(&WS(int, off_first)[lab], idx);
+    atomicMax(&WS(int, off_scal)[SC_VMAX], lab);
+}
+
+__global__ void k_rec_write(const uint8_t *__restrict__ cm, int max_rec, cpx_record *__restrict__ rec,
+                            int32_t *__restrict__ counts, PPLayout lay, void *ws) {
+    int v = blockIdx.x * NTHR + threadIdx.x + 1;
+    if (v >= lay.L) return;
+    int n = WS(int, off_cnt)[v];
+    if (n <= 0) return;
+    // records are emitted at slot label-1 (labels are contiguous after renumber);
+    // counts[tile] = max label
+    if (v - 1 < max_rec) {
+        cpx_record r;
+        const int *bb = WS(int, off_bbox) + 4 * v;
+        r.tile = blockIdx.y; r.label = v;
+        r.cls = cm ? cm[(size_t)blockIdx.y * lay.HW + WS(int, off_first)[v]] : 0;
+        r.area = n; r.y0 = bb[0]; r.x0 = bb[1]; r.y1 = bb[2] + 1; r.x1 = bb[3] + 1;
+        r.sum_y = (int64_t)WS(unsigned long long, off_sumy)[v];
+        r.sum_x = (int64_t)WS(unsigned long long, off_sumx)[v];
+        rec[(size_t)blockIdx.y * max_rec + v - 1] = r;
+    }
+    atomicMax(&counts[blockIdx.y], v);
+}
+
+// ---------------------------------------------------------------------------
+// host-side launch sequences (C ABI)
+// ---------------------------------------------------------------------------
+#define GRID_PIX(lay, nT) dim3(cpx_cdiv((lay).HW, NTHR), nT)
+#define GRID_PAD(lay, nT) dim3(cpx_cdiv((lay).HWp, NTHR), nT)
+#define GRID_LAB(lay, nT) dim3(cpx_cdiv((lay).L, NTHR), nT)
+
+static int pp_check(int nT, int H, int W) {
+    CPX_REQUIRE(nT > 0 && H >= 2 && W >= 2 && H <= 16384 && W <= 16384);
+    return CPX_OK;
+}
+
+extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, int H, int W,
+                                float thr, int niter, int32_t *p_final, float *p_float, void *ws,
+                                void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(dP && cellprob && p_final && ws && niter >= 0);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
+    hipLaunchKernelGGL(k_prep_flow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, dP, cellprob, thr, kx, ky, lay, ws);
+    hipLaunchKernelGGL(k_follow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, cellprob, thr, niter,
+                       (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
+                       p_float, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+// zero labels flagged? no: shared tail "renumber by first appearance"
+static int pp_renumber(int32_t *masks, int nT, const PPLayout &lay, void *ws, hipStream_t s,
+                       bool first_already) {
+    if (!first_already) {
+        hipLaunchKernelGGL(k_fill_i32, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay.off_first, lay.L, 0x7FFFFFFF, lay, ws);
+        hipLaunchKernelGGL(k_first, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    }
+    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal + sizeof(int) * SC_NLAB, 1, 0, lay, ws);
+    hipLaunchKernelGGL(k_renumber_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, SC_VMAX, lay, ws);
+    hipLaunchKernelGGL(k_relabel, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    return CPX_OK;
+}
+
+extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, double max_size_fraction,
+                             int32_t *masks, int32_t *nlabels, void *ws, void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(p_final && masks && ws);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    hipLaunchKernelGGL(k_fill_i32, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay.off_h1, lay.HWp, 0, lay, ws);
+    hipLaunchKernelGGL(k_fill_i32, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay.off_M1, lay.HWp, 0, lay, ws);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
+    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_hist, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, lay, ws);
+    hipLaunchKernelGGL(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_seed_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_seed_grow, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_gather, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
+    double big = (double)((long long)H * W) * max_size_fraction;
+    hipLaunchKernelGGL(k_big_first, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
+    // labels here are seed ranks 1..nseeds
+    hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_VMAX, SC_NSEEDS, lay, ws);
+    pp_renumber(masks, nT, lay, ws, s, true);
+    if (nlabels) hipLaunchKernelGGL(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT, int H, int W,
+                                         double threshold, double *flow_errors, void *ws,
+                                         void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(masks && dP && ws);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
+    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_zero_f64, dim3(cpx_cdiv(2 * lay.THW, NTHR), nT), dim3(NTHR), 0, s, lay.off_T, 2 * lay.THW, lay, ws);
+    hipLaunchKernelGGL(k_lab_stats, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_center_d2, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_niter, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_flow_err_pix, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, dP, lay, ws);
+    hipLaunchKernelGGL(k_flow_err_label, GRID_LAB(lay, nT), dim3(NTHR), 0, s, masks, threshold, flow_errors, lay, ws);
+    hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+static void pp_size_filter(int32_t *masks, int nT, int min_size, const PPLayout &lay, void *ws,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
+    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_count_labels, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
+    hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    pp_renumber(masks, nT, lay, ws, s, false);
+}
+
+extern "C" int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int H, int W,
+                                                     int min_size, int32_t *nlabels, void *ws,
+                                                     void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(masks && ws);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s);
+    else {   // labels may be non-contiguous: bbox loop below handles absent labels (slc None)
+        hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
+        hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+        hipLaunchKernelGGL(k_count_labels, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+        hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, lay, ws);
+    }
+    // find_objects(masks): bbox per label, then fill
+    int nlab_saved_slot = SC_NLAB;
+    (void)nlab_saved_slot;
+    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_lab_stats, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_copy_to_tmp, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_fill_serial, dim3(1, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s);
+    if (nlabels) hipLaunchKernelGGL(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+extern "C" int cpx_compute_class_masks(const int32_t *masks, const float *logits, int nT, int ncls,
+                                       int H, int W, uint8_t *class_masks, void *ws, void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(masks && logits && class_masks && ws && ncls >= 1 && ncls <= PP_MAXCLS);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    hipLaunchKernelGGL(k_fill_i32, dim3(cpx_cdiv(lay.L * PP_MAXCLS, NTHR), nT), dim3(NTHR), 0, s, lay.off_cls, lay.L * PP_MAXCLS, 0, lay, ws);
+    hipLaunchKernelGGL(k_class_count, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, logits, ncls, lay, ws);
+    hipLaunchKernelGGL(k_class_pick, GRID_LAB(lay, nT), dim3(NTHR), 0, s, ncls, lay, ws);
+    hipLaunchKernelGGL(k_class_write, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks, int nT, int H,
+                                           int W, void *ws, void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(masks && ws);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    hipLaunchKernelGGL(k_fill_i32, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay.off_flag, lay.L, 0, lay, ws);
+    hipLaunchKernelGGL(k_border_flag, dim3(cpx_cdiv(2 * (H + W), NTHR), nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_border_zero, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const float *logits, int nT,
+                                 int ncls, int H, int W, float cellprob_threshold,
+                                 double flow_threshold, int niter, int min_size,
+                                 double max_size_fraction, uint16_t *masks_u16,
+                                 uint8_t *class_masks, int32_t *nlabels, void *ws, void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(dP && cellprob && masks_u16 && ws);
+    CPX_REQUIRE(H * (long long)W / 11 + 2 < 65536);
+    CPX_REQUIRE(min_size > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)nT * H * W;
+    int32_t *masks = (int32_t *)ws;
+    int32_t *p_final = (int32_t *)((char *)ws + cpx_align_up(sizeof(int) * n, 256));
+    rc = cpx_follow_flows(dP, cellprob, nT, H, W, cellprob_threshold, niter, p_final, nullptr, ws, stream);
+    if (rc) return rc;
+    rc = cpx_get_masks(p_final, nT, H, W, max_size_fraction, masks, nullptr, ws, stream);
+    if (rc) return rc;
+    if (flow_threshold > 0) {
+        rc = cpx_remove_bad_flow_masks(masks, dP, nT, H, W, flow_threshold, nullptr, ws, stream);
+        if (rc) return rc;
+    }
+    rc = cpx_fill_holes_and_remove_small_masks(masks, nT, H, W, min_size, nlabels, ws, stream);
+    if (rc) return rc;
+    if (class_masks) {
+        if (logits && ncls > 1) {
+            rc = cpx_compute_class_masks(masks, logits, nT, ncls, H, W, class_masks, ws, stream);
+            if (rc) return rc;
+        } else {
+            CPX_HIP(hipMemsetAsync(class_masks, 0, n, s));
+        }
+    }
+    hipLaunchKernelGGL(k_to_u16, dim3(cpx_cdiv((long long)n, NTHR)), dim3(NTHR), 0, s, masks, masks_u16, n);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *class_masks, int nT,
+                                    int H, int W, int max_rec, cpx_record *records,
+                                    int32_t *counts, void *ws, void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(masks_u16 && records && counts && ws && max_rec > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PPLayout lay = pp_layout(H, W);
+    ws = pp_tiles(ws, nT, H, W);
+    CPX_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * nT, s));
+    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
+    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_rec_stats, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks_u16, lay, ws);
+    hipLaunchKernelGGL(k_rec_write, GRID_LAB(lay, nT), dim3(NTHR), 0, s, class_masks, max_rec, records, counts, lay, ws);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}

@@ -1,0 +1,309 @@
+"""Device pipeline for the WSI tile path: uint8 tiles in HBM -> instance/class maps.
+
+Host-side mirror of what ``ClassposeModel.eval`` does per tile
+(/root/reference/src/classpose/models.py:478-827: normalize -> core.run_net ->
+compute_masks -> compute_class_masks), re-cut for MI355X: tiles are batched
+ACROSS WSI tiles (the reference only batches the sub-tiles of one tile,
+predict_wsi.py:749-756), every stage is a hand-written HIP kernel behind the C
+ABI of include/classpose_hip.h, and nothing returns to the host between stages.
+torch is used for device memory, streams and (elsewhere) torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CpxBlockWeights, CpxNetWeights, CpxRecord, CpxTiling, check, ptr
+
+PS = 8
+BSIZE = 256
+HALF_DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+# --------------------------------------------------------------------------
+# host geometry (cellpose get_pad_yx / make_tiles grid, core.py:129-149)
+# --------------------------------------------------------------------------
+def make_tiling(H: int, W: int, bsize: int = BSIZE, augment: bool = False,
+                tile_overlap: float = 0.1) -> CpxTiling:
+    def pad(L):
+        lpad = int(16 * math.ceil(L / 16) - L) if L >= bsize else bsize - L
+        return 8 + lpad // 2, 8 + lpad - lpad // 2
+    yp1, yp2 = pad(H)
+    xp1, xp2 = pad(W)
+    Ly, Lx = H + yp1 + yp2, W + xp1 + xp2
+    if augment:
+        ny = max(2, int(math.ceil(2.0 * Ly / bsize)))
+        nx = max(2, int(math.ceil(2.0 * Lx / bsize)))
+    else:
+        ov = min(0.5, max(0.05, tile_overlap))
+        ny = 1 if Ly <= bsize else int(math.ceil((1.0 + 2 * ov) * Ly / bsize))
+        nx = 1 if Lx <= bsize else int(math.ceil((1.0 + 2 * ov) * Lx / bsize))
+    if ny > 16 or nx > 16:
+        raise ValueError(f"tile {H}x{W} needs a {ny}x{nx} sub-tile grid; at most 16x16 is supported")
+    t = CpxTiling()
+    t.H, t.W, t.ypad1, t.xpad1, t.Ly, t.Lx = H, W, yp1, xp1, Ly, Lx
+    t.ny, t.nx, t.bsize, t.augment = ny, nx, bsize, int(bool(augment))
+    ys = np.linspace(0, Ly - bsize, ny).astype(int)
+    xs = np.linspace(0, Lx - bsize, nx).astype(int)
+    for i in range(16):
+        t.ystart[i] = int(ys[i]) if i < ny else 0
+        t.xstart[i] = int(xs[i]) if i < nx else 0
+    return t
+
+
+def taper_1d(bsize: int = BSIZE, sig: float = 7.5) -> np.ndarray:
+    """1-D factor of cellpose's ``_taper_mask`` for a bsize x bsize sub-tile (float64)."""
+    b = max(224, bsize)
+    xm = np.arange(b)
+    xm = np.abs(xm - xm.mean())
+    m = 1 / (1 + np.exp((xm - (b / 2 - 20)) / sig))
+    return np.ascontiguousarray(m[b // 2 - bsize // 2: b // 2 + bsize // 2 + bsize % 2])
+
+
+def percentile_params(n: int, q: float) -> tuple[int, float]:
+    """(previous index, gamma) of np.percentile(..., q) on n float32 samples:
+    numpy's 'linear' method evaluated in float32 exactly like numpy does."""
+    q32 = np.float32(q) / np.float32(100)
+    vi = np.float32((n - 1) * q32)      # _QuantileMethods["linear"]: (n - 1) * quantiles, in float32
+    prev = np.floor(vi)
+    if vi >= n - 1:
+        return n - 1, 0.0
+    return int(prev), float(np.float32(vi - prev))
+
+
+# --------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------
+def interp_rel_pos(rel_pos: torch.Tensor, size: int = 63) -> torch.Tensor:
+    """segment_anything get_rel_pos resize step (F.interpolate linear) in rel_pos.dtype."""
+    if rel_pos.shape[0] == size:
+        return rel_pos
+    r = torch.nn.functional.interpolate(
+        rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=size, mode="linear")
+    return r.reshape(-1, size).permute(1, 0)
+
+
+class NetWeights:
+    """ClassTransformer parameters laid out for the HIP kernels.
+
+    ``from_state_dict`` accepts the reference's state-dict layout
+    (predict_wsi.py:1393-1405; ``torch.save(net.state_dict())``, vit_sam.py:269-285)
+    and mirrors ``net.load_model`` + ``net.to(dtype)``: every parameter is first
+    rounded to the half dtype, GEMM weights stay in it, vectors are widened back
+    to float32 for the epilogues.
+    """
+
+    def __init__(self):
+        self.keep = []          # tensors that own the device memory
+        self.c = CpxNetWeights()
+
+    @staticmethod
+    def infer_structure(sd) -> tuple[list[int] | None, int, int]:
+        import re
+        fts = [sd[k].shape[0] for k in sd
+               if re.search(r"out_class\.encoder_blocks\.[0-9]+\.block.conv1.weight", k)]
+        n_classes = sd["W3"].shape[1] if "W3" in sd else 1
+        depth = 1 + max(int(m.group(1)) for k in sd
+                        if (m := re.match(r"encoder\.blocks\.(\d+)\.norm1\.weight", k)))
+        return (fts or None), n_classes, depth
+
+    @classmethod
+    def from_state_dict(cls, sd: dict, precision: str = "bf16", device="cuda:0") -> "NetWeights":
+        if precision not in HALF_DTYPES:
+            raise ValueError(f"precision {precision!r}: the MI355X engine computes in bf16 or fp16 "
+                             "(fp32 has no MFMA fast path on gfx950)")
+        sd = {k.removeprefix("module."): v for k, v in sd.items()}
+        hd = HALF_DTYPES[precision]
+        fts, ncls, depth = cls.infer_structure(sd)
+        if fts is not None:
+            raise NotImplementedError("UNet semantic head (feature_transformation_structure) "
+                                      "is not yet built for the HIP engine")
+        if sd["encoder.patch_embed.proj.weight"].shape != (1024, 3, 8, 8):
+            raise ValueError("only the vit_l / ps=8 Cellpose-SAM backbone is supported")
+        self = cls()
+        dev = torch.device(device)
+
+        def half(t):        # GEMM operand: stays in the half dtype
+            x = t.detach().to(hd).contiguous().to(dev)
+            self.keep.append(x)
+            return x.data_ptr()
+
+        def vec(t):         # epilogue vector: rounded through the half dtype, kept as f32
+            x = t.detach().to(hd).float().contiguous().to(dev)
+            self.keep.append(x)
+            return x.data_ptr()
+
+        c = self.c
+        c.depth, c.ncls = depth, ncls
+        c.n_head_cols = 192 + (ncls * 64 if ncls > 1 else 0)
+        c.ld_head = (c.n_head_cols + 127) // 128 * 128
+        c.dtype = 0 if precision == "bf16" else 1
+        c.pe_w = half(sd["encoder.patch_embed.proj.weight"].reshape(1024, 192))
+        c.pe_b = vec(sd["encoder.patch_embed.proj.bias"])
+        c.pos = vec(sd["encoder.pos_embed"].reshape(1024, 1024))
+        self.blocks = (CpxBlockWeights * depth)()
+        for i in range(depth):
+            p = f"encoder.blocks.{i}."
+            b = self.blocks[i]
+            b.ln1_w, b.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
+            b.qkv_w, b.qkv_b = half(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
+            b.proj_w, b.proj_b = half(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
+            for name, key in (("rel_h", "attn.rel_pos_h"), ("rel_w", "attn.rel_pos_w")):
+                # table interpolated to 2*32-1 rows in the half dtype (what get_rel_pos does on
+                # the casted parameter), x8 = 1/scale (exact), padded with a zero row to 64
+                t = interp_rel_pos(sd[p + key].detach().to(hd)).float() * 8.0
+                t = torch.cat([t, torch.zeros(1, 64)], 0)
+                setattr(b, name, half(t))
+            b.ln2_w, b.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
+            b.fc1_w, b.fc1_b = half(sd[p + "mlp.lin1.weight"]), vec(sd[p + "mlp.lin1.bias"])
+            b.fc2_w, b.fc2_b = half(sd[p + "mlp.lin2.weight"]), vec(sd[p + "mlp.lin2.bias"])
+        c.blocks = C.cast(self.blocks, C.POINTER(CpxBlockWeights))
+        c.neck0_w = half(sd["encoder.neck.0.weight"].reshape(256, 1024))
+        c.neck_ln1_w, c.neck_ln1_b = vec(sd["encoder.neck.1.weight"]), vec(sd["encoder.neck.1.bias"])
+        c.neck2_w = half(sd["encoder.neck.2.weight"].permute(0, 2, 3, 1).reshape(256, 2304))
+        c.neck_ln2_w, c.neck_ln2_b = vec(sd["encoder.neck.3.weight"]), vec(sd["encoder.neck.3.bias"])
+        hw = [sd["out.weight"].reshape(192, 256)]
+        hb = [sd["out.bias"]]
+        if ncls > 1:
+            hw.append(sd["out_class.weight"].reshape(ncls * 64, 256))
+            hb.append(sd["out_class.bias"])
+        hw = torch.cat(hw, 0)
+        hb = torch.cat(hb, 0)
+        padn = c.ld_head - hw.shape[0]
+        c.head_w = half(torch.cat([hw, torch.zeros(padn, 256)], 0))
+        c.head_b = vec(torch.cat([hb, torch.zeros(padn)], 0))
+        self.ncls, self.depth, self.precision, self.device = ncls, depth, precision, dev
+        return self
+
+
+# --------------------------------------------------------------------------
+# engine
+# --------------------------------------------------------------------------
+@dataclass
+class TileOutputs:
+    masks: torch.Tensor          # uint16 [nT, H, W]   (torch has no uint16 math; stored as int16 bits)
+    class_masks: torch.Tensor    # uint8  [nT, H, W]
+    nlabels: torch.Tensor        # int32  [nT]
+    dP: torch.Tensor             # f32 [nT, 2, H, W]
+    cellprob: torch.Tensor       # f32 [nT, H, W]
+    logits: torch.Tensor | None  # f32 [nT, ncls, H, W]
+
+
+class Engine:
+    """Persistent device buffers + launch sequence for batches of nT WSI tiles."""
+
+    def __init__(self, weights: NetWeights, tile_h: int = 256, tile_w: int | None = None,
+                 batch_tiles: int = 8, augment: bool = False, tile_overlap: float = 0.1,
+                 niter: int = 200, cellprob_threshold: float = 0.0, flow_threshold: float = 0.4,
+                 min_size: int = 15, max_size_fraction: float = 0.4):
+        self.L = _lib.lib()
+        self.w = weights
+        self.dev = weights.device
+        self.H, self.W = tile_h, tile_w or tile_h
+        self.nT = batch_tiles
+        self.tiling = make_tiling(self.H, self.W, BSIZE, augment, tile_overlap)
+        self.n_sub = self.tiling.ny * self.tiling.nx
+        self.niter, self.cp_thr, self.flow_thr = niter, cellprob_threshold, flow_threshold
+        self.min_size, self.max_frac = min_size, max_size_fraction
+        nT, H, W, ncls = self.nT, self.H, self.W, weights.ncls
+        nS = nT * self.n_sub
+        d = self.dev
+        lo = percentile_params(H * W, 1)
+        hi = percentile_params(H * W, 99)
+        self.pct = (lo[0], lo[1], hi[0], hi[1])
+        self.stats = torch.empty(nT * 3 * 4, dtype=torch.float32, device=d)
+        self.hist = torch.empty(nT * 768, dtype=torch.int32, device=d)
+        self.patches = torch.empty(nS * 1024 * 192, dtype=torch.int16, device=d)
+        self.head = torch.empty(nS * 1024 * weights.c.ld_head, dtype=torch.float32, device=d)
+        self.net_ws_bytes = self.L.cpx_net_workspace_bytes(nS)
+        self.net_ws = torch.empty(self.net_ws_bytes, dtype=torch.uint8, device=d)
+        self.taper = torch.from_numpy(taper_1d(BSIZE)).to(d)
+        self.dP = torch.empty((nT, 2, H, W), dtype=torch.float32, device=d)
+        self.cellprob = torch.empty((nT, H, W), dtype=torch.float32, device=d)
+        self.logits = torch.empty((nT, max(ncls, 1), H, W), dtype=torch.float32, device=d)
+        self.pp_ws_bytes = self.L.cpx_postproc_workspace_bytes(nT, H, W)
+        self.pp_ws = torch.empty(self.pp_ws_bytes, dtype=torch.uint8, device=d)
+        self.masks = torch.empty((nT, H, W), dtype=torch.int16, device=d)
+        self.class_masks = torch.empty((nT, H, W), dtype=torch.uint8, device=d)
+        self.nlabels = torch.empty(nT, dtype=torch.int32, device=d)
+        self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 8192)
+        self.records = torch.empty(nT * self.max_rec * C.sizeof(CpxRecord), dtype=torch.uint8, device=d)
+        self.rec_counts = torch.empty(nT, dtype=torch.int32, device=d)
+
+    # -- stages ---------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def preprocess(self, tiles_u8: torch.Tensor, n: int):
+        s = self._stream()
+        lo_p, lo_g, hi_p, hi_g = self.pct
+        check(self.L.cpx_normalize_stats_u8(ptr(tiles_u8), n, self.H, self.W, lo_p, lo_g, hi_p, hi_g,
+                                            ptr(self.stats), ptr(self.hist), s), "normalize_stats")
+        check(self.L.cpx_make_subtiles(ptr(tiles_u8), ptr(self.stats), n, C.byref(self.tiling),
+                                       ptr(self.patches), s), "make_subtiles")
+
+    def network(self, n: int):
+        check(self.L.cpx_net_forward(C.byref(self.w.c), ptr(self.patches), n * self.n_sub,
+                                     ptr(self.head), ptr(self.net_ws), self.net_ws_bytes,
+                                     self._stream()), "net_forward")
+
+    def blend(self, n: int):
+        ncls = self.w.ncls if self.w.ncls > 1 else 0
+        check(self.L.cpx_blend_subtiles(ptr(self.head), self.w.c.ld_head, ncls, n,
+                                        C.byref(self.tiling), ptr(self.taper), ptr(self.dP),
+                                        ptr(self.cellprob), ptr(self.logits), self._stream()), "blend")
+
+    def dynamics(self, n: int, dP=None, cellprob=None, logits=None):
+        dP = self.dP if dP is None else dP
+        cellprob = self.cellprob if cellprob is None else cellprob
+        logits = self.logits if logits is None else logits
+        ncls = self.w.ncls
+        check(self.L.cpx_compute_masks(ptr(dP), ptr(cellprob), ptr(logits) if ncls > 1 else None, n,
+                                       ncls, self.H, self.W, self.cp_thr, self.flow_thr, self.niter,
+                                       self.min_size, self.max_frac, ptr(self.masks),
+                                       ptr(self.class_masks), ptr(self.nlabels), ptr(self.pp_ws),
+                                       self._stream()), "compute_masks")
+
+    def make_records(self, n: int):
+        check(self.L.cpx_instance_records(ptr(self.masks), ptr(self.class_masks), n, self.H, self.W,
+                                          self.max_rec, ptr(self.records), ptr(self.rec_counts),
+                                          ptr(self.pp_ws), self._stream()), "instance_records")
+
+    # -- whole path -----------------------------------------------------
+    def run(self, tiles_u8: torch.Tensor, inject=None, records: bool = True) -> TileOutputs:
+        """tiles_u8: uint8 [n, H, W, 3] already resident on the device, n <= batch_tiles.
+
+        ``inject`` = (dP, cellprob, logits) device tensors: flow-injection mode (the
+        network still runs; the dynamics consume the injected fields instead)."""
+        n = tiles_u8.shape[0]
+        assert n <= self.nT and tiles_u8.dtype == torch.uint8 and tiles_u8.is_contiguous()
+        assert tiles_u8.shape[1:] == (self.H, self.W, 3) and tiles_u8.device == self.dev
+        self.preprocess(tiles_u8, n)
+        self.network(n)
+        self.blend(n)
+        if inject is not None:
+            self.dynamics(n, *inject)
+        else:
+            self.dynamics(n)
+        if records:
+            self.make_records(n)
+        return TileOutputs(self.masks[:n], self.class_masks[:n], self.nlabels[:n], self.dP[:n],
+                           self.cellprob[:n], self.logits[:n] if self.w.ncls > 1 else None)
+
+    def fetch_records(self, n: int) -> np.ndarray:
+        """Compact per-cell records of the last run() as a structured numpy array (D2H)."""
+        counts = self.rec_counts[:n].cpu().numpy()
+        raw = self.records.cpu().numpy().view(RECORD_DTYPE).reshape(self.nT, self.max_rec)
+        return np.concatenate([raw[t, :min(int(counts[t]), self.max_rec)] for t in range(n)]) \
+            if n else raw[:0, 0]
+
+
+RECORD_DTYPE = np.dtype([("tile", "<i4"), ("label", "<i4"), ("cls", "<i4"), ("area", "<i4"),
+                         ("y0", "<i4"), ("x0", "<i4"), ("y1", "<i4"), ("x1", "<i4"),
+                         ("sum_y", "<i8"), ("sum_x", "<i8")])
+assert RECORD_DTYPE.itemsize == C.sizeof(CpxRecord)

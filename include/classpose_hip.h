@@ -1,0 +1,214 @@
+/*
+ * classpose_hip.h -- C ABI of libclasspose_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the `classpose-predict-wsi` tile path of
+ * sohmandal/classpose.  The reference is pure Python; every entry point below
+ * replaces one library call the reference makes on that path (cited per
+ * function as /root/reference/<file>:<line>, or as the cellpose==4.0.8 /
+ * segment-anything==1.0 symbol that call bottoms out in).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream);
+ *   - return 0 on success, a negative CPX_E* code otherwise; nothing throws,
+ *     nothing allocates: the caller supplies workspaces sized by the
+ *     *_workspace_bytes() queries (graph-capture safe);
+ *   - tiles are batched: leading dimension nT, then the reference's layout;
+ *   - thread-safe for distinct streams + distinct workspaces.
+ */
+#ifndef CLASSPOSE_HIP_H
+#define CLASSPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPX_OK 0
+#define CPX_EINVAL (-22)
+#define CPX_ENOMEM (-12)
+#define CPX_EHIP (-5)
+
+/* Library / device identification. Returns the ABI version (this header: 1). */
+int cpx_abi_version(void);
+/* Last HIP error string recorded by a failing call on this thread (host ptr). */
+const char *cpx_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * a6  image normalisation
+ * replaces cellpose.transforms.normalize_img as called from
+ * ClassposeModel.eval, /root/reference/src/classpose/models.py:642-666
+ * ---------------------------------------------------------------------- */
+/* Per tile and channel: 1st / 99th percentile of the uint8 pixels with numpy's
+ * float32 'linear' quantile arithmetic (prev-index + gamma supplied by the host
+ * because they only depend on H*W), then x01 / (x99-x01) / mode.
+ * tiles_u8 [nT][H][W][3];  stats [nT][3][4] = {x01, x99-x01, mode, unused},
+ * mode 0: ptp==0 -> channel left untouched, 1: (x-x01)/(x99-x01), 2: zeros.
+ * hist_ws: nT*3*256 uint32.                                               */
+int cpx_normalize_stats_u8(const uint8_t *tiles_u8, int nT, int H, int W,
+                           int lo_prev, float lo_gamma, int hi_prev, float hi_gamma,
+                           float *stats, uint32_t *hist_ws, void *stream);
+/* Applies the stats: out_f32 [nT][H][W][3] float32 (what normalize_img returns). */
+int cpx_normalize_apply_u8(const uint8_t *tiles_u8, const float *stats, int nT, int H, int W,
+                           float *out_f32, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a7  sub-tiling and taper blending
+ * replaces transforms.get_pad_yx + np.pad + transforms.make_tiles in
+ * core.run_net, /root/reference/src/classpose/core.py:129-178, and
+ * unaugment_tiles / unaugment_class_tiles / average_tiles + crop,
+ * core.py:197-231 and transforms/transforms.py:4-21
+ * ---------------------------------------------------------------------- */
+typedef struct cpx_tiling {
+    int H, W;            /* WSI tile size (pixels)                              */
+    int ypad1, xpad1;    /* leading zero pad (get_pad_yx)                       */
+    int Ly, Lx;          /* padded size                                         */
+    int ny, nx;          /* sub-tile grid                                       */
+    int bsize;           /* sub-tile size, 256                                  */
+    int augment;         /* TTA flips by (j,i) parity                           */
+    int ystart[16];      /* np.linspace(0, Ly-bsize, ny).astype(int)            */
+    int xstart[16];
+} cpx_tiling;
+
+/* Normalised pixels (from stats) -> zero pad -> sub-tile -> flip -> 8x8 patch
+ * rows (im2col of the patch-embed conv) in bf16.
+ * patches [nT*ny*nx][1024][192], k = c*64 + i*8 + j.                       */
+int cpx_make_subtiles(const uint8_t *tiles_u8, const float *stats, int nT,
+                      const cpx_tiling *tiling_host, void *patches_bf16, void *stream);
+/* Same but float32 NCHW sub-tiles [nT*ny*nx][3][bsize][bsize] (what
+ * make_tiles returns; used by parity tests and the fp32 debug path).        */
+int cpx_make_subtiles_f32(const uint8_t *tiles_u8, const float *stats, int nT,
+                          const cpx_tiling *tiling_host, float *subtiles, void *stream);
+/* Head outputs of all sub-tiles -> per WSI tile dP/cellprob/logits.
+ * head [nT*ny*nx][1024][ld_head] float32 token-major; column c*64+i*8+j of the
+ * flow block (cols 0..191: dY,dX,cellprob) and of the class block (cols
+ * 192..192+ncls*64) is pixel (8*ph+i, 8*pw+j) of channel c (pixel shuffle W2/W3,
+ * vit_sam.py:181-188).  taper1d_host: 1-D cellpose taper (float64, bsize).
+ * Outputs float32: dP [nT][2][H][W], cellprob [nT][H][W], logits [nT][ncls][H][W]. */
+int cpx_blend_subtiles(const float *head, int ld_head, int ncls, int nT,
+                       const cpx_tiling *tiling_host, const double *taper1d,
+                       float *dP, float *cellprob, float *logits, void *stream);
+/* Same from NCHW sub-tile outputs y [nS][3][b][b], y_class [nS][ncls][b][b]
+ * (the arrays core.run_net holds before average_tiles).                      */
+int cpx_blend_subtiles_nchw(const float *y, const float *y_class, int ncls, int nT,
+                            const cpx_tiling *tiling_host, const double *taper1d,
+                            float *dP, float *cellprob, float *logits, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a9/a10  network forward (ClassTransformer.forward,
+ * /root/reference/src/classpose/vit_sam.py:148-197 with flash_forward :15-65)
+ * ---------------------------------------------------------------------- */
+typedef struct cpx_block_weights {
+    const float *ln1_w, *ln1_b;          /* [1024]                            */
+    const void *qkv_w;  const float *qkv_b;   /* bf16 [3072][1024], [3072]    */
+    const void *proj_w; const float *proj_b;  /* bf16 [1024][1024]            */
+    const void *rel_h, *rel_w;           /* bf16 [64][64]: rows 0..62 = table
+                                            interpolated to 63 rows, /scale   */
+    const float *ln2_w, *ln2_b;
+    const void *fc1_w;  const float *fc1_b;   /* bf16 [4096][1024]            */
+    const void *fc2_w;  const float *fc2_b;   /* bf16 [1024][4096]            */
+} cpx_block_weights;
+
+typedef struct cpx_net_weights {
+    int depth;              /* 24 for vit_l                                    */
+    int ncls;               /* n_cell_classes (W3.shape[1])                    */
+    int n_head_cols;        /* 192 + ncls*64                                   */
+    int ld_head;            /* n_head_cols rounded up to 128                   */
+    int dtype;              /* 0 = bf16, 1 = fp16                              */
+    const void *pe_w;       /* [1024][192]                                     */
+    const float *pe_b;      /* [1024]                                          */
+    const float *pos;       /* [1024 tokens][1024] float32                     */
+    const cpx_block_weights *blocks;   /* HOST array of depth entries          */
+    const void *neck0_w;    /* [256][1024]                                     */
+    const float *neck_ln1_w, *neck_ln1_b;
+    const void *neck2_w;    /* [256][9*256], k = (ky*3+kx)*256 + c             */
+    const float *neck_ln2_w, *neck_ln2_b;
+    const void *head_w;     /* [ld_head][256] rows: out (192) then out_class   */
+    const float *head_b;    /* [ld_head]                                       */
+} cpx_net_weights;
+
+size_t cpx_net_workspace_bytes(int n_subtiles);
+/* patches_bf16 [nS*1024][192] -> head [nS*1024][ld_head] float32.           */
+int cpx_net_forward(const cpx_net_weights *w_host, const void *patches_bf16, int n_subtiles,
+                    float *head, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Building blocks (exposed for parity tests / rooflines).
+ * C[M][N] = A[M][K] * W[N][K]^T (+epilogue).  M%128==0, N%128==0, K%64==0.    */
+#define CPX_EPI_BF16 0            /* out bf16 = acc (+bias if bias)            */
+#define CPX_EPI_GELU_BF16 1       /* out bf16 = gelu_erf(acc + bias)           */
+#define CPX_EPI_RESID_BF16 2      /* out bf16 = resid + acc + bias             */
+#define CPX_EPI_F32 3             /* out f32  = acc (+bias)                    */
+#define CPX_EPI_POS_BF16 4        /* out bf16 = acc + bias + pos[row%1024]     */
+#define CPX_EPI_RELU_BF16 5
+int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                  const float *bias, const void *resid_or_pos, void *out, int ld_out,
+                  void *stream);
+int cpx_layernorm_bf16(const void *x, const float *w, const float *b, int rows, int C,
+                       float eps, void *out, void *stream);
+/* qkv [nS*1024][3072] bf16 (q|k|v, head-major inside) -> attn out [nS*1024][1024]. */
+int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                         void *vT_ws, void *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a11-a16  flows -> instance ids -> classes
+ * ---------------------------------------------------------------------- */
+size_t cpx_postproc_workspace_bytes(int nT, int H, int W);
+int cpx_postproc_max_labels(int H, int W);
+
+/* cellpose.dynamics.follow_flows (steps_interp) as driven by
+ * dynamics.compute_masks; call site models.py:149-159.
+ * dP [nT][2][H][W] (dY,dX) raw network flows, cellprob [nT][H][W].
+ * p_final [nT][H*W] int32: (y<<16)|x of the truncated end point, -1 where
+ * cellprob <= threshold.  p_float (nullable) [nT][2][H*W] float end points. */
+int cpx_follow_flows(const float *dP, const float *cellprob, int nT, int H, int W,
+                     float cellprob_threshold, int niter, int32_t *p_final, float *p_float,
+                     void *workspace, void *stream);
+/* cellpose.dynamics.get_masks_torch: histogram, 5x5 NMS seeds (>10), 11x11
+ * seeded growth (h>2, 5 iters), label gather, big-mask removal, renumber.
+ * masks [nT][H*W] int32, nlabels [nT].                                      */
+int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, double max_size_fraction,
+                  int32_t *masks, int32_t *nlabels, void *workspace, void *stream);
+/* cellpose.dynamics.remove_bad_flow_masks (metrics.flow_error +
+ * masks_to_flows_gpu, fp64 diffusion).  flow_errors (nullable) [nT][max_labels]. */
+int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT, int H, int W,
+                              double threshold, double *flow_errors, void *workspace,
+                              void *stream);
+/* cellpose.utils.fill_holes_and_remove_small_masks.                          */
+int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int H, int W, int min_size,
+                                          int32_t *nlabels, void *workspace, void *stream);
+/* classpose.models.compute_class_masks, models.py:191-230.
+ * logits [nT][ncls][H][W]; class_masks [nT][H*W] uint8.                      */
+int cpx_compute_class_masks(const int32_t *masks, const float *logits, int nT, int ncls, int H,
+                            int W, uint8_t *class_masks, void *workspace, void *stream);
+/* classpose.metrics.pq.remove_border_instances, metrics/pq.py:65-92
+ * (class_masks nullable = the (H,W) form; else the (H,W,2) form).            */
+int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks, int nT, int H, int W,
+                                void *workspace, void *stream);
+/* The whole of dynamics.resize_and_compute_masks + compute_class_masks
+ * (models.py:750-768): masks_u16 [nT][H*W] uint16, class_masks [nT][H*W] uint8. */
+int cpx_compute_masks(const float *dP, const float *cellprob, const float *logits, int nT,
+                      int ncls, int H, int W, float cellprob_threshold, double flow_threshold,
+                      int niter, int min_size, double max_size_fraction, uint16_t *masks_u16,
+                      uint8_t *class_masks, int32_t *nlabels, void *workspace, void *stream);
+
+/* Compact per-instance records: what leaves the device in place of the pickled
+ * (masks, class_masks) arrays of predict_wsi.py:757-763 / :595-652.          */
+typedef struct cpx_record {
+    int32_t tile;        /* index in the batch                                 */
+    int32_t label;       /* instance id inside the tile                        */
+    int32_t cls;         /* class of its first raster pixel (predict_wsi.py:634) */
+    int32_t area;        /* pixel count                                        */
+    int32_t y0, x0, y1, x1;   /* bbox, end exclusive                           */
+    int64_t sum_y, sum_x;     /* pixel-coordinate sums (centroid = sum/area)   */
+} cpx_record;
+int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *class_masks, int nT, int H,
+                         int W, int max_records_per_tile, cpx_record *records,
+                         int32_t *counts, void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""GPU numerics: MFMA GEMM / LayerNorm / attention / whole ClassTransformer vs torch fp32 and
+the CPU oracle.  Tolerances (stated per test) follow SURVEY 8c: half-precision compute vs an
+fp32 reference of the same op on the SAME half-rounded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from classpose_amd import _lib, engine, ops, synth
+from oracle import net as onet
+from oracle import tiling
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (1024, 1024, 1024), (2048, 640, 256),
+                                   (1024, 256, 2304)])
+def test_gemm_epilogues(cuda, variant, M, N, K):
+    _lib.lib().cpx_gemm_set_variant(variant)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+        bias = torch.randn(N, generator=g).to(cuda)
+        ref = A.float() @ W.float().T
+        out = ops.gemm(A, W, "f32", bias)
+        assert _rel(out, ref + bias) < 1e-5                     # fp32 accumulate of exact products
+        out = ops.gemm(A, W, "bf16", None)
+        assert torch.equal(out, ref.to(torch.bfloat16)) or _rel(out.float(), ref) < 4e-3
+        out = ops.gemm(A, W, "gelu", bias)
+        assert _rel(out.float(), torch.nn.functional.gelu(ref + bias)) < 4e-3
+        out = ops.gemm(A, W, "relu", bias)
+        assert _rel(out.float(), torch.relu(ref + bias)) < 4e-3
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(cuda)
+        out = ops.gemm(A, W, "resid", bias, res)
+        assert _rel(out.float(), ref + bias + res.float()) < 4e-3
+        if N == 1024:
+            pos = torch.randn(1024, N, generator=g).to(cuda)
+            out = ops.gemm(A, W, "pos", bias, pos)
+            exp = ref + bias + pos[torch.arange(M, device=cuda) % 1024]
+            assert _rel(out.float(), exp) < 4e-3
+    finally:
+        _lib.lib().cpx_gemm_set_variant(1)
+
+
+def test_gemm_identity_asymmetric(cuda):
+    """A = I against an asymmetric W catches transposed / permuted fragment maps exactly."""
+    K = N = 128
+    A = torch.eye(128, K).to(torch.bfloat16).to(cuda)
+    W = (torch.arange(N * K).reshape(N, K) % 251 - 125).to(torch.bfloat16).to(cuda)
+    out = ops.gemm(A, W, "f32", None)
+    assert torch.equal(out, W.float().T.contiguous())
+
+
+@pytest.mark.parametrize("C", [1024, 256])
+def test_layernorm(cuda, C):
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(512, C, generator=g) * 3 + 1).to(torch.bfloat16).to(cuda)
+    w = torch.randn(C, generator=g).to(cuda)
+    b = torch.randn(C, generator=g).to(cuda)
+    out = ops.layernorm(x, w, b, 1e-6)
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), w, b, 1e-6)
+    assert _rel(out.float(), ref) < 4e-3
+    assert float((out.float() - ref).abs().max()) < 0.06
+
+
+def _attention_ref(qkv, relh63, relw63, nS):
+    """flash_forward semantics in fp32 on the half-rounded inputs."""
+    B, L, H = nS, 1024, 16
+    q, k, v = qkv.float().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    idx = torch.arange(32)[:, None] - torch.arange(32)[None, :] + 31
+    Rh, Rw = relh63[idx.to(relh63.device)], relw63[idx.to(relw63.device)]     # [32,32,64]
+    qhw = q.reshape(B, H, 32, 32, 64)
+    rel_h = torch.einsum("bnhwc,hkc->bnhwk", qhw, Rh)
+    rel_w = torch.einsum("bnhwc,wkc->bnhwk", qhw, Rw)
+    bias = (rel_h[..., :, None] + rel_w[..., None, :]).reshape(B, H, L, L)
+    att = torch.softmax(q @ k.transpose(-1, -2) * 0.125 + bias, -1)
+    return (att @ v).transpose(1, 2).reshape(B * L, 1024)
+
+
+def test_attention_relpos(cuda):
+    g = torch.Generator().manual_seed(5)
+    nS = 2
+    qkv = torch.randn(nS * 1024, 3072, generator=g).to(torch.bfloat16).to(cuda)
+    relh = (torch.randn(63, 64, generator=g) * 0.3).to(torch.bfloat16)
+    relw = (torch.randn(63, 64, generator=g) * 0.3).to(torch.bfloat16)
+    pad = lambda t: torch.cat([t.float() * 8, torch.zeros(1, 64)]).to(torch.bfloat16).to(cuda)
+    out = ops.attention(qkv, pad(relh), pad(relw))
+    ref = _attention_ref(qkv, relh.float().to(cuda), relw.float().to(cuda), nS)
+    r = _rel(out.float(), ref)
+    assert r < 1e-2, r                      # bf16 P and bf16 output rounding
+    assert float((out.float() - ref).abs().max()) < 0.05
+
+
+def test_attention_spiked_rows(cuda):
+    """one key dominates -> the online-softmax rescale path is taken; result ~= that key's V"""
+    g = torch.Generator().manual_seed(6)
+    qkv = (torch.randn(1024, 3072, generator=g) * 0.1)
+    qkv[:, :1024] = 1.0                                       # all q equal
+    qkv[700, 1024:2048] = 30.0                                # key 700 spikes for every head
+    qkv = qkv.to(torch.bfloat16).to(cuda)
+    z = torch.zeros(64, 64, dtype=torch.bfloat16, device=cuda)
+    out = ops.attention(qkv, z, z)
+    ref = _attention_ref(qkv, torch.zeros(63, 64, device=cuda), torch.zeros(63, 64, device=cuda), 1)
+    assert float((out.float() - ref).abs().max()) < 0.02
+    assert torch.allclose(out.float()[5], qkv[700, 2048:].float(), atol=0.02)
+
+
+@pytest.mark.parametrize("depth,nS", [(2, 4), (24, 1)])
+def test_net_forward_vs_oracle(cuda, depth, nS):
+    sd = synth.make_state_dict(7, None, depth=depth, seed=3)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", cuda)
+    rng = np.random.default_rng(0)
+    x = rng.random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5) \
+        .reshape(nS * 1024, 192).to(torch.bfloat16).to(cuda)
+    L = _lib.lib()
+    head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+    ws = torch.empty(L.cpx_net_workspace_bytes(nS), dtype=torch.uint8, device=cuda)
+    import ctypes as C
+    _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), torch.cuda.current_stream().cuda_stream))
+    out = head[:, :640].reshape(nS, 32, 32, 10, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(nS, 10, 256, 256)
+    out = out.cpu()
+    # oracle channel order: [class logits (7), dY, dX, cellprob]; ours: [flow(3), class(7)]
+    ours = torch.cat([out[:, 3:], out[:, :3]], 1)
+    ref32 = onet.class_transformer_forward(sd, torch.from_numpy(x))
+    sdb = {k: v.to(torch.bfloat16) if v.is_floating_point() else v for k, v in sd.items()}
+    refbf = onet.class_transformer_forward(sdb, torch.from_numpy(x), torch.bfloat16)
+    e_ours, e_ref = _rel(ours, ref32), _rel(refbf, ref32)
+    print(f"depth {depth}: HIP bf16 vs fp32 oracle {e_ours:.4f}; torch-CPU bf16 vs fp32 {e_ref:.4f}; "
+          f"HIP vs torch-CPU bf16 {_rel(ours, refbf):.4f}")
+    assert e_ours < 2e-2                       # SURVEY 8c tolerance for half precision
+    assert e_ours < 1.5 * e_ref + 2e-3         # no worse than the reference's own bf16 path
+
+
+def test_engine_end_to_end(cuda):
+    """tiles -> ids: network outputs within tolerance of the oracle, ids bit-exact given the
+    device's own flow/cellprob/logit tensors."""
+    from oracle import classmask, dynamics
+    sd = synth.make_state_dict(7, None, depth=2, seed=4)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", cuda)
+    eng = engine.Engine(w, 256, batch_tiles=2)
+    tiles = np.stack([synth.render_region(1234, 0, 0, 256, 256), synth.render_region(1234, 224, 448, 256, 256)])
+    out = eng.run(torch.from_numpy(tiles).to(cuda))
+    fw = onet.make_forward(sd)
+    for i in range(2):
+        x = tiling.normalize_img(tiles[i:i + 1])
+        dP, cp, yc = tiling.run_net(fw, x, batch_size=8)
+        assert _rel(out.dP[i].cpu(), torch.from_numpy(dP)) < 2e-2
+        assert _rel(out.cellprob[i].cpu(), torch.from_numpy(cp)) < 2e-2
+        assert _rel(out.logits[i].cpu(), torch.from_numpy(yc)) < 2e-2
+        ref = dynamics.compute_masks(out.dP[i].cpu().numpy(), out.cellprob[i].cpu().numpy())
+        assert np.array_equal(ops.masks_to_numpy(out.masks)[i], ref)
+        cm, _ = classmask.compute_class_masks(ref, out.logits[i].cpu().numpy())
+        assert np.array_equal(out.class_masks[i].cpu().numpy(), cm.astype(np.uint8))
+    # flow injection: analytic fields -> known cells, records consistent with the maps
+    inj = [synth.analytic_fields(1234, 0, 0, 256, 256, 7), synth.analytic_fields(1234, 224, 448, 256, 256, 7)]
+    dPi = torch.from_numpy(np.stack([a[0] for a in inj])).to(cuda)
+    cpi = torch.from_numpy(np.stack([a[1] for a in inj])).to(cuda)
+    lgi = torch.from_numpy(np.stack([a[2] for a in inj])).to(cuda)
+    out = eng.run(torch.from_numpy(tiles).to(cuda), inject=(dPi, cpi, lgi))
+    rec = eng.fetch_records(2)
+    m = ops.masks_to_numpy(out.masks)
+    for i in range(2):
+        ref = dynamics.compute_masks(inj[i][0], inj[i][1])
+        assert np.array_equal(m[i], ref)
+        cm, _ = classmask.compute_class_masks(ref, inj[i][2])
+        exp = classmask.instance_records(ref, cm)
+        r = rec[rec["tile"] == i]
+        assert len(r) == ref.max() >= inj[i][3]
+        assert np.array_equal(r["area"], exp["area"]) and np.array_equal(r["cls"], exp["cls"])
+        assert np.array_equal(np.stack([r["y0"], r["x0"], r["y1"], r["x1"]], 1), exp["bbox"])
+        assert np.array_equal(r["sum_y"], exp["sum_y"]) and np.array_equal(r["sum_x"], exp["sum_x"])

@@ -1,0 +1,186 @@
+"""GPU parity (bit-exact): HIP post-processing kernels vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from classpose_amd import ops, synth
+from oracle import classmask, cref, dynamics
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(kind, H, W, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "discs":
+        dP, cp, lg, _ = synth.analytic_fields(1234 + seed, 37 * seed, 91 * seed, W, H, 7)
+    elif kind == "noisy_discs":
+        dP, cp, lg, _ = synth.analytic_fields(99 + seed, 10 * seed, 5 * seed, W, H, 7)
+        dP = dP + rng.standard_normal(dP.shape).astype(np.float32) * 1.5
+        cp = cp + rng.standard_normal(cp.shape).astype(np.float32) * 3
+        lg = lg + rng.standard_normal(lg.shape).astype(np.float32)
+    else:   # smooth random field: big ragged blobs, exercises big-bbox / removal paths
+        from scipy.ndimage import gaussian_filter
+        dP = np.stack([gaussian_filter(rng.standard_normal((H, W)), 6) for _ in range(2)]) * 60
+        cp = gaussian_filter(rng.standard_normal((H, W)), 5) * 20
+        lg = rng.standard_normal((7, H, W))
+        dP, cp, lg = dP.astype(np.float32), cp.astype(np.float32), lg.astype(np.float32)
+    return dP, cp, lg
+
+
+CASES = [("discs", 256, 256, 1), ("discs", 200, 312, 2), ("noisy_discs", 256, 256, 3),
+         ("random", 128, 160, 4), ("random", 256, 256, 5), ("noisy_discs", 97, 131, 6)]
+
+
+def _unpack(pf, n_active=None):
+    pf = pf.cpu().numpy()
+    return pf >> 16, (pf & 0xFFFF).astype(np.int16).astype(np.int64)
+
+
+@pytest.mark.parametrize("kind,H,W,seed", CASES)
+def test_follow_flows_bit_exact(cuda, kind, H, W, seed):
+    dP, cp, _ = _fields(kind, H, W, seed)
+    pf, fl = ops.follow_flows(torch.from_numpy(dP).to(cuda), torch.from_numpy(cp).to(cuda),
+                              niter=200, return_float=True)
+    inds = np.nonzero(cp > 0)
+    ref = cref.follow_flows(dP * (cp > 0) / 5.0, inds, 200)          # == torch grid_sample loop
+    fl = fl.cpu().numpy()[0].reshape(2, H, W)
+    assert np.array_equal(fl[:, inds[0], inds[1]], ref)
+    py, px = _unpack(pf)
+    assert np.array_equal(py[0].reshape(H, W)[inds], ref[0].astype(np.int32))
+    assert np.array_equal(px[0].reshape(H, W)[inds], ref[1].astype(np.int32))
+    assert np.all(pf.cpu().numpy()[0].reshape(H, W)[cp <= 0] == -1)
+
+
+def test_follow_flows_torch_pin_small(cuda):
+    """the literal torch path, not only its C restatement"""
+    dP, cp, _ = _fields("noisy_discs", 64, 80, 7)
+    _, fl = ops.follow_flows(torch.from_numpy(dP).to(cuda), torch.from_numpy(cp).to(cuda), 50,
+                             return_float=True)
+    inds = np.nonzero(cp > 0)
+    ref = dynamics.follow_flows(dP * (cp > 0) / 5.0, inds, 50).numpy()
+    assert np.array_equal(fl.cpu().numpy()[0].reshape(2, 64, 80)[:, inds[0], inds[1]], ref)
+
+
+@pytest.mark.parametrize("kind,H,W,seed", CASES)
+def test_stagewise_masks_bit_exact(cuda, kind, H, W, seed):
+    dP, cp, lg = _fields(kind, H, W, seed)
+    ref, st = dynamics.compute_masks(dP, cp, return_stages=True)
+    dPd, cpd = torch.from_numpy(dP).to(cuda)[None], torch.from_numpy(cp).to(cuda)[None]
+    pf = ops.follow_flows(dPd, cpd, 200)
+    masks, nlab = ops.get_masks(pf, H, W, 0.4)
+    assert np.array_equal(masks.cpu().numpy()[0], st["masks_seeded"].astype(np.int32)), "get_masks"
+    assert int(nlab[0]) == int(st["masks_seeded"].max())
+    if st["masks_seeded"].max() > 0:
+        masks, errs = ops.remove_bad_flow_masks(masks, dPd, 0.4, return_errors=True)
+        e = errs.cpu().numpy()[0][: len(st["flow_errors"])]
+        amb = np.abs(st["flow_errors"] - 0.4) < 1e-9
+        assert np.allclose(e, st["flow_errors"], rtol=1e-12, atol=1e-14), "flow errors"
+        if not amb.any():
+            assert np.array_equal(masks.cpu().numpy()[0], st["masks_flowfiltered"].astype(np.int32)), "flow filter"
+    masks, nlab = ops.fill_holes_and_remove_small_masks(masks, 15)
+    assert np.array_equal(masks.cpu().numpy()[0], ref.astype(np.int32)), "fill/size filter"
+    assert int(nlab[0]) == int(ref.max())
+    cm = ops.compute_class_masks(masks, torch.from_numpy(lg).to(cuda)[None])
+    cm_ref, _ = classmask.compute_class_masks(ref, lg)
+    assert np.array_equal(cm.cpu().numpy()[0], cm_ref.astype(np.uint8))
+
+
+def test_compute_masks_batched_equals_oracle(cuda):
+    tiles = [_fields(k, 256, 256, s) for k, s in (("discs", 11), ("noisy_discs", 12), ("random", 13),
+                                                   ("discs", 14))]
+    dP = torch.from_numpy(np.stack([t[0] for t in tiles])).to(cuda)
+    cp = torch.from_numpy(np.stack([t[1] for t in tiles])).to(cuda)
+    lg = torch.from_numpy(np.stack([t[2] for t in tiles])).to(cuda)
+    m, cm, nlab = ops.compute_masks(dP, cp, lg)
+    m = ops.masks_to_numpy(m)
+    for i, (a, b, c) in enumerate(tiles):
+        ref = dynamics.compute_masks(a, b)
+        assert np.array_equal(m[i], ref), i
+        cref_, _ = classmask.compute_class_masks(ref, c)
+        assert np.array_equal(cm.cpu().numpy()[i], cref_.astype(np.uint8)), i
+        assert int(nlab[i]) == ref.max()
+    # idempotence / determinism: same inputs -> same ids
+    m2, _, _ = ops.compute_masks(dP, cp, lg)
+    assert np.array_equal(ops.masks_to_numpy(m2), m)
+
+
+def test_empty_and_degenerate_tiles(cuda):
+    H = W = 64
+    z = torch.zeros((2, 2, H, W), device=cuda)
+    cp = torch.full((2, H, W), -1.0, device=cuda)
+    cp[1, 10:30, 10:30] = 1.0                       # active pixels but zero flow: no seed > 10
+    m, cm, nlab = ops.compute_masks(z, cp, None)
+    assert ops.masks_to_numpy(m).max() == 0 and int(nlab.max()) == 0
+    ref = dynamics.compute_masks(np.zeros((2, H, W), np.float32), cp[1].cpu().numpy())
+    assert ref.max() == 0
+
+
+def _fill_cases():
+    rng = np.random.default_rng(5)
+    cases = []
+    m = np.zeros((64, 64), np.int32)             # ring with a hole + a small cell inside the hole
+    yy, xx = np.mgrid[:64, :64]
+    r = np.hypot(yy - 30, xx - 30)
+    m[(r < 20) & (r > 12)] = 1
+    m[(np.hypot(yy - 30, xx - 30) < 4)] = 2     # nested label -> sequential path
+    m[50:56, 50:58] = 3
+    m[52:54, 52:55] = 0                          # plain hole
+    cases.append(m)
+    m = np.zeros((96, 120), np.int32)            # many blobs with random holes and gaps in ids
+    lab = 1
+    for _ in range(40):
+        y, x = rng.integers(0, 80), rng.integers(0, 100)
+        h, w = rng.integers(3, 16), rng.integers(3, 16)
+        m[y:y + h, x:x + w] = lab
+        if h > 4 and w > 4:
+            m[y + 2:y + h - 2, x + 2:x + w - 2] = 0
+        lab += rng.integers(1, 3)
+    cases.append(m)
+    m = np.zeros((150, 150), np.int32)           # bbox > 64 with a spiral-ish hole -> serial path
+    m[10:140, 10:140] = 1
+    m[20:130, 20:130] = 0
+    m[40:110, 40:110] = 2
+    m[60:90, 60:90] = 0
+    m[20:130, 70:75] = 1
+    cases.append(m)
+    m = np.zeros((12, 40), np.int32)             # positional-index quirk of the size filter
+    m[1:6, 1:6] = 1; m[1:6, 10:15] = 2; m[1:6, 20:25] = 4; m[1:3, 30:33] = 5
+    cases.append(m)
+    m = np.ones((20, 20), np.int32)              # no background pixel at all
+    m[5:15, 5:15] = 2; m[8:10, 8:10] = 3
+    cases.append(m)
+    return cases
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_fill_holes_and_remove_small_masks(cuda, idx):
+    m = _fill_cases()[idx]
+    ref = dynamics.fill_holes_and_remove_small_masks(m.astype(np.uint16), 15)
+    out, nlab = ops.fill_holes_and_remove_small_masks(torch.from_numpy(m.copy()).to(cuda)[None], 15)
+    assert np.array_equal(out.cpu().numpy()[0], ref.astype(np.int32))
+    assert int(nlab[0]) == ref.max()
+
+
+def test_compute_class_masks_golden(cuda, golden):
+    npz, _ = golden
+    for i in range(int(npz["ccm_n"])):
+        masks = torch.from_numpy(npz[f"ccm_masks_{i}"].astype(np.int32)).to(cuda)[None]
+        lg = torch.from_numpy(npz[f"ccm_logits_{i}"][:, 0]).to(cuda)[None]
+        cm = ops.compute_class_masks(masks, lg)
+        assert np.array_equal(cm.cpu().numpy()[0].astype(np.int64), npz[f"ccm_out_{i}"]), i
+
+
+def test_remove_border_instances_golden(cuda, golden):
+    npz, _ = golden
+    for i in range(int(npz["rbi_n"])):
+        a = npz[f"rbi_in_{i}"]
+        exp = npz[f"rbi_out_{i}"]
+        if a.ndim == 2:
+            out = ops.remove_border_instances(torch.from_numpy(a.astype(np.int32)).to(cuda)[None])
+            assert np.array_equal(out.cpu().numpy()[0], exp), i
+        else:
+            inst = torch.from_numpy(a[..., 0].astype(np.int32)).to(cuda)[None]
+            cls = torch.from_numpy(a[..., 1].astype(np.uint8)).to(cuda)[None]
+            o1, o2 = ops.remove_border_instances(inst, cls)
+            assert np.array_equal(o1.cpu().numpy()[0], exp[..., 0]), i
+            assert np.array_equal(o2.cpu().numpy()[0], exp[..., 1]), i

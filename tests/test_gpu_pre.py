@@ -1,0 +1,77 @@
+"""GPU parity: normalisation, sub-tiling and blending vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from classpose_amd import ops, synth
+from oracle import tiling
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiles(n, H, W, seed=0):
+    t = np.stack([synth.render_region(1234 + seed, 300 * i, 17 * i, W, H) for i in range(n)])
+    return t
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (200, 312), (64, 64)])
+def test_normalize_img_bit_exact(cuda, H, W):
+    t = _tiles(3, H, W)
+    t[1, ..., 2] = 77                                   # ptp == 0 channel stays untouched
+    t[2, ..., 0] = (t[2, ..., 0] > 128) * 255            # bimodal: x01 / x99 on distinct values
+    out = ops.normalize_img(torch.from_numpy(t).to(cuda)).cpu().numpy()
+    ref = tiling.normalize_img(t)
+    assert np.array_equal(out, ref)
+
+
+def test_normalize_interpolated_percentile(cuda):
+    """force sorted[655] != sorted[656] so the float32 lerp of np.percentile is exercised"""
+    rng = np.random.default_rng(0)
+    t = np.zeros((1, 256, 256, 3), np.uint8)
+    for c in range(3):
+        v = np.empty(65536, np.uint8)
+        v[:656] = 10 + c; v[656:64880] = 14 + 2 * c; v[64880:] = 200 + c
+        rng.shuffle(v)
+        t[0, ..., c] = v.reshape(256, 256)
+    out = ops.normalize_img(torch.from_numpy(t).to(cuda)).cpu().numpy()
+    assert np.array_equal(out, tiling.normalize_img(t))
+
+
+@pytest.mark.parametrize("H,W,aug", [(256, 256, False), (256, 256, True), (300, 260, False), (512, 512, False)])
+def test_make_subtiles_bit_exact(cuda, H, W, aug):
+    t = _tiles(2, H, W, 3)
+    sub, til = ops.make_subtiles(torch.from_numpy(t).to(cuda), 256, aug)
+    x = tiling.normalize_img(t)
+    ref = np.concatenate([tiling.subtile_batch(x[i:i + 1], 256, aug)[0] for i in range(2)])
+    assert np.array_equal(sub.cpu().numpy(), ref)
+    # the bf16 patch rows are the same pixels, cast, in im2col order
+    pat, _ = ops.make_patches(torch.from_numpy(t).to(cuda), 256, aug)
+    nS = ref.shape[0]
+    exp = torch.from_numpy(ref).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5).reshape(nS * 1024, 192)
+    assert torch.equal(pat.cpu(), exp.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("H,W,aug", [(256, 256, False), (256, 256, True), (300, 260, True)])
+def test_blend_subtiles_bit_exact(cuda, H, W, aug):
+    rng = np.random.default_rng(1)
+    nT, ncls = 2, 7
+    til_geoms = [tiling.subtile_batch(np.zeros((1, H, W, 3), np.float32), 256, aug)[1] for _ in range(nT)]
+    nsub = til_geoms[0]["ny"] * til_geoms[0]["nx"]
+    y = rng.standard_normal((nT * nsub, 3, 256, 256)).astype(np.float32)
+    yc = rng.standard_normal((nT * nsub, ncls, 256, 256)).astype(np.float32)
+    from classpose_amd.engine import make_tiling
+    til = make_tiling(H, W, 256, aug)
+    dP, cp, lg = ops.blend_subtiles(torch.from_numpy(y).to(cuda), torch.from_numpy(yc).to(cuda), til, nT)
+    for i in range(nT):
+        yf, ycf = tiling.blend_subtiles(y[i * nsub:(i + 1) * nsub], yc[i * nsub:(i + 1) * nsub], til_geoms[i], aug)
+        assert np.array_equal(dP.cpu().numpy()[i], yf[:2])
+        assert np.array_equal(cp.cpu().numpy()[i], yf[2])
+        assert np.array_equal(lg.cpu().numpy()[i], ycf)
+    # token-major head layout (pixel shuffle) gives the same result
+    ld = 640
+    head = np.zeros((nT * nsub, 1024, ld), np.float32)
+    full = np.concatenate([y, yc], 1)                     # [nS, 3+ncls, 256, 256]
+    head[:, :, : (3 + ncls) * 64] = (full.reshape(nT * nsub, 3 + ncls, 32, 8, 32, 8)
+                                     .transpose(0, 2, 4, 1, 3, 5).reshape(nT * nsub, 1024, -1))
+    dP2, cp2, lg2 = ops.blend_head(torch.from_numpy(head).to(cuda), ld, ncls, til, nT)
+    assert torch.equal(dP2, dP) and torch.equal(cp2, cp) and torch.equal(lg2, lg)

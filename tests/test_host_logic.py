@@ -1,0 +1,97 @@
+"""CPU: host-side logic of classpose_amd (no compute calls on the HIP library)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from classpose_amd import _lib, engine, synth
+from oracle import tiling
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    so = _lib.LIB_PATH
+    if not os.path.exists(so):
+        _lib.build()
+    L = ctypes.CDLL(so)
+    hdr = open(os.path.join(ROOT, "include", "classpose_hip.h")).read()
+    declared = set(re.findall(r"\b(cpx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().cpx_abi_version() == _lib.ABI_VERSION
+    assert _lib.lib().cpx_postproc_workspace_bytes(2, 256, 256) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CpxError):
+        _lib.lib()
+
+
+@pytest.mark.parametrize("H,W,aug", [(256, 256, False), (256, 256, True), (512, 512, False),
+                                     (300, 260, False), (1024, 1024, False), (200, 256, True)])
+def test_make_tiling_matches_oracle(H, W, aug):
+    t = engine.make_tiling(H, W, 256, aug)
+    x = np.zeros((1, H, W, 3), np.float32)
+    _, geom = tiling.subtile_batch(x, 256, aug)
+    assert (t.ny, t.nx) == (geom["ny"], geom["nx"])
+    assert (t.Ly, t.Lx) == (geom["Ly"], geom["Lx"])
+    assert (t.ypad1, t.xpad1) == (geom["pads"][0], geom["pads"][2])
+    ys = sorted({a for a, _ in geom["ysub"]})
+    xs = sorted({a for a, _ in geom["xsub"]})
+    assert list(t.ystart[: t.ny]) == ys and list(t.xstart[: t.nx]) == xs
+
+
+def test_sub_tile_counts_of_the_baseline_configs():
+    assert engine.make_tiling(256, 256).ny * engine.make_tiling(256, 256).nx == 4
+    assert engine.make_tiling(256, 256, augment=True).ny ** 2 == 9
+    assert engine.make_tiling(512, 512).ny ** 2 == 9
+    assert engine.make_tiling(512, 512, augment=True).ny ** 2 == 25
+
+
+def test_taper_matches_oracle():
+    assert np.array_equal(engine.taper_1d(256), tiling.taper_mask_1d(256))
+    assert np.array_equal(np.outer(engine.taper_1d(256), engine.taper_1d(256)), tiling.taper_mask(256, 256))
+
+
+@pytest.mark.parametrize("n", [65536, 256 * 300, 1000, 97])
+def test_percentile_params_reproduce_numpy(n):
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 256, n).astype(np.uint8).astype(np.float32)
+    s = np.sort(x)
+    for q in (1, 99):
+        prev, g = engine.percentile_params(n, q)
+        a, b = s[prev], s[min(prev + 1, n - 1)]
+        t = np.float32(g)
+        diff = b - a
+        r = a + diff * t
+        if t >= 0.5:
+            r = b - diff * (np.float32(1) - t)
+        assert np.float32(r) == np.percentile(x, q)
+
+
+def test_synthetic_slide_is_a_pure_function_of_coordinates():
+    s = synth.SyntheticSlide(2000, 1500, mpp=0.5, seed=7)
+    a = s.read_region((100, 200), 0, (300, 200))
+    b = s.read_region((250, 300), 0, (100, 50))
+    assert a.shape == (200, 300, 4) and a.dtype == np.uint8
+    assert np.array_equal(a[100:150, 150:250], b)
+    assert float(s.properties["openslide.mpp-x"]) == 0.5
+    u = synth.SyntheticSlide.from_uri("synthetic://10000x8000?mpp=0.25&seed=3")
+    assert u.level_dimensions[0] == (10000, 8000) and u.seed == 3
+
+
+def test_state_dict_layout_matches_infer_structure():
+    sd = synth.make_state_dict(7, None, depth=2)
+    fts, ncls, depth = engine.NetWeights.infer_structure(sd)
+    assert (fts, ncls, depth) == (None, 7, 2)
+    sd = synth.make_state_dict(10, [64, 128], depth=1)
+    fts, ncls, depth = engine.NetWeights.infer_structure(sd)
+    assert (fts, ncls, depth) == ([64, 128], 10, 1)
+    assert sd["W3"].shape == (640, 10, 8, 8)
+    assert sd["encoder.blocks.0.attn.rel_pos_h"].shape == (27, 64)
