@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: WSI tiles/s (+ cells/s) of the classpose tile path on MI355X.
+
+Workload = BASELINE.json configs[1]: synthetic 10 000 x 10 000 WSI, tile 256 / overlap 32,
+conic (7 classes), bf16, batch 32 sub-tiles (= 8 WSI tiles of 4 overlapping 256^2 sub-tiles,
+exactly the reference's per-tile sub-tiling, batched across tiles).  A "step" is one pass of
+the whole path over one batch of 8 tiles whose uint8 pixels are already resident in HBM:
+percentile normalisation -> pad/sub-tile -> ViT-L ClassTransformer (24 blocks, random-init
+weights of the reference layout) -> pixel-shuffle/taper blend -> flow dynamics -> instance ids
+-> class vote -> per-cell records (+ their D2H copy).  Random weights produce no meaningful
+cells, so the dynamics consume analytic flow/cellprob/logit fields rendered from the same
+procedural nuclei ("flow injection") while the network still runs on the pixels.
+
+    python bench.py --gpus 1 --steps 40 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from classpose_amd import _lib, engine, parallel, synth, wsi  # noqa: E402
+
+SLIDE = 10000
+TILE, OVERLAP, NCLS = 256, 32, 7
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def render_batches(coords, idxs, n_batches, bt, seed=1234):
+    tiles, fields, ncell = [], [], 0
+    for b in range(n_batches):
+        ts, dp, cp, lg = [], [], [], []
+        for k in range(bt):
+            (x0, y0), _ = coords[idxs[(b * bt + k) % len(idxs)]]
+            ts.append(synth.render_region(seed, x0, y0, TILE, TILE))
+            a = synth.analytic_fields(seed, x0, y0, TILE, TILE, NCLS)
+            dp.append(a[0]); cp.append(a[1]); lg.append(a[2])
+        tiles.append(np.stack(ts))
+        fields.append((np.stack(dp), np.stack(cp), np.stack(lg)))
+    return tiles, fields
+
+
+def cpu_baseline(sd, coords, budget_s=15.0, max_tiles=8):
+    """Reference-shaped CPU path (the oracle, kind 'port'), one tile per eval like
+    predict_wsi.worker: normalize -> run_net (4 sub-tiles, torch-CPU fp32) -> compute_masks on
+    the same injected fields -> class vote -> records.  Bounded sample."""
+    from oracle import classmask, dynamics, net, tiling
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fw = net.make_forward(sd, torch.float32)
+    fw(np.zeros((1, 3, 256, 256), np.float32))                       # warm-up (thread pool, caches)
+    n, cells, t0 = 0, 0, time.perf_counter()
+    while n < max_tiles and (n == 0 or time.perf_counter() - t0 < budget_s):
+        (x0, y0), _ = coords[n]
+        tile = synth.render_region(1234, x0, y0, TILE, TILE)
+        dP, cp, lg, _ = synth.analytic_fields(1234, x0, y0, TILE, TILE, NCLS)
+        t1 = time.perf_counter()
+        x = tiling.normalize_img(tile[None])
+        tiling.run_net(fw, x, batch_size=8, bsize=256)
+        m = dynamics.compute_masks(dP, cp)
+        cm, _ = classmask.compute_class_masks(m, lg)
+        classmask.instance_records(m, cm)
+        t0 += 0.0
+        cells += int(m.max())
+        n += 1
+        if n == 1:
+            first = time.perf_counter() - t1
+            t0 = time.perf_counter() - first                          # exclude rendering of tile 0
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="tiles/s", cores=cores, kind="port",
+                cells_per_s=cells / dt,
+                sample=f"{n} tiles of the same workload, one tile per eval (4 sub-tiles, fp32 torch-CPU "
+                       f"ViT-L + oracle dynamics on the injected fields), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-tiles", type=int, default=8)
+    ap.add_argument("--pool", type=int, default=2, help="distinct tile batches kept resident in HBM")
+    ap.add_argument("--depth", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    L = _lib.lib()
+
+    sd = synth.make_state_dict(NCLS, None, depth=args.depth, seed=0)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", dev)
+    bt = args.batch_tiles
+    eng = engine.Engine(w, TILE, batch_tiles=bt)
+    slide = synth.SyntheticSlide(SLIDE, SLIDE, mpp=0.5, seed=1234)
+    plan = wsi.plan_slide(slide, TILE, OVERLAP, 0.5)
+    coords = plan.coords
+    assert len(coords) == 1936
+    mine = list(parallel.shard_indices(len(coords), rank, world))      # tile k -> rank k % world
+    tiles_h, fields_h = render_batches(coords, mine, args.pool, bt)
+    tiles = [torch.from_numpy(t).to(dev) for t in tiles_h]
+    fields = [tuple(torch.from_numpy(a).to(dev) for a in f) for f in fields_h]
+    rec_bytes = C.sizeof(_lib.CpxRecord)
+    pinned = torch.empty(eng.records.numel(), dtype=torch.uint8).pin_memory()
+    pinned_cnt = torch.empty(bt, dtype=torch.int32).pin_memory()
+    cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    rec_keep = []
+
+    def step(i, keep=False):
+        p = i % args.pool
+        out = eng.run(tiles[p], inject=fields[p], records=True)
+        pinned.copy_(eng.records, non_blocking=True)                   # records leave the device
+        pinned_cnt.copy_(eng.rec_counts, non_blocking=True)
+        cells_acc.add_(out.nlabels.sum())
+        if keep:
+            rec_keep.append(eng.records.view(bt, eng.max_rec, rec_bytes)[:, :256].clone())
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    cells_acc.zero_()
+    _lib.check(L.cpx_prof_enable(args.steps * args.depth + 8), "prof_enable")
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, keep=(i == args.steps - 1))
+    # the path's one exchange: per-cell records of this rank's shard -> every rank (RCCL)
+    rec = rec_keep[-1].reshape(-1, rec_bytes)
+    allrec = parallel.all_gather_records(rec)
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.allreduce_max(dt, dev)
+    cells = parallel.allreduce_sum(float(cells_acc.item()), dev)
+    ms_sum, cnt = C.c_double(0), C.c_int(0)
+    _lib.check(L.cpx_prof_collect(C.byref(ms_sum), C.byref(cnt)), "prof_collect")
+    L.cpx_prof_enable(0)
+
+    n_tiles = args.steps * bt * world
+    M = bt * eng.n_sub * 1024
+    fc1_flops = 2.0 * M * 4096 * 1024
+    avg_ms = ms_sum.value / max(cnt.value, 1)
+    achieved = fc1_flops / (avg_ms * 1e-3) / 1e12 if cnt.value else 0.0
+    flop_per_tile = 727.3e9 * eng.n_sub
+    line = {
+        "metric": "wsi_tiles_per_sec",
+        "value": n_tiles / dt,
+        "unit": "tiles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "cells_per_sec": cells / dt,
+        "network_tflops": n_tiles * flop_per_tile / dt / 1e12 / world,
+        "config": {"workload": "configs[1]: synthetic 10000x10000 WSI (1936 tiles), tile 256 / overlap 32, "
+                               "conic 7 classes, ViT-L ClassTransformer depth %d random-init, batch 32 "
+                               "sub-tiles = %d WSI tiles/step, flow-injection dynamics, tiles sharded "
+                               "k %% n_gpus" % (args.depth, bt),
+                   "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * eng.n_sub,
+                   "tiles_per_step": bt, "records_gathered": int(allrec.shape[0])},
+        "roofline": {"bound": "mfma", "kernel": "k_gemm<GELU> (mlp.lin1 %dx4096x1024)" % M,
+                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "launches_timed": cnt.value, "avg_launch_ms": avg_ms},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, coords)
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

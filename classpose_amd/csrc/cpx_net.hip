@@ -359,6 +359,36 @@ extern "C" size_t cpx_net_workspace_bytes(int n_subtiles) {
 
 extern "C" void cpx_set_half_dtype(int f16);
 
+// ---------------------------------------------------------------------------
+// optional per-launch timing of the dominant kernel (the fc1 GEMM, k_gemm<GELU>):
+// HIP events recorded on the launch stream around every fc1 launch of a forward.
+// Events are created by cpx_prof_enable (never inside the launch path).
+// ---------------------------------------------------------------------------
+static hipEvent_t *g_prof_ev = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+extern "C" int cpx_prof_enable(int max_launches) {
+    for (int i = 0; i < 2 * g_prof_cap; ++i) (void)hipEventDestroy(g_prof_ev[i]);
+    delete[] g_prof_ev; g_prof_ev = nullptr; g_prof_cap = 0; g_prof_n = 0;
+    if (max_launches <= 0) return CPX_OK;
+    g_prof_ev = new hipEvent_t[2 * (size_t)max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i) CPX_HIP(hipEventCreate(&g_prof_ev[i]));
+    g_prof_cap = max_launches;
+    return CPX_OK;
+}
+// sum of elapsed ms and number of timed launches since enable; call after a stream sync
+extern "C" int cpx_prof_collect(double *ms_sum, int *count) {
+    double s = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        CPX_HIP(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        s += ms;
+    }
+    if (ms_sum) *ms_sum = s;
+    if (count) *count = g_prof_n;
+    g_prof_n = 0;
+    return CPX_OK;
+}
+
 extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, int nS, float *head,
                                void *workspace, size_t workspace_bytes, void *stream) {
     CPX_REQUIRE(w && patches && head && workspace && nS > 0);
@@ -382,7 +412,10 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
         RUN(cpx_attention_relpos(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream));
         RUN(cpx_gemm_bf16(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, stream));
         RUN(cpx_layernorm_bf16(x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
+        const bool prof = g_prof_ev && g_prof_n < g_prof_cap;
+        if (prof) CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n], (hipStream_t)stream));
         RUN(cpx_gemm_bf16(xn, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, stream));
+        if (prof) { CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], (hipStream_t)stream)); ++g_prof_n; }
         RUN(cpx_gemm_bf16(hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, stream));
     }
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d

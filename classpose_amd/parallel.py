@@ -1,0 +1,91 @@
+"""Multi-GPU plumbing for the tile path: static tile sharding + one record all-gather.
+
+The reference shares ONE multiprocessing queue between per-device worker processes
+and funnels every (masks, class_masks) array through one PostProcessor process
+(/root/reference/src/classpose/entrypoints/predict_wsi.py:1542-1572, 547-566);
+it uses no collective in inference.  Here each rank (one process per GPU, launched
+by torch.distributed.run) owns the tiles ``k % world == rank`` of the
+``_get_coords`` order -- no data-path collective -- and the only exchange is a
+variable-length all-gather of the compact per-cell records at the end of the
+slide (RCCL over xGMI on the GPU box, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> tuple[int, int, int]:
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
+            int(os.environ.get("LOCAL_RANK", 0)))
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment (no-op for world 1)."""
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> range:
+    """Tile k of the x-major ``_get_coords`` order goes to rank k % world."""
+    return range(rank, n_items, world)
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_max(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_sum(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
+    """Variable-length all-gather of per-cell records.
+
+    rec: [n_local, rec_bytes] uint8 on this rank's device (n_local may be 0).
+    Returns [sum n, rec_bytes] with rank 0's records first (deterministic order).
+    Implemented as an all-gather of counts followed by one padded
+    all_gather_into_tensor: the payload is tiny (48 B per cell), so a single
+    latency-bound exchange beats anything cleverer on point-to-point xGMI.
+    """
+    if not dist.is_initialized():
+        return rec
+    world = dist.get_world_size()
+    dev = rec.device
+    n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n)
+    mx = max(int(counts.max().item()), 1)
+    width = rec.shape[1]
+    padded = torch.zeros((mx, width), dtype=torch.uint8, device=dev)
+    padded[: rec.shape[0]] = rec
+    out = torch.empty((world * mx, width), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, padded)
+    out = out.view(world, mx, width)
+    return torch.cat([out[r, : int(counts[r])] for r in range(world)], 0)

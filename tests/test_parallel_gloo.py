@@ -1,0 +1,62 @@
+"""CPU: the N>1 path (tile sharding + record all-gather) over gloo, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from classpose_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = parallel.init_distributed("gloo")
+    idx = list(parallel.shard_indices(11, r, w))
+    # each rank "finds" a different number of cells; rank 1 may even find none
+    n = 5 if r == 0 else 0
+    rec = torch.full((n, 48), r + 1, dtype=torch.uint8)
+    rec[:, 0] = torch.arange(n, dtype=torch.uint8)
+    allrec = parallel.all_gather_records(rec)
+    rec2 = torch.full((3 + r, 48), 10 + r, dtype=torch.uint8)
+    allrec2 = parallel.all_gather_records(rec2)
+    mx = parallel.allreduce_max(float(r + 1), torch.device("cpu"))
+    sm = parallel.allreduce_sum(float(r + 1), torch.device("cpu"))
+    parallel.barrier()
+    q.put((r, idx, allrec.numpy(), allrec2.numpy(), mx, sm))
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_and_all_gather_records_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6, 8, 10] and res[1][1] == [1, 3, 5, 7, 9]
+    for r in res:
+        assert r[2].shape == (5, 48) and np.all(r[2][:, 1] == 1)          # only rank 0 had records
+        assert r[3].shape == (7, 48)
+        assert np.all(r[3][:3, 5] == 10) and np.all(r[3][3:, 5] == 11)   # rank order preserved
+        assert r[4] == 2.0 and r[5] == 3.0
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def test_single_process_passthrough():
+    rec = torch.zeros((4, 48), dtype=torch.uint8)
+    assert parallel.all_gather_records(rec) is rec
+    assert list(parallel.shard_indices(5, 0, 1)) == [0, 1, 2, 3, 4]
