@@ -51,7 +51,21 @@ __device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c)
                                                        *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
+// (below half-precision output rounding by > 3 orders of magnitude); one v_exp + one v_rcp
+// instead of libm erff's ~40-instruction piecewise polynomial in the epilogue.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = 1.0f - poly * t * __expf(-z * z);
+    const float erfv = copysignf(e, x);
+    return 0.5f * x * (1.0f + erfv);
+}
 
 template <bool F16>
 __device__ __forceinline__ unsigned short to_half(float f) {

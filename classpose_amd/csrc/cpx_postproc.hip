@@ -53,7 +53,7 @@ static PPLayout pp_layout(int H, int W) {
     p.off_cnt = take(sizeof(int) * p.L);
     p.off_first = take(sizeof(int) * p.L);
     p.off_remap = take(sizeof(int) * p.L);
-    p.off_flag = take(sizeof(int) * p.L);
+    p.off_flag = take(sizeof(int) * (p.L > 65536 ? p.L : 65536));   // border flags index raw uint16 ids
     p.off_bbox = take(sizeof(int) * 4 * p.L);
     p.off_sumy = take(sizeof(unsigned long long) * p.L);
     p.off_sumx = take(sizeof(unsigned long long) * p.L);
@@ -808,7 +808,7 @@ __global__ void k_border_flag(const int32_t *__restrict__ masks, PPLayout lay, v
     else if (i < 2 * W + H) { y = i - 2 * W; x = 0; }
     else { y = i - 2 * W - H; x = W - 1; }
     int lab = masks[(size_t)blockIdx.y * lay.HW + y * W + x];
-    if (lab > 0 && lab < lay.L) WS(int, off_flag)[lab] = 1;
+    if (lab > 0 && lab < 65536) WS(int, off_flag)[lab] = 1;
 }
 
 __global__ void k_border_zero(int32_t *__restrict__ masks, uint8_t *__restrict__ cm, PPLayout lay,
@@ -817,7 +817,7 @@ __global__ void k_border_zero(int32_t *__restrict__ masks, uint8_t *__restrict__
     if (idx >= lay.HW) return;
     size_t t = blockIdx.y;
     int lab = masks[t * lay.HW + idx];
-    if (lab > 0 && WS(int, off_flag)[lab]) {
+    if (lab > 0 && lab < 65536 && WS(int, off_flag)[lab]) {
         masks[t * lay.HW + idx] = 0;
         if (cm) cm[t * lay.HW + idx] = 0;
     }
@@ -1016,7 +1016,7 @@ extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks,
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    hipLaunchKernelGGL(k_fill_i32, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay.off_flag, lay.L, 0, lay, ws);
+    hipLaunchKernelGGL(k_fill_i32, dim3(cpx_cdiv(65536, NTHR), nT), dim3(NTHR), 0, s, lay.off_flag, 65536, 0, lay, ws);
     hipLaunchKernelGGL(k_border_flag, dim3(cpx_cdiv(2 * (H + W), NTHR), nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_border_zero, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
     CPX_CHECK_LAUNCH();
