@@ -55,16 +55,18 @@ __device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c)
 // (below half-precision output rounding by > 3 orders of magnitude); one v_exp + one v_rcp
 // instead of libm erff's ~40-instruction piecewise polynomial in the epilogue.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    // gelu = 0.5 x (1 + erf(x / sqrt2)) = 0.5 x + 0.5 |x| (1 - poly(t) t exp(-x^2 / 2)),
+    // t = 1 / (1 + (p / sqrt2) |x|); constants folded so that |x| is a free source modifier
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(__fmaf_rn(0.23164189f, ax, 1.0f));          // 0.3275911 / sqrt(2)
     float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = 1.0f - poly * t * __expf(-z * z);
-    const float erfv = copysignf(e, x);
-    return 0.5f * x * (1.0f + erfv);
+    poly = __fmaf_rn(poly, t, -1.453152027f);
+    poly = __fmaf_rn(poly, t, 1.421413741f);
+    poly = __fmaf_rn(poly, t, -0.284496736f);
+    poly = __fmaf_rn(poly, t, 0.254829592f);
+    const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2/2)
+    const float e = __fmaf_rn(-(poly * t), ex, 1.0f);                       // erf(|x| / sqrt2)
+    return __fmaf_rn(0.5f * ax, e, 0.5f * x);
 }
 
 template <bool F16>
@@ -215,14 +217,253 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
     }
 }
 
+
+// ===========================================================================
+// 256 x 256 x 64 tile, 512 threads (8 waves = 2 (M) x 4 (N)), 4 phases per K tile
+// ===========================================================================
+// Per-wave output = 2 x 2 quadrants of (64 tokens x 32 channels): quadrant (hm, hn) covers
+// tokens 128*hm + 64*wm + [0,64) and channels 128*hn + 32*wn + [0,32), so in every phase ALL
+// waves read the same two 16 KB half-tiles (X_hm, W_hn) and a half-tile can be re-staged
+// as soon as its phase is over.  LDS = 2 K-tile buffers x {X0, X1, W0, W1} x 16 KB = 128 KB,
+// filled by 16-byte LDS-DMA with the chunk swizzle on the source address.  Schedule per K
+// tile t (reads -> quadrant), one half-tile staged per phase, each >= 2 phases after the last
+// read of the region it overwrites and never drained to zero in the steady state:
+//   p1: X0,W0 -> (0,0)   stage X1(t+1)        p3: X1 -> (1,1)   stage X0(t+2)
+//   p2: W1    -> (0,1)   stage W0(t+1)        p4: W0 -> (1,0)   stage W1(t+2), vmcnt(4)
+// The two wave rows (wm) run half a phase apart (one extra s_barrier for wm == 1 at the
+// start, one for wm == 0 at the end): on every SIMD one wave issues MFMAs while its partner
+// issues LDS reads and DMA.  Fragment reads are inline-asm ds_read_b128 so that hipcc
+// neither drains the DMA in front of them nor re-orders them across the raw barriers.
+// Epilogue: accumulators -> bf16 tile in LDS (528-byte rows) -> whole 512-byte rows stored
+// with 16-byte stores (+ residual add on the store side, = the reference's double rounding).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define G2_THREADS 512
+#define G2_HALF 16384
+#define G2_BUF 65536
+#define G2_EPI_LD 528
+#define G2_LDS_BYTES (256 * G2_EPI_LD)      // 135168 >= 2 * G2_BUF
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16v(const u32x4 &a, const u32x4 &b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int HM>
+__device__ __forceinline__ void g2_read_x(u32x4 (&fx)[4][2], unsigned b0, unsigned b1) {
+    fx[0][0] = lds_read128<HM * G2_HALF + 0 * 2048>(b0); fx[0][1] = lds_read128<HM * G2_HALF + 0 * 2048>(b1);
+    fx[1][0] = lds_read128<HM * G2_HALF + 1 * 2048>(b0); fx[1][1] = lds_read128<HM * G2_HALF + 1 * 2048>(b1);
+    fx[2][0] = lds_read128<HM * G2_HALF + 2 * 2048>(b0); fx[2][1] = lds_read128<HM * G2_HALF + 2 * 2048>(b1);
+    fx[3][0] = lds_read128<HM * G2_HALF + 3 * 2048>(b0); fx[3][1] = lds_read128<HM * G2_HALF + 3 * 2048>(b1);
+}
+template <int HN>
+__device__ __forceinline__ void g2_read_w(u32x4 (&fw)[2][2], unsigned b0, unsigned b1) {
+    fw[0][0] = lds_read128<(2 + HN) * G2_HALF + 0 * 2048>(b0); fw[0][1] = lds_read128<(2 + HN) * G2_HALF + 0 * 2048>(b1);
+    fw[1][0] = lds_read128<(2 + HN) * G2_HALF + 1 * 2048>(b0); fw[1][1] = lds_read128<(2 + HN) * G2_HALF + 1 * 2048>(b1);
+}
+template <bool F16>
+__device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][2], const u32x4 (&fw)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma16v<F16>(fw[nb][ks], fx[mb][ks], acc[mb][nb]);
+    __builtin_amdgcn_s_setprio(0);
+}
+#define G2_BAR() __builtin_amdgcn_s_barrier()
+#define G2_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int EPI, bool F16>
+__global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    int bid = blockIdx.x;
+    {
+        const int nxcd = 8, q = g.n_blocks / nxcd, r = g.n_blocks % nxcd, x = bid % nxcd;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / nxcd;
+    }
+    const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int K = g.K, nk = K / 64;
+
+    // staging: thread -> (row = tid>>3 (+64 for the second DMA), position pc = tid&7, source chunk kc)
+    const int srow = tid >> 3, kc = (tid & 7) ^ (srow & 7);
+    const unsigned short *pX = g.A + (size_t)(m0 + srow) * K + kc * 8;
+    const unsigned short *pW = g.W + (size_t)(n0 + srow) * K + kc * 8;
+    const size_t k64 = (size_t)64 * K, k128 = (size_t)128 * K;
+    char *sdst = smem + wave * 1024;
+    auto stage = [&](int which, int t) {        // which: 0 X0, 1 X1, 2 W0, 3 W1 (compile-time at call sites)
+        const unsigned short *p = (which < 2 ? pX : pW) + (which & 1) * k128 + (size_t)t * 64;
+        char *d = sdst + (t & 1) * G2_BUF + which * G2_HALF;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                         (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p + k64),
+                                         (__attribute__((address_space(3))) void *)(d + 8192), 16, 0, 0);
+    };
+
+    // fragment read bases (LDS byte addresses), one per k-substep and buffer
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    unsigned xb[2][2], wb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned sw = (unsigned)(((ks * 4 + fq) ^ (fr & 7)) << 4);
+        xb[0][ks] = lds0 + (wm * 64 + fr) * 128 + sw;
+        wb[0][ks] = lds0 + (wn * 32 + fr) * 128 + sw;
+        xb[1][ks] = xb[0][ks] + G2_BUF;
+        wb[1][ks] = wb[0][ks] + G2_BUF;
+    }
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 fx[4][2], fw[2][2];
+
+    // prologue: all of tile 0, then X0 / W1 of tile 1 (the two a steady-state tile -1 would have staged)
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+    if (nk > 1) { stage(0, 1); stage(3, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2_BAR();
+    if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
+
+#define G2_TILE(T, B)                                                                       \
+    {                                                                                       \
+        const int t_ = (T);                                                                 \
+        /* p1 */                                                                            \
+        g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
+        g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                               \
+        if (t_ + 1 < nk) stage(1, t_ + 1);                                                  \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[0][0], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        /* p2 */                                                                            \
+        g2_read_w<1>(fw, wb[B][0], wb[B][1]);                                               \
+        if (t_ + 1 < nk) stage(2, t_ + 1);                                                  \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[0][1], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        /* p3 */                                                                            \
+        g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                               \
+        if (t_ + 2 < nk) stage(0, t_ + 2);                                                  \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[1][1], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        /* p4 */                                                                            \
+        g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
+        if (t_ + 2 < nk) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+        else if (t_ + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[1][0], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+    }
+
+    for (int t = 0; t < nk; t += 2) {
+        G2_TILE(t, 0)
+        G2_TILE(t + 1, 1)
+    }
+#undef G2_TILE
+    if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: bias/activation in f32 -> half tile in LDS -> whole rows to HBM
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int ml = hm * 128 + wm * 64 + mb * 16 + fr;
+                    const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
+                    f32x4 v = acc[hm][hn][mb][nb];
+                    if (g.bias) {
+                        const float4 b = *reinterpret_cast<const float4 *>(g.bias + n0 + nl);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if constexpr (EPI == CPX_EPI_GELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    uint2 o;
+                    o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
+                    o.y = (unsigned)to_half<F16>(v[2]) | ((unsigned)to_half<F16>(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(smem + ml * G2_EPI_LD + nl * 2) = o;
+                }
+    __syncthreads();
+    {
+        const int c16 = tid & 31;               // 16-byte chunk within the 512-byte row
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 16 + (tid >> 5);
+            uint4 v = *reinterpret_cast<const uint4 *>(smem + ml * G2_EPI_LD + c16 * 16);
+            const size_t go = (size_t)(m0 + ml) * g.ld_out + n0 + c16 * 8;
+            if constexpr (EPI == CPX_EPI_RESID_BF16) {
+                const uint4 rr = *reinterpret_cast<const uint4 *>((const unsigned short *)g.aux + go);
+                unsigned a[4] = {v.x, v.y, v.z, v.w}, b[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = from_half<F16>(a[i] & 0xFFFF) + from_half<F16>(b[i] & 0xFFFF);
+                    float hi = from_half<F16>(a[i] >> 16) + from_half<F16>(b[i] >> 16);
+                    a[i] = (unsigned)to_half<F16>(lo) | ((unsigned)to_half<F16>(hi) << 16);
+                }
+                v = make_uint4(a[0], a[1], a[2], a[3]);
+            }
+            *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = v;
+        }
+    }
+}
+
 static int g_gemm_variant = 1;     // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
 static int g_gemm_f16 = 0;
 extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
 extern "C" void cpx_set_half_dtype(int f16) { g_gemm_f16 = f16; }
 extern "C" int cpx_get_half_dtype(void) { return g_gemm_f16; }
 
+static int g_gemm_big = 1;         // 1 = use the 256^2 kernel when the shape allows
+extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
+
+template <int EPI, bool F16>
+static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
+    if constexpr (EPI == CPX_EPI_F32 || EPI == CPX_EPI_POS_BF16) return false;
+    else {
+        if (!g_gemm_big || a0.M % 256 || a0.N % 256 || (a0.K / 64) % 2 || a0.K < 128) return false;
+        if ((a0.M / 256) * (a0.N / 256) < 256) return false;          // not enough tiles for 256 CUs
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+            attr_done = true;
+        }
+        GemmArgs a = a0;
+        a.tiles_n = a.N / 256; a.n_blocks = (a.M / 256) * (a.N / 256);
+        hipLaunchKernelGGL((k_gemm256<EPI, F16>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
+        return true;
+    }
+}
+
 template <int EPI>
 static void launch_gemm(const GemmArgs &a, hipStream_t s) {
+    if (g_gemm_f16 ? launch_gemm256<EPI, true>(a, s) : launch_gemm256<EPI, false>(a, s)) return;
     dim3 grid(a.n_blocks), block(GEMM_THREADS);
     size_t lds = 2 * STAGE_BYTES;
     if (g_gemm_f16) {

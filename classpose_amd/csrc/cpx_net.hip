@@ -45,6 +45,17 @@ __device__ __forceinline__ float f32_from_h(unsigned short u) {
     else return bf16_to_f32(u);
 }
 
+// two floats -> one dword of two halves with a single v_cvt_pk_* (vector convert)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
 // ---------------------------------------------------------------------------
 // LayerNorm over the last dim (C = 1024 or 256), one wave per row
 // ---------------------------------------------------------------------------
@@ -216,11 +227,16 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     *reinterpret_cast<uint4 *>(&sV[0][v_dst]) = vreg;
     __syncthreads();
 
-    f32x16 O[2];
+    f32x16 O[2], GW, Lacc;                                   // Lacc row 0 = running softmax denominator
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; }
-    float m_run = -1e30f, l_run = 0.f;
+    for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; GW[i] = gw[i]; Lacc[i] = 0.f; }
+    // A operand whose row 0 is all ones: (ones . P^T)[0][q] = sum_k P[k][q], summed over both
+    // half-waves by the MFMA itself -> no VALU adds and no cross-lane reduction for the row sums
+    const unsigned one2 = F16 ? 0x3C003C00u : 0x3F803F80u;
+    const uint4 ones_f = r == 0 ? make_uint4(one2, one2, one2, one2) : make_uint4(0, 0, 0, 0);
+    float m_run = -1e30f;
     const float cexp = 0.125f * 1.44269504088896340736f;   // softmax scale (64^-0.5) * log2(e)
+    const float RESCALE_THR = 6.0f;                         // defer-max: tolerate p <= 2^6 (exp2 domain)
     const int krow = pi_perm(r);                            // key row this lane feeds to the K operand
 
     for (int kh = 0; kh < 32; ++kh) {
@@ -229,39 +245,54 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
             kreg = *reinterpret_cast<const uint4 *>(kbase + (size_t)(kh + 1) * 32 * 3072);
             vreg = *reinterpret_cast<const uint4 *>(vbase + (kh + 1) * 32);
         }
-        // S^T = K . Q^T, accumulator pre-loaded with the bias
+        // S' = K . Q^T + Gw   (Gw rides in as the MFMA C operand; Gh is one scalar per lane and
+        // is folded into the exponent offset, so the bias costs no per-element VALU work)
         const float gh = G[r * GS_LD + (qh - kh + 31)];
         f32x16 S;
+        {
+            uint4 kf = *reinterpret_cast<const uint4 *>(&sK[buf][krow * 64 + (((0 + h2) ^ (krow & 7)) * 8)]);
+            S = mfma32<F16>(kf, qf[0], GW);
+        }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] = gw[i] + gh;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 1; ks < 4; ++ks) {
             uint4 kf = *reinterpret_cast<const uint4 *>(&sK[buf][krow * 64 + (((2 * ks + h2) ^ (krow & 7)) * 8)]);
             S = mfma32<F16>(kf, qf[ks], S);
         }
         // online softmax (per lane = per query; the two half-waves hold different keys)
-        float mx = S[0];
+        float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, S[i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * cexp);
-        float psum = 0.f;
+        for (int i = 3; i < 15; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, S[i]), S[i + 1]);
+        mx = __builtin_fmaxf(mx, S[15]);
+        {   // other half-wave's maximum: one VALU half-swap instead of an LDS bpermute round trip
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __uint_as_float(sw[0])), __uint_as_float(sw[1])) + gh;
+        }
+        // deferred rescale: keep the old reference max while the new one is within 2^THR of it
+        if (!__all((mx - m_run) * cexp <= RESCALE_THR)) {
+            const float m_new = __builtin_fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);
+            Lacc[0] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+            m_run = m_new;
+        }
+        const float off = (gh - m_run) * cexp;
         float p[16];
+        const f32x2_t c2 = {cexp, cexp}, off2 = {off, off};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p[i] = exp2f((S[i] - m_new) * cexp); psum += p[i]; }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+        for (int i = 0; i < 16; i += 2) {
+            f32x2_t sv = {S[i], S[i + 1]};
+            f32x2_t a = sv * c2 + off2;                    // one v_pk_fma_f32
+            p[i] = __builtin_amdgcn_exp2f(a[0]);
+            p[i + 1] = __builtin_amdgcn_exp2f(a[1]);
+        }
         // P^T (accumulator layout) -> B operand of the P.V product, natural key order
         uint4 pf[2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             unsigned u[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                u[jj] = (unsigned)h_from_f32<F16>(p[8 * st + 2 * jj]) | ((unsigned)h_from_f32<F16>(p[8 * st + 2 * jj + 1]) << 16);
+            for (int jj = 0; jj < 4; ++jj) u[jj] = pack2<F16>(p[8 * st + 2 * jj], p[8 * st + 2 * jj + 1]);
             pf[st] = make_uint4(u[0], u[1], u[2], u[3]);
         }
 #pragma unroll
@@ -273,13 +304,16 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
                 O[db] = mfma32<F16>(vf, pf[st], O[db]);
             }
         }
+        Lacc = mfma32<F16>(ones_f, pf[0], Lacc);
+        Lacc = mfma32<F16>(ones_f, pf[1], Lacc);
         if (kh + 1 < 32) {
             *reinterpret_cast<uint4 *>(&sK[buf ^ 1][k_dst]) = kreg;
             *reinterpret_cast<uint4 *>(&sV[buf ^ 1][v_dst]) = vreg;
         }
         __syncthreads();
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    // row 0 of Lacc sits in register 0 of the lower half-wave (row = (reg&3)+8*(reg>>2)+4*h2)
+    const float l_tot = __shfl(Lacc[0], r);
     const float inv = 1.0f / l_tot;
     unsigned short *orow = out + (tok0 + qh * 32 + r) * 1024 + head * 64;
 #pragma unroll

@@ -47,6 +47,46 @@ def test_gemm_epilogues(cuda, variant, M, N, K):
         _lib.lib().cpx_gemm_set_variant(1)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 1024), (16384, 1024, 128), (16384, 1024, 256),
+                                   (4096, 4096, 4096), (32768, 512, 192 * 2)])
+def test_gemm256_epilogues(cuda, M, N, K):
+    """the 256x256 8-phase kernel (taken when M%256 == N%256 == 0, K/64 even, >= 256 tiles)
+    against the 128x128 kernel and torch fp32"""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(cuda)
+    ref = A.float() @ W.float().T
+    L = _lib.lib()
+    outs = {}
+    for big in (1, 0):
+        L.cpx_gemm_set_big(big)
+        try:
+            outs[big] = [ops.gemm(A, W, "bf16", None), ops.gemm(A, W, "bf16", bias), ops.gemm(A, W, "gelu", bias),
+                         ops.gemm(A, W, "relu", bias), ops.gemm(A, W, "resid", bias, res)]
+        finally:
+            L.cpx_gemm_set_big(1)
+    exp = [ref, ref + bias, torch.nn.functional.gelu(ref + bias), torch.relu(ref + bias), ref + bias + res.float()]
+    for k, (o1, o0, e) in enumerate(zip(outs[1], outs[0], exp)):
+        assert _rel(o1.float(), e) < 5e-3, (k, _rel(o1.float(), e))
+        # same fp32 accumulation order per output element up to the k-split -> nearly identical
+        assert _rel(o1.float(), o0.float()) < 3e-3, k
+    assert torch.equal(outs[1][0], outs[0][0]) or _rel(outs[1][0].float(), outs[0][0].float()) < 1e-3
+
+
+def test_gemm256_identity_asymmetric(cuda):
+    """exact layout check of the big kernel: A = [I | 0] rows against an asymmetric W"""
+    M, N, K = 16384, 1024, 128
+    A = torch.zeros(M, K)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    A = A.to(torch.bfloat16).to(cuda)
+    W = ((torch.arange(N * K).reshape(N, K) * 7) % 251 - 125).to(torch.bfloat16).to(cuda)
+    out = ops.gemm(A, W, "bf16", None)
+    exp = W.float().T[torch.arange(M, device=cuda) % K]
+    assert torch.equal(out.float(), exp)
+
+
 def test_gemm_identity_asymmetric(cuda):
     """A = I against an asymmetric W catches transposed / permuted fragment maps exactly."""
     K = N = 128
