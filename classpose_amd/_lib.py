@@ -45,6 +45,11 @@ class CpxRecord(C.Structure):
                 ("sum_y", C.c_int64), ("sum_x", C.c_int64)]
 
 
+class CpxCell(C.Structure):
+    _fields_ = [("area", C.c_double), ("perimeter", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("n_pts", C.c_int32), ("offset", C.c_int32), ("valid", C.c_int32), ("cls", C.c_int32)]
+
+
 _p, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/classpose_hip.h declares
@@ -72,6 +77,7 @@ SIGNATURES = {
     "cpx_remove_border_instances": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "cpx_compute_masks": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _d, _i, _i, _d, _p, _p, _p, _p, _p]),
     "cpx_instance_records": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "cpx_polygonize_host": (_i, [_p, _i, _i, _p, _i, _d, _d, _d, _p, _i, _p]),
 }
 # not part of the public header (debug / A-B switches)
 _PRIVATE = {

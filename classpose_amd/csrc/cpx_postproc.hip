@@ -1030,7 +1030,6 @@ extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const f
                                  uint8_t *class_masks, int32_t *nlabels, void *ws, void *stream) {
     int rc = pp_check(nT, H, W); if (rc) return rc;
     CPX_REQUIRE(dP && cellprob && masks_u16 && ws);
-    CPX_REQUIRE(H * (long long)W / 11 + 2 < 65536);
     CPX_REQUIRE(min_size > 0);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)nT * H * W;

@@ -1,0 +1,305 @@
+"""``classpose-predict-wsi`` on the MI355X engine: same flags, same outputs.
+
+Drop-in for /root/reference/src/classpose/entrypoints/predict_wsi.py (``main_with_args``
+:1891-2019, ``main`` :1451-1886) on the tile path:
+
+  slide -> tile grid (``_get_coords``) -> [per GPU] tiles streamed through pinned memory
+  -> Engine (normalise, sub-tile, ClassTransformer, blend, dynamics, class vote, records)
+  -> id maps + records to the host -> polygons/measurements (``cpx_polygonize_host``)
+  -> all-gather of the cell tables across ranks (RCCL) -> de-duplication -> GeoJSON.
+
+Differences by design (MI355X-first, results unchanged): tiles are batched across the slide
+instead of one ``model.eval([tile])`` per tile; one process per GPU with STATIC sharding
+(tile k -> rank k % world) instead of a shared queue; polygonisation runs in a thread pool of
+the rank that produced the tile instead of one PostProcessor process for all devices.
+Multi-GPU: either launch under ``torch.distributed.run`` or pass ``--device cuda:0,1,...``
+(this process then spawns one worker per listed GPU, like the reference does).
+
+Not built yet (raise, never silently ignored): GrandQC tissue/artefact detection, ROI
+filtering, ``--output_type`` csv/spatialdata, slides whose mpp differs from the model mpp.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import queue
+import sys
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import engine, geojson, parallel, postprocess, wsi
+from ..log import get_logger
+from ..model_configs import DEFAULT_MODEL_CONFIGS, ModelConfig
+
+logger = get_logger("classpose")
+
+DEFAULT_TILE_SIZE = 1024
+DEFAULT_OVERLAP = 64
+MIN_TILE_SIZE = 256
+
+GEOJSON_OUTPUT_TEMPLATES = {
+    "cell_contours": os.getenv("CLASSPOSE_CELL_CONTOURS_GEOJSON", "{base_name}_cell_contours.geojson"),
+    "cell_centroids": os.getenv("CLASSPOSE_CELL_CENTROIDS_GEOJSON", "{base_name}_cell_centroids.geojson"),
+    "tissue_contours": os.getenv("CLASSPOSE_TISSUE_CONTOURS_GEOJSON", "{base_name}_tissue_contours.geojson"),
+    "artefact_contours": os.getenv("CLASSPOSE_ARTEFACT_CONTOURS_GEOJSON", "{base_name}_artefact_contours.geojson"),
+    "roi": os.getenv("CLASSPOSE_ROI_GEOJSON", "{base_name}_roi.geojson"),
+}
+
+
+def get_geojson_output_filename(output_kind: str, base_name: str) -> str:
+    if output_kind not in GEOJSON_OUTPUT_TEMPLATES:
+        raise ValueError(f"Invalid output kind: {output_kind}. Valid options are: "
+                         + ", ".join(GEOJSON_OUTPUT_TEMPLATES))
+    return GEOJSON_OUTPUT_TEMPLATES[output_kind].format(base_name=base_name)
+
+
+def get_device(device: str | None = None) -> list[torch.device]:
+    """utils.get_device: ``cuda:0,1,2`` -> one device per index."""
+    if device is not None:
+        if ":" in device:
+            kind, idxs = device.split(":")
+            return [torch.device(f"{kind}:{i}") for i in idxs.split(",")]
+        return [torch.device(device)]
+    if torch.cuda.is_available():
+        return [torch.device("cuda")]
+    raise RuntimeError("no GPU visible: the MI355X engine has no CPU path")
+
+
+CELL_ROW = np.dtype([("area", "<f8"), ("perimeter", "<f8"), ("cx", "<f8"), ("cy", "<f8"),
+                     ("n_pts", "<i8"), ("cls", "<i8")])
+
+
+class TileStream:
+    """Reader thread: slide regions -> pinned host batches -> device (hipMemcpyAsync on a side
+    stream), double buffered so reads / copies overlap the engine."""
+
+    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3):
+        self.slide, self.plan, self.idxs, self.nT = slide, plan, list(idxs), nT
+        self.dev = device
+        self.q: queue.Queue = queue.Queue(maxsize=depth)
+        self.pinned = [torch.empty((nT, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(depth + 2)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        try:
+            for b, s in enumerate(range(0, len(self.idxs), self.nT)):
+                chunk = self.idxs[s:s + self.nT]
+                host = self.pinned[b % len(self.pinned)]
+                for k, ti in enumerate(chunk):
+                    host[k].copy_(torch.from_numpy(wsi.read_tile(self.slide, self.plan, self.plan.coords[ti])))
+                with torch.cuda.stream(self.copy_stream):
+                    dev = host[: len(chunk)].to(self.dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_stream)
+                self.q.put((chunk, dev, ev))
+            self.q.put(None)
+        except BaseException as e:      # surface reader errors in the consumer
+            self.q.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+
+def run_rank(args, rank: int, world: int, device: torch.device):
+    """Everything one GPU does; returns (cell table, vertex pool) of this rank's shard."""
+    if args.model_config in DEFAULT_MODEL_CONFIGS:
+        model_config = ModelConfig(**DEFAULT_MODEL_CONFIGS[args.model_config])
+    else:
+        model_config = ModelConfig.load_from_yaml(args.model_config)
+    model_config.download_if_necessary()
+    torch.cuda.set_device(device)
+    sd = model_config.load_state_dict()
+    fts, n_classes, _ = engine.NetWeights.infer_structure(sd)
+    if model_config.cell_types:
+        if len(model_config.cell_types) != n_classes - 1:
+            raise ValueError(f"Number of labels ({len(model_config.cell_types)}) does not match "
+                             f"number of classes ({n_classes - 1})")
+        labels = model_config.cell_types
+    else:
+        labels = [str(i) for i in range(1, n_classes)]
+    slide = wsi.WSIReader(args.slide_path)
+    plan = wsi.plan_slide(slide, args.tile_size, args.overlap, model_config.mpp)
+    if rank == 0:
+        logger.info(f"Slide MPP: {plan.mpp}; model MPP: {model_config.mpp}; tiles: {len(plan.coords)}; "
+                    f"slide dimensions: {plan.slide_dim}; tile {args.tile_size}/{args.overlap}")
+    weights = engine.NetWeights.from_state_dict(sd, args.precision, device)
+    H = W = args.tile_size
+    n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
+    nT = max(1, max(args.batch_size, 32) // n_sub)
+    eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
+    mine = list(parallel.shard_indices(len(plan.coords), rank, world))
+    stream = TileStream(slide, plan, mine, nT, H, W, device)
+    pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
+    futures = []
+    scale = plan.prediction_to_slide_scale
+    t0 = time.time()
+    n_done = 0
+    for chunk, tiles_dev, ev in stream:
+        torch.cuda.current_stream(device).wait_event(ev)
+        n = len(chunk)
+        inject = None
+        if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
+            # test / bench mode for synthetic slides with random weights: the dynamics consume
+            # analytic fields of the procedural nuclei, the network still runs on the pixels
+            from .. import synth
+            f = [synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], W, H, n_classes)
+                 for ti in chunk]
+            inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
+        out = eng.run(tiles_dev, inject=inject, records=True)
+        masks = out.masks.cpu().numpy().view(np.uint16)          # D2H: 2 B / pixel
+        recs = eng.fetch_records(n)
+        if int(out.nlabels.max()) >= 65535:
+            raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
+        for k, ti in enumerate(chunk):
+            origin = plan.coords[ti][0]
+            futures.append(pool.submit(postprocess.polygonize_tile, masks[k].copy(),
+                                       recs[recs["tile"] == k], scale, origin))
+        n_done += n
+        if rank == 0 and (n_done // nT) % 20 == 0:
+            logger.info(f"Predicted tiles: {n_done}/{len(mine)} ({n_done / max(time.time() - t0, 1e-9):.1f} tiles/s/GPU)")
+    cells_all, xy_all, n_invalid = [], [], 0
+    for f in futures:
+        cells, xy = f.result()
+        keep = cells["valid"] == 1
+        n_invalid += int((~keep).sum())
+        for c in cells[keep]:
+            xy_all.append(xy[c["offset"]: c["offset"] + c["n_pts"]])
+        rows = np.zeros(int(keep.sum()), CELL_ROW)
+        for name in ("area", "perimeter", "cx", "cy", "n_pts", "cls"):
+            rows[name] = cells[keep][name]
+        cells_all.append(rows)
+    pool.shutdown()
+    slide.close()
+    cells = np.concatenate(cells_all) if cells_all else np.zeros(0, CELL_ROW)
+    xy = np.concatenate(xy_all) if xy_all else np.zeros((0, 2))
+    logger.info(f"[rank {rank}] {len(cells)} cells, {n_invalid} invalid, {len(mine)} tiles in {time.time() - t0:.1f}s")
+    return cells, xy, labels, plan
+
+
+def gather_cells(cells: np.ndarray, xy: np.ndarray, device) -> tuple[np.ndarray, np.ndarray]:
+    """The path's one collective: per-rank cell tables + vertex pools -> every rank."""
+    c = torch.from_numpy(cells.view(np.uint8).reshape(len(cells), CELL_ROW.itemsize).copy()).to(device)
+    v = torch.from_numpy(np.ascontiguousarray(xy).view(np.uint8).reshape(len(xy), 16).copy()).to(device)
+    c = parallel.all_gather_records(c).cpu().numpy()
+    v = parallel.all_gather_records(v).cpu().numpy()
+    return c.reshape(-1).view(CELL_ROW), v.reshape(-1).view(np.float64).reshape(-1, 2)
+
+
+def write_outputs(args, cells, xy, labels, plan):
+    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])]).astype(np.int64)
+    curr = []
+    for i, c in enumerate(cells):
+        coords = xy[offs[i]: offs[i + 1]].tolist()
+        centroid = np.round([c["cx"], c["cy"]], 2).tolist()
+        curr.append(geojson.cell_dict(coords, int(c["cls"]), labels, c["area"], c["perimeter"], centroid))
+    polygons = [geojson.to_geojson_polygon(x) for x in curr]
+    logger.info(f"Number of detected cells: {len(polygons)}")
+    if len(polygons) == 0:
+        logger.warning("No cells detected")
+        return None
+    polygons = geojson.deduplicate(polygons)
+    logger.info(f"Number of cells after de-duplication: {len(polygons)}")
+    if args.min_area and args.min_area > 0:
+        pass   # --min_area only applies to tissue polygons in the reference (predict_wsi.py:1948-1955)
+    bx, by = plan.bounds
+    if bx != 0 or by != 0:
+        polygons = [geojson.apply_bounds_offset_to_feature(p, bx, by) for p in polygons]
+    out = Path(args.output_folder)
+    out.mkdir(parents=True, exist_ok=True)
+    base = Path(args.slide_path.split("?")[0]).stem if "://" not in args.slide_path else \
+        args.slide_path.split("://", 1)[1].split("?")[0].replace("/", "_")
+    contours = out / get_geojson_output_filename("cell_contours", base)
+    centroids = out / get_geojson_output_filename("cell_centroids", base)
+    with open(contours, "w") as f:
+        json.dump({"type": "FeatureCollection", "features": polygons}, f)
+    with open(centroids, "w") as f:
+        json.dump({"type": "FeatureCollection", "features": geojson.polygons_to_centroids(polygons)}, f)
+    logger.info(f"Wrote {contours} and {centroids}")
+    return contours, centroids
+
+
+def _check_unsupported(args):
+    for name in ("tissue_detection_model_path", "artefact_detection_model_path", "roi_geojson"):
+        if getattr(args, name):
+            raise NotImplementedError(f"--{name} is not built yet on the MI355X engine (SURVEY 8f next rows)")
+    if args.filter_artefacts or args.output_type:
+        raise NotImplementedError("--filter_artefacts / --output_type are not built yet")
+    if args.tile_size < MIN_TILE_SIZE:
+        raise ValueError(f"Tile size must be at least {MIN_TILE_SIZE}, got {args.tile_size}")
+
+
+def _spawn_entry(local_rank: int, world: int, port: int, argv: list[str], dev_ids: list[int]):
+    os.environ.update(RANK=str(local_rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev_ids[local_rank]),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    main(build_parser().parse_args(argv), spawned=True)
+
+
+def main(args, spawned: bool = False):
+    _check_unsupported(args)
+    devices = get_device(args.device)
+    env_world = int(os.environ.get("WORLD_SIZE", 1))
+    if len(devices) > 1 and env_world == 1 and not spawned:
+        import socket
+        import torch.multiprocessing as mp
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ids = [d.index or 0 for d in devices]
+        mp.start_processes(_spawn_entry, args=(len(devices), port, sys.argv[1:], ids),
+                           nprocs=len(devices), start_method="spawn")
+        return
+    rank, world, local = parallel.init_distributed()
+    device = torch.device("cuda", local) if world > 1 else \
+        (devices[0] if devices[0].index is not None else torch.device("cuda", 0))
+    cells, xy, labels, plan = run_rank(args, rank, world, device)
+    if world > 1:
+        cells, xy = gather_cells(cells, xy, device)
+    if rank == 0:
+        write_outputs(args, cells, xy, labels, plan)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Predict Classpose cells and centroids for a whole-slide image (MI355X engine)")
+    p.add_argument("--model_config", type=str, required=True,
+                   help="One of %s or a path to a YAML model config" % ", ".join(DEFAULT_MODEL_CONFIGS))
+    p.add_argument("--slide_path", type=str, required=True)
+    p.add_argument("--output_folder", type=str, required=True)
+    p.add_argument("--tissue_detection_model_path", type=str, default=None)
+    p.add_argument("--artefact_detection_model_path", type=str, default=None)
+    p.add_argument("--filter_artefacts", action=argparse.BooleanOptionalAction, default=False)
+    p.add_argument("--roi_geojson", type=str, default=None)
+    p.add_argument("--roi_class_priority", type=str, nargs="+", default=None)
+    p.add_argument("--min_area", type=int, default=0)
+    p.add_argument("--tta", action=argparse.BooleanOptionalAction, default=False)
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("--device", type=str, default=None)
+    p.add_argument("--precision", type=str, default="bf16", choices=["fp32", "fp16", "bf16"])
+    p.add_argument("--tile_size", type=int, default=DEFAULT_TILE_SIZE)
+    p.add_argument("--overlap", type=int, default=DEFAULT_OVERLAP)
+    p.add_argument("--output_type", type=str, nargs="+", default=None, choices=["csv", "spatialdata"])
+    p.add_argument("--inference_threads", type=int, default=None,
+                   help="accepted for compatibility; the engine overlaps stages with HIP streams instead")
+    return p
+
+
+def main_with_args():
+    main(build_parser().parse_args())
+
+
+if __name__ == "__main__":
+    main_with_args()

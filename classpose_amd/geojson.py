@@ -1,0 +1,118 @@
+"""Cells -> QuPath GeoJSON (host side), cross-tile de-duplication.
+
+Mirrors /root/reference/src/classpose/entrypoints/predict_wsi.py:
+``to_geojson_polygon`` :813-854, ``apply_bounds_offset_to_feature`` :857-893,
+``deduplicate`` :896-965 (KDTree pairs within 7.5 px, greedy order-dependent grouping over
+the ``set`` of pairs, keep the largest area), ``polygons_to_centroids`` :1336-1374 and the
+colour table ``COLORMAP`` :99 (matplotlib ``Set3`` x 255, truncated to int).
+"""
+from __future__ import annotations
+
+import uuid
+
+import numpy as np
+from scipy.spatial import KDTree
+
+COLORMAP = [[141, 211, 199], [255, 255, 179], [190, 186, 218], [251, 128, 114], [128, 177, 211],
+            [253, 180, 98], [179, 222, 105], [252, 205, 229], [217, 217, 217], [188, 128, 189],
+            [204, 235, 197], [255, 237, 111]]
+
+
+def cell_dict(coords: list, cl: int, labels: list[str] | None, area: float, perimeter: float,
+              centroid: list) -> dict:
+    """One entry of ``curr_cells`` (predict_wsi.py:629-652). ``cl`` is the class-map value;
+    class 0 indexes labels[-1] / COLORMAP[-1] exactly like the reference's ``labels[cl - 1]``."""
+    if labels is not None:
+        label, color, class_int = labels[int(cl) - 1], COLORMAP[int(cl) - 1], int(cl) - 1
+    else:
+        label, color, class_int = "cell", [0, 168, 132], 0
+    coords = [list(map(float, p)) for p in coords]
+    coords.append(coords[0].copy())
+    return {"id": str(uuid.uuid4()), "coords": coords, "class_int": class_int, "area": float(area),
+            "label": label, "color": color, "perimeter": float(perimeter), "centroid": centroid}
+
+
+def to_geojson_polygon(curr_cell: dict) -> dict:
+    return {
+        "type": "Feature",
+        "id": curr_cell["id"],
+        "geometry": {"type": "Polygon", "coordinates": [curr_cell["coords"]]},
+        "properties": {
+            "objectType": "annotation",
+            "isLocked": False,
+            "classification": {"name": curr_cell["label"], "color": curr_cell["color"]},
+            "measurements": [
+                {"name": "area", "value": curr_cell["area"]},
+                {"name": "perimeter", "value": curr_cell["perimeter"]},
+                {"name": "centroidX", "value": curr_cell["centroid"][0]},
+                {"name": "centroidY", "value": curr_cell["centroid"][1]},
+            ],
+        },
+    }
+
+
+def apply_bounds_offset_to_feature(feature: dict, bounds_x: float, bounds_y: float) -> dict:
+    if not feature or "geometry" not in feature or "coordinates" not in feature["geometry"]:
+        return feature
+    g = feature["geometry"]
+    g["coordinates"] = [[[p[0] - bounds_x, p[1] - bounds_y] for p in ring] for ring in g["coordinates"]]
+    for m in feature.get("properties", {}).get("measurements", []):
+        if m["name"] == "centroidX":
+            m["value"] -= bounds_x
+        elif m["name"] == "centroidY":
+            m["value"] -= bounds_y
+    return feature
+
+
+def _measure(feature: dict, name: str):
+    return [x for x in feature["properties"]["measurements"] if x["name"] == name][0]["value"]
+
+
+def dedup_indices(centers, sizes, max_dist: float = 15 / 2) -> list[int]:
+    """Indices kept by the reference's greedy grouping (identical control flow)."""
+    if len(centers) == 0:
+        return []
+    neighbours = KDTree(centers).query_pairs(max_dist)
+    groups: dict[int, list] = {}
+    member_to_group: dict[int, int] = {}
+    for pair in neighbours:
+        if pair[0] not in member_to_group and pair[1] not in member_to_group:
+            gi = len(groups)
+            groups[gi] = []
+            member_to_group[pair[0]] = gi
+            member_to_group[pair[1]] = gi
+        else:
+            gi = member_to_group[pair[0]] if pair[0] in member_to_group else member_to_group[pair[1]]
+        if pair[0] not in groups[gi]:
+            groups[gi].append(pair[0])
+        if pair[1] not in groups[gi]:
+            groups[gi].append(pair[1])
+    to_remove = {}
+    for group in groups.values():
+        if len(group) > 1:
+            largest = group[int(np.argmax([sizes[i] for i in group]))]
+            for i in group:
+                if i != largest and i not in to_remove:
+                    to_remove[i] = True
+    return [i for i in range(len(centers)) if i not in to_remove]
+
+
+def deduplicate(features: list[dict], max_dist: float = 15 / 2) -> list[dict]:
+    centers = [[_measure(f, "centroidX"), _measure(f, "centroidY")] for f in features]
+    sizes = [_measure(f, "area") for f in features]
+    return [features[i] for i in dedup_indices(centers, sizes, max_dist)]
+
+
+def polygons_to_centroids(cells: list[dict]) -> list[dict]:
+    out = []
+    for cell in cells:
+        out.append({
+            "type": "Feature",
+            "id": str(uuid.uuid4()),
+            "geometry": {"type": "Point",
+                         "coordinates": [_measure(cell, "centroidX"), _measure(cell, "centroidY")]},
+            "properties": {"objectType": "annotation", "isLocked": False,
+                           "classification": cell["properties"]["classification"],
+                           "measurements": cell["properties"]["measurements"]},
+        })
+    return out

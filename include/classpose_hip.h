@@ -208,6 +208,24 @@ int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *class_masks, 
                          int W, int max_records_per_tile, cpx_record *records,
                          int32_t *counts, void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------
+ * a17  polygonisation (HOST function: all pointers are host pointers)
+ * replaces, per instance, cv2.findContours(cell_mask, RETR_EXTERNAL,
+ * CHAIN_APPROX_SIMPLE)[0] + shapely.Polygon(...).is_valid/.centroid/.area/.length
+ * of PostProcessor.__call__, /root/reference/src/classpose/entrypoints/predict_wsi.py:601-652.
+ * ---------------------------------------------------------------------- */
+typedef struct cpx_cell {
+    double area, perimeter, cx, cy;  /* in level-0 slide pixels (after scale + offset)   */
+    int32_t n_pts, offset;           /* vertices xy_pool[offset .. offset+n_pts) (ring not closed) */
+    int32_t valid;                   /* >= 4 vertices and a simple (OGC-valid) ring       */
+    int32_t cls;
+} cpx_cell;
+/* masks_host [H][W] uint16 of ONE tile; recs_host[n] its records; vertex i of a cell is
+ * (x_px * scale + off_x, y_px * scale + off_y).  Returns #vertices written (>= 0) or < 0. */
+int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, const cpx_record *recs_host, int n,
+                        double scale, double off_x, double off_y, double *xy_pool, int max_pts,
+                        cpx_cell *cells);
+
 #ifdef __cplusplus
 }
 #endif

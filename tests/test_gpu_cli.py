@@ -1,0 +1,68 @@
+"""GPU: the classpose-predict-wsi drop-in end to end on a small synthetic slide."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from classpose_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_predict_wsi_cli_flow_injection(cuda, tmp_path, monkeypatch):
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs = 1180, 956
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "conic", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.5&seed=77",
+        "--output_folder", str(tmp_path), "--tile_size", "256", "--overlap", "32", "--device", "cuda:0"])
+    predict_wsi.main(args)
+    files = sorted(p.name for p in tmp_path.glob("*.geojson"))
+    assert len(files) == 2
+    cont = json.load(open(tmp_path / [f for f in files if "contours" in f][0]))
+    cent = json.load(open(tmp_path / [f for f in files if "centroids" in f][0]))
+    assert cont["type"] == cent["type"] == "FeatureCollection"          # what the reference's test asserts
+    assert len(cont["features"]) == len(cent["features"]) > 0
+    f0 = cont["features"][0]
+    assert f0["geometry"]["type"] == "Polygon" and f0["geometry"]["coordinates"][0][0] == f0["geometry"]["coordinates"][0][-1]
+    assert [m["name"] for m in f0["properties"]["measurements"]] == ["area", "perimeter", "centroidX", "centroidY"]
+    assert f0["properties"]["classification"]["name"] in ["Neutrophil", "Epithelial", "Lymphocyte", "Plasma cell",
+                                                           "Eosinophil", "Connective"]
+    # covered region: tiles at stride 224 that fit -> x < 5*224+... ; every nucleus fully inside
+    # the covered area must be found exactly once (stitching + de-duplication), near its centre
+    nx, ny = (W - 256) // 224 + 1, (Hs - 256) // 224 + 1
+    cov_w, cov_h = (nx - 1) * 224 + 256, (ny - 1) * 224 + 256
+    cx, cy, r, ident = synth.nuclei_in_region(77, 0, 0, cov_w, cov_h)
+    inner = (cx - r > 12) & (cx + r < cov_w - 12) & (cy - r > 12) & (cy + r < cov_h - 12)
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[inner], cy[inner]], 1))
+    assert np.all(d < 1.5), (d.max(), int((d >= 1.5).sum()))
+    assert len(np.unique(idx)) == inner.sum()                          # one detection per nucleus
+    counts = cKDTree(found).query_ball_point(np.stack([cx[inner], cy[inner]], 1), 7.5, return_length=True)
+    assert np.all(counts == 1)                                         # duplicates from tile overlaps were removed
+    # class label follows the nucleus id hash
+    names = ["Neutrophil", "Epithelial", "Lymphocyte", "Plasma cell", "Eosinophil", "Connective"]
+    exp = [names[int(i % np.uint64(6))] for i in ident[inner]]
+    got = [cont["features"][j]["properties"]["classification"]["name"] for j in idx]
+    assert got == exp
+
+
+def test_classpose_model_eval_api(cuda):
+    from classpose_amd.models import ClassposeModel
+    sd = synth.make_state_dict(7, None, depth=1, seed=2)
+    model = ClassposeModel(gpu=True, pretrained_model=sd, device=cuda, nclasses=7, precision="bf16")
+    tile = synth.render_region(5, 0, 0, 256, 256)
+    masks, flows, class_masks, styles = model.eval([tile, tile], batch_size=8, augment=False, bsize=256,
+                                                   compute_masks=True)
+    assert len(masks) == 2 and masks[0].dtype == np.uint16 and masks[0].shape == (256, 256)
+    assert class_masks[0].dtype == np.int64 and class_masks[0].shape == (256, 256)
+    assert flows[0][1].shape == (2, 256, 256) and flows[0][2].shape == (256, 256) and flows[0][3].shape == (7, 256, 256)
+    assert np.array_equal(masks[0], masks[1])                           # deterministic
+    m1, f1, c1, s1 = model.eval(tile)
+    assert np.array_equal(m1, masks[0]) and np.array_equal(c1, class_masks[0])
