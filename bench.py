@@ -50,12 +50,14 @@ def render_batches(coords, idxs, n_batches, bt, seed=1234):
     return tiles, fields
 
 
-def cpu_baseline(sd, coords, budget_s=15.0, max_tiles=8):
+def cpu_baseline(sd, coords, budget_s=12.0, max_tiles=4):
     """Reference-shaped CPU path (the oracle, kind 'port'), one tile per eval like
     predict_wsi.worker: normalize -> run_net (4 sub-tiles, torch-CPU fp32) -> compute_masks on
     the same injected fields -> class vote -> records.  Bounded sample."""
     from oracle import classmask, dynamics, net, tiling
-    cores = os.cpu_count() or 1
+    # torch-CPU scales to ~16-32 threads on this ViT-L and collapses beyond (measured on the
+    # 256-core GPU-box host: 5.1 s/tile at 32 threads, 151 s/tile at 256: tools/cpu_threads.py)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     fw = net.make_forward(sd, torch.float32)
     fw(np.zeros((1, 3, 256, 256), np.float32))                       # warm-up (thread pool, caches)

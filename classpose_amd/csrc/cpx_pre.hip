@@ -137,6 +137,12 @@ __device__ __forceinline__ float padded_px(const uint8_t *tiles, const float *st
 }
 
 // one thread = one (sub-tile, token, c, ii) = 8 consecutive k (jj = 0..7)
+extern "C" int cpx_get_half_dtype(void);
+__device__ __forceinline__ unsigned short f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    return *reinterpret_cast<unsigned short *>(&h);
+}
+template <bool F16>
 __global__ void k_make_patches(const uint8_t *__restrict__ tiles, const float *__restrict__ stats,
                                TilingDev g, unsigned short *__restrict__ patches) {
     const int tok_per = (g.b / 8) * (g.b / 8);
@@ -160,7 +166,7 @@ __global__ void k_make_patches(const uint8_t *__restrict__ tiles, const float *_
         int x = 8 * pw + jj;
         int sx = fx ? g.b - 1 - x : x;
         float v = padded_px(tiles, stats, g, t, g.ys[j] + sy, g.xs[ii_t] + sx, c);
-        o.h[jj] = f32_to_bf16(v);
+        o.h[jj] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
     }
     *reinterpret_cast<uint4 *>(patches + ((size_t)sub * tok_per + tok) * 192 + c * 64 + ii * 8) = o.v;
 }
@@ -187,8 +193,12 @@ extern "C" int cpx_make_subtiles(const uint8_t *tiles, const float *stats, int n
     TilingDev g; int rc = tiling_to_dev(tiling, &g); if (rc) return rc;
     CPX_REQUIRE(tiles && stats && patches && nT > 0);
     int per_sub = (g.b / 8) * (g.b / 8) * 24;
-    hipLaunchKernelGGL(k_make_patches, dim3(cpx_cdiv(per_sub, NTHR), nT * g.ny * g.nx), dim3(NTHR), 0,
-                       (hipStream_t)stream, tiles, stats, g, (unsigned short *)patches);
+    if (cpx_get_half_dtype())
+        hipLaunchKernelGGL(k_make_patches<true>, dim3(cpx_cdiv(per_sub, NTHR), nT * g.ny * g.nx), dim3(NTHR), 0,
+                           (hipStream_t)stream, tiles, stats, g, (unsigned short *)patches);
+    else
+        hipLaunchKernelGGL(k_make_patches<false>, dim3(cpx_cdiv(per_sub, NTHR), nT * g.ny * g.nx), dim3(NTHR), 0,
+                           (hipStream_t)stream, tiles, stats, g, (unsigned short *)patches);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }

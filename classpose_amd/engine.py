@@ -241,6 +241,7 @@ class Engine:
 
     def preprocess(self, tiles_u8: torch.Tensor, n: int):
         s = self._stream()
+        self.L.cpx_set_half_dtype(self.w.c.dtype)        # patch rows are written in the net's half dtype
         lo_p, lo_g, hi_p, hi_g = self.pct
         check(self.L.cpx_normalize_stats_u8(ptr(tiles_u8), n, self.H, self.W, lo_p, lo_g, hi_p, hi_g,
                                             ptr(self.stats), ptr(self.hist), s), "normalize_stats")

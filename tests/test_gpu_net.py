@@ -216,3 +216,25 @@ def test_engine_end_to_end(cuda):
         assert np.array_equal(r["area"], exp["area"]) and np.array_equal(r["cls"], exp["cls"])
         assert np.array_equal(np.stack([r["y0"], r["x0"], r["y1"], r["x1"]], 1), exp["bbox"])
         assert np.array_equal(r["sum_y"], exp["sum_y"]) and np.array_equal(r["sum_x"], exp["sum_x"])
+
+
+@pytest.mark.parametrize("H,aug,precision", [(256, True, "bf16"), (512, False, "bf16"), (256, False, "fp16"),
+                                             (320, True, "bf16")])
+def test_engine_variants_tta_512_fp16(cuda, H, aug, precision):
+    """configs 4/5 building blocks: --tta (flipped 3x3 / 5x5 sub-tile grids), 512-px tiles (9
+    sub-tiles), fp16; network outputs vs the fp32 oracle, ids bit-exact on the device tensors."""
+    from oracle import classmask, dynamics
+    sd = synth.make_state_dict(7, None, depth=1, seed=9)
+    w = engine.NetWeights.from_state_dict(sd, precision, cuda)
+    eng = engine.Engine(w, H, batch_tiles=1, augment=aug)
+    tile = synth.render_region(4321, 100, 50, H, H)[None]
+    out = eng.run(torch.from_numpy(tile).to(cuda))
+    fw = onet.make_forward(sd)
+    dP, cp, yc = tiling.run_net(fw, tiling.normalize_img(tile), batch_size=8, augment=aug)
+    tol = 2e-2 if precision == "bf16" else 5e-3
+    assert _rel(out.dP[0].cpu(), torch.from_numpy(dP)) < tol
+    assert _rel(out.cellprob[0].cpu(), torch.from_numpy(cp)) < tol
+    assert _rel(out.logits[0].cpu(), torch.from_numpy(yc)) < tol
+    ref = dynamics.compute_masks(out.dP[0].cpu().numpy(), out.cellprob[0].cpu().numpy())
+    assert np.array_equal(ops.masks_to_numpy(out.masks)[0], ref)
+    _lib.lib().cpx_set_half_dtype(0)
