@@ -112,30 +112,40 @@ def main():
     tiles = [torch.from_numpy(t).to(dev) for t in tiles_h]
     fields = [tuple(torch.from_numpy(a).to(dev) for a in f) for f in fields_h]
     rec_bytes = C.sizeof(_lib.CpxRecord)
-    pinned = torch.empty(eng.records.numel(), dtype=torch.uint8).pin_memory()
+    pinned = torch.empty(eng.slots[0].records.numel(), dtype=torch.uint8).pin_memory()
     pinned_cnt = torch.empty(bt, dtype=torch.int32).pin_memory()
     cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
     rec_keep = []
 
-    def step(i, keep=False):
-        p = i % args.pool
-        out = eng.run(tiles[p], inject=fields[p], records=True)
-        pinned.copy_(eng.records, non_blocking=True)                   # records leave the device
-        pinned_cnt.copy_(eng.rec_counts, non_blocking=True)
+    def collect(sid, keep=False):
+        out = eng.result(sid)                                          # current stream waits for the post stream
+        pinned.copy_(out.records, non_blocking=True)                   # records leave the device
+        pinned_cnt.copy_(out.rec_counts, non_blocking=True)
         cells_acc.add_(out.nlabels.sum())
         if keep:
-            rec_keep.append(eng.records.view(bt, eng.max_rec, rec_bytes)[:, :256].clone())
+            rec_keep.append(out.records.view(bt, eng.max_rec, rec_bytes)[:, :256].clone())
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(n, keep_last=False):
+        """n steps through the 2-stream pipeline: network of step i+1 overlaps post-processing of i."""
+        prev = None
+        if n <= 0:
+            return
+        for i in range(n):
+            p = i % args.pool
+            sid = eng.submit(tiles[p], inject=fields[p], records=True)
+            if prev is not None:
+                collect(prev)
+            prev = sid
+        collect(prev, keep=keep_last)
+
+    run_steps(args.warmup)
     torch.cuda.synchronize(dev)
     cells_acc.zero_()
     _lib.check(L.cpx_prof_enable(args.steps * args.depth + 8), "prof_enable")
     parallel.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, keep=(i == args.steps - 1))
+    run_steps(args.steps, keep_last=True)
     # the path's one exchange: per-cell records of this rank's shard -> every rank (RCCL)
     rec = rec_keep[-1].reshape(-1, rec_bytes)
     allrec = parallel.all_gather_records(rec)

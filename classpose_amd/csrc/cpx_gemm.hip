@@ -207,6 +207,14 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
             }
             if constexpr (EPI == CPX_EPI_F32) {
                 *reinterpret_cast<float4 *>((float *)g.out + (size_t)m * g.ld_out + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (EPI == CPX_EPI_QKV_BF16 && n >= 2048) {
+                unsigned short *vT = (unsigned short *)g.aux;
+                const size_t s_ = (size_t)(m >> 10), t_ = (size_t)(m & 1023);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = n - 2048 + r;
+                    vT[((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t_] = to_half<F16>(v[r]);
+                }
             } else {
                 uint2 o;
                 o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
@@ -383,6 +391,15 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: bias/activation in f32 -> half tile in LDS -> whole rows to HBM
+    const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;     // V third of the qkv projection
+    const int c16 = tid & 31;                   // 16-byte chunk within a 512-byte row (store phase)
+    uint4 rres[16];
+    if constexpr (EPI == CPX_EPI_RESID_BF16) {  // residual rows: issue the loads now, consume after the LDS pass
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            rres[it] = *reinterpret_cast<const uint4 *>((const unsigned short *)g.aux +
+                                                        (size_t)(m0 + it * 16 + (tid >> 5)) * g.ld_out + n0 + c16 * 8);
+    }
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -405,21 +422,37 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    uint2 o;
-                    o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
-                    o.y = (unsigned)to_half<F16>(v[2]) | ((unsigned)to_half<F16>(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(smem + ml * G2_EPI_LD + nl * 2) = o;
+                    if (vt_tile) {              // transposed image [channel][token] for the V^T layout
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            *reinterpret_cast<unsigned short *>(smem + (nl + r) * G2_EPI_LD + ml * 2) = to_half<F16>(v[r]);
+                    } else {
+                        uint2 o;
+                        o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
+                        o.y = (unsigned)to_half<F16>(v[2]) | ((unsigned)to_half<F16>(v[3]) << 16);
+                        *reinterpret_cast<uint2 *>(smem + ml * G2_EPI_LD + nl * 2) = o;
+                    }
                 }
     __syncthreads();
-    {
-        const int c16 = tid & 31;               // 16-byte chunk within the 512-byte row
+    if (vt_tile) {
+        // LDS row = channel c (head = c/64, d = c%64), 256 tokens contiguous -> vT[s][head][d][t0..t0+255]
+        unsigned short *vT = (unsigned short *)g.aux;
+        const size_t s_ = (size_t)(m0 >> 10), t0 = (size_t)(m0 & 1023);
 #pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 16 + (tid >> 5);
+            const int c = n0 - 2048 + row;
+            uint4 v = *reinterpret_cast<const uint4 *>(smem + row * G2_EPI_LD + c16 * 16);
+            *reinterpret_cast<uint4 *>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8) = v;
+        }
+    } else {
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int ml = it * 16 + (tid >> 5);
             uint4 v = *reinterpret_cast<const uint4 *>(smem + ml * G2_EPI_LD + c16 * 16);
             const size_t go = (size_t)(m0 + ml) * g.ld_out + n0 + c16 * 8;
             if constexpr (EPI == CPX_EPI_RESID_BF16) {
-                const uint4 rr = *reinterpret_cast<const uint4 *>((const unsigned short *)g.aux + go);
+                const uint4 rr = rres[it];
                 unsigned a[4] = {v.x, v.y, v.z, v.w}, b[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -480,7 +513,8 @@ extern "C" int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K,
     CPX_REQUIRE(A && Wt && out);
     CPX_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0);
     CPX_REQUIRE(ld_out >= N && ld_out % 4 == 0);
-    CPX_REQUIRE((epilogue != CPX_EPI_RESID_BF16 && epilogue != CPX_EPI_POS_BF16) || aux);
+    CPX_REQUIRE((epilogue != CPX_EPI_RESID_BF16 && epilogue != CPX_EPI_POS_BF16 && epilogue != CPX_EPI_QKV_BF16) || aux);
+    CPX_REQUIRE(epilogue != CPX_EPI_QKV_BF16 || (N == 3072 && M % 1024 == 0));
     GemmArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;
@@ -493,6 +527,7 @@ extern "C" int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K,
         case CPX_EPI_F32: launch_gemm<CPX_EPI_F32>(a, s); break;
         case CPX_EPI_POS_BF16: launch_gemm<CPX_EPI_POS_BF16>(a, s); break;
         case CPX_EPI_RELU_BF16: launch_gemm<CPX_EPI_RELU_BF16>(a, s); break;
+        case CPX_EPI_QKV_BF16: launch_gemm<CPX_EPI_QKV_BF16>(a, s); break;
         default: CPX_REQUIRE(!"unknown epilogue");
     }
     CPX_CHECK_LAUNCH();

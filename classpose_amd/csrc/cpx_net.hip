@@ -328,12 +328,20 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
         }
 }
 
+static int attention_launch(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                            void *vT_ws, void *out, void *stream, bool transpose_v);
 extern "C" int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w,
                                     int n_subtiles, void *vT_ws, void *out, void *stream) {
+    return attention_launch(qkv, rel_h, rel_w, n_subtiles, vT_ws, out, stream, true);
+}
+// transpose_v = false: vT_ws already holds V^T (written by the qkv GEMM's CPX_EPI_QKV_BF16 epilogue)
+static int attention_launch(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                            void *vT_ws, void *out, void *stream, bool transpose_v) {
     CPX_REQUIRE(qkv && rel_h && rel_w && vT_ws && out && n_subtiles > 0);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
-                       (const unsigned short *)qkv, (unsigned short *)vT_ws);
+    if (transpose_v)
+        hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
+                           (const unsigned short *)qkv, (unsigned short *)vT_ws);
     dim3 grid(8, 16, n_subtiles);
     if (cpx_get_half_dtype())
         hipLaunchKernelGGL(k_attention<true>, grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
@@ -442,8 +450,8 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
     for (int i = 0; i < w->depth; ++i) {
         const cpx_block_weights &b = w->blocks[i];
         RUN(cpx_layernorm_bf16(x, b.ln1_w, b.ln1_b, M, 1024, 1e-6f, xn, stream));
-        RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, CPX_EPI_BF16, b.qkv_b, nullptr, qkv, 3072, stream));
-        RUN(cpx_attention_relpos(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream));
+        RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, CPX_EPI_QKV_BF16, b.qkv_b, vt, qkv, 3072, stream));
+        RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
         RUN(cpx_gemm_bf16(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, stream));
         RUN(cpx_layernorm_bf16(x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
         const bool prof = g_prof_ev && g_prof_n < g_prof_cap;

@@ -192,10 +192,46 @@ class TileOutputs:
     dP: torch.Tensor             # f32 [nT, 2, H, W]
     cellprob: torch.Tensor       # f32 [nT, H, W]
     logits: torch.Tensor | None  # f32 [nT, ncls, H, W]
+    records: torch.Tensor | None = None      # uint8 view of cpx_record[nT][max_rec]
+    rec_counts: torch.Tensor | None = None   # int32 [nT]
+
+
+class _Slot:
+    """One in-flight batch: every buffer a batch touches after the shared network workspace."""
+
+    def __init__(self, eng: "Engine"):
+        nT, H, W, ncls, d = eng.nT, eng.H, eng.W, eng.w.ncls, eng.dev
+        nS = nT * eng.n_sub
+        self.stats = torch.empty(nT * 3 * 4, dtype=torch.float32, device=d)
+        self.hist = torch.empty(nT * 768, dtype=torch.int32, device=d)
+        self.patches = torch.empty(nS * 1024 * 192, dtype=torch.int16, device=d)
+        self.head = torch.empty(nS * 1024 * eng.w.c.ld_head, dtype=torch.float32, device=d)
+        self.dP = torch.empty((nT, 2, H, W), dtype=torch.float32, device=d)
+        self.cellprob = torch.empty((nT, H, W), dtype=torch.float32, device=d)
+        self.logits = torch.empty((nT, max(ncls, 1), H, W), dtype=torch.float32, device=d)
+        self.pp_ws = torch.empty(eng.pp_ws_bytes, dtype=torch.uint8, device=d)
+        self.masks = torch.empty((nT, H, W), dtype=torch.int16, device=d)
+        self.class_masks = torch.empty((nT, H, W), dtype=torch.uint8, device=d)
+        self.nlabels = torch.empty(nT, dtype=torch.int32, device=d)
+        self.records = torch.empty(nT * eng.max_rec * C.sizeof(CpxRecord), dtype=torch.uint8, device=d)
+        self.rec_counts = torch.empty(nT, dtype=torch.int32, device=d)
+        self.ev_net = torch.cuda.Event()
+        self.ev_post = torch.cuda.Event()
+        self.n = 0
+        self.inject = None
+        self.busy = False
 
 
 class Engine:
-    """Persistent device buffers + launch sequence for batches of nT WSI tiles."""
+    """Persistent device buffers + launch sequence for batches of nT WSI tiles.
+
+    Two HIP streams: the NETWORK stream runs normalise -> sub-tile -> ClassTransformer of batch
+    i+1 while the POST stream runs blend -> dynamics -> class vote -> records of batch i (the
+    post-processing kernels are small and latency-bound: they slot into the gaps of the MFMA
+    kernels).  ``submit`` / ``result`` expose the pipeline; ``run`` = submit + result.
+    """
+
+    N_SLOTS = 2
 
     def __init__(self, weights: NetWeights, tile_h: int = 256, tile_w: int | None = None,
                  batch_tiles: int = 8, augment: bool = False, tile_overlap: float = 0.1,
@@ -210,96 +246,99 @@ class Engine:
         self.n_sub = self.tiling.ny * self.tiling.nx
         self.niter, self.cp_thr, self.flow_thr = niter, cellprob_threshold, flow_threshold
         self.min_size, self.max_frac = min_size, max_size_fraction
-        nT, H, W, ncls = self.nT, self.H, self.W, weights.ncls
-        nS = nT * self.n_sub
+        nT, H, W = self.nT, self.H, self.W
         d = self.dev
         lo = percentile_params(H * W, 1)
         hi = percentile_params(H * W, 99)
         self.pct = (lo[0], lo[1], hi[0], hi[1])
-        self.stats = torch.empty(nT * 3 * 4, dtype=torch.float32, device=d)
-        self.hist = torch.empty(nT * 768, dtype=torch.int32, device=d)
-        self.patches = torch.empty(nS * 1024 * 192, dtype=torch.int16, device=d)
-        self.head = torch.empty(nS * 1024 * weights.c.ld_head, dtype=torch.float32, device=d)
-        self.net_ws_bytes = self.L.cpx_net_workspace_bytes(nS)
+        self.net_ws_bytes = self.L.cpx_net_workspace_bytes(nT * self.n_sub)
         self.net_ws = torch.empty(self.net_ws_bytes, dtype=torch.uint8, device=d)
         self.taper = torch.from_numpy(taper_1d(BSIZE)).to(d)
-        self.dP = torch.empty((nT, 2, H, W), dtype=torch.float32, device=d)
-        self.cellprob = torch.empty((nT, H, W), dtype=torch.float32, device=d)
-        self.logits = torch.empty((nT, max(ncls, 1), H, W), dtype=torch.float32, device=d)
         self.pp_ws_bytes = self.L.cpx_postproc_workspace_bytes(nT, H, W)
-        self.pp_ws = torch.empty(self.pp_ws_bytes, dtype=torch.uint8, device=d)
-        self.masks = torch.empty((nT, H, W), dtype=torch.int16, device=d)
-        self.class_masks = torch.empty((nT, H, W), dtype=torch.uint8, device=d)
-        self.nlabels = torch.empty(nT, dtype=torch.int32, device=d)
         self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 8192)
-        self.records = torch.empty(nT * self.max_rec * C.sizeof(CpxRecord), dtype=torch.uint8, device=d)
-        self.rec_counts = torch.empty(nT, dtype=torch.int32, device=d)
+        self.slots = [_Slot(self) for _ in range(self.N_SLOTS)]
+        self.s_net = torch.cuda.Stream(d)
+        self.s_post = torch.cuda.Stream(d)
+        self._next = 0
+        self._last: _Slot | None = None
 
-    # -- stages ---------------------------------------------------------
-    def _stream(self):
-        return torch.cuda.current_stream(self.dev).cuda_stream
-
-    def preprocess(self, tiles_u8: torch.Tensor, n: int):
-        s = self._stream()
-        self.L.cpx_set_half_dtype(self.w.c.dtype)        # patch rows are written in the net's half dtype
-        lo_p, lo_g, hi_p, hi_g = self.pct
-        check(self.L.cpx_normalize_stats_u8(ptr(tiles_u8), n, self.H, self.W, lo_p, lo_g, hi_p, hi_g,
-                                            ptr(self.stats), ptr(self.hist), s), "normalize_stats")
-        check(self.L.cpx_make_subtiles(ptr(tiles_u8), ptr(self.stats), n, C.byref(self.tiling),
-                                       ptr(self.patches), s), "make_subtiles")
-
-    def network(self, n: int):
-        check(self.L.cpx_net_forward(C.byref(self.w.c), ptr(self.patches), n * self.n_sub,
-                                     ptr(self.head), ptr(self.net_ws), self.net_ws_bytes,
-                                     self._stream()), "net_forward")
-
-    def blend(self, n: int):
-        ncls = self.w.ncls if self.w.ncls > 1 else 0
-        check(self.L.cpx_blend_subtiles(ptr(self.head), self.w.c.ld_head, ncls, n,
-                                        C.byref(self.tiling), ptr(self.taper), ptr(self.dP),
-                                        ptr(self.cellprob), ptr(self.logits), self._stream()), "blend")
-
-    def dynamics(self, n: int, dP=None, cellprob=None, logits=None):
-        dP = self.dP if dP is None else dP
-        cellprob = self.cellprob if cellprob is None else cellprob
-        logits = self.logits if logits is None else logits
-        ncls = self.w.ncls
-        check(self.L.cpx_compute_masks(ptr(dP), ptr(cellprob), ptr(logits) if ncls > 1 else None, n,
-                                       ncls, self.H, self.W, self.cp_thr, self.flow_thr, self.niter,
-                                       self.min_size, self.max_frac, ptr(self.masks),
-                                       ptr(self.class_masks), ptr(self.nlabels), ptr(self.pp_ws),
-                                       self._stream()), "compute_masks")
-
-    def make_records(self, n: int):
-        check(self.L.cpx_instance_records(ptr(self.masks), ptr(self.class_masks), n, self.H, self.W,
-                                          self.max_rec, ptr(self.records), ptr(self.rec_counts),
-                                          ptr(self.pp_ws), self._stream()), "instance_records")
-
-    # -- whole path -----------------------------------------------------
-    def run(self, tiles_u8: torch.Tensor, inject=None, records: bool = True) -> TileOutputs:
-        """tiles_u8: uint8 [n, H, W, 3] already resident on the device, n <= batch_tiles.
-
-        ``inject`` = (dP, cellprob, logits) device tensors: flow-injection mode (the
-        network still runs; the dynamics consume the injected fields instead)."""
+    # -- pipeline -------------------------------------------------------
+    def submit(self, tiles_u8: torch.Tensor, inject=None, records: bool = True) -> int:
+        """Enqueue one batch (uint8 [n, H, W, 3] resident on the device, n <= batch_tiles) and
+        return its slot id.  ``inject`` = (dP, cellprob, logits) device tensors: flow-injection
+        mode (the network still runs; the dynamics consume the injected fields instead)."""
         n = tiles_u8.shape[0]
         assert n <= self.nT and tiles_u8.dtype == torch.uint8 and tiles_u8.is_contiguous()
         assert tiles_u8.shape[1:] == (self.H, self.W, 3) and tiles_u8.device == self.dev
-        self.preprocess(tiles_u8, n)
-        self.network(n)
-        self.blend(n)
+        sid = self._next
+        self._next = (self._next + 1) % self.N_SLOTS
+        sl = self.slots[sid]
+        if sl.busy:
+            raise RuntimeError("Engine: slot still holds an uncollected batch; call result() first")
+        sl.n, sl.inject, sl.busy = n, inject, True
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_net.wait_stream(cur)                     # inputs were produced on the caller's stream
+        self.s_net.wait_event(sl.ev_post)               # this slot's previous batch left the head buffer
+        lo_p, lo_g, hi_p, hi_g = self.pct
+        sn, sp = self.s_net.cuda_stream, self.s_post.cuda_stream
+        self.L.cpx_set_half_dtype(self.w.c.dtype)
+        check(self.L.cpx_normalize_stats_u8(ptr(tiles_u8), n, self.H, self.W, lo_p, lo_g, hi_p, hi_g,
+                                            ptr(sl.stats), ptr(sl.hist), sn), "normalize_stats")
+        check(self.L.cpx_make_subtiles(ptr(tiles_u8), ptr(sl.stats), n, C.byref(self.tiling),
+                                       ptr(sl.patches), sn), "make_subtiles")
+        check(self.L.cpx_net_forward(C.byref(self.w.c), ptr(sl.patches), n * self.n_sub, ptr(sl.head),
+                                     ptr(self.net_ws), self.net_ws_bytes, sn), "net_forward")
+        sl.ev_net.record(self.s_net)
+        tiles_u8.record_stream(self.s_net)
+        # post stream
+        self.s_post.wait_event(sl.ev_net)
         if inject is not None:
-            self.dynamics(n, *inject)
-        else:
-            self.dynamics(n)
+            self.s_post.wait_stream(cur)
+        ncls = self.w.ncls
+        check(self.L.cpx_blend_subtiles(ptr(sl.head), self.w.c.ld_head, ncls if ncls > 1 else 0, n,
+                                        C.byref(self.tiling), ptr(self.taper), ptr(sl.dP),
+                                        ptr(sl.cellprob), ptr(sl.logits), sp), "blend")
+        dP, cp, lg = (sl.dP, sl.cellprob, sl.logits) if inject is None else inject
+        check(self.L.cpx_compute_masks(ptr(dP), ptr(cp), ptr(lg) if ncls > 1 else None, n, ncls,
+                                       self.H, self.W, self.cp_thr, self.flow_thr, self.niter,
+                                       self.min_size, self.max_frac, ptr(sl.masks), ptr(sl.class_masks),
+                                       ptr(sl.nlabels), ptr(sl.pp_ws), sp), "compute_masks")
         if records:
-            self.make_records(n)
-        return TileOutputs(self.masks[:n], self.class_masks[:n], self.nlabels[:n], self.dP[:n],
-                           self.cellprob[:n], self.logits[:n] if self.w.ncls > 1 else None)
+            check(self.L.cpx_instance_records(ptr(sl.masks), ptr(sl.class_masks), n, self.H, self.W,
+                                              self.max_rec, ptr(sl.records), ptr(sl.rec_counts),
+                                              ptr(sl.pp_ws), sp), "instance_records")
+        sl.ev_post.record(self.s_post)
+        return sid
 
-    def fetch_records(self, n: int) -> np.ndarray:
-        """Compact per-cell records of the last run() as a structured numpy array (D2H)."""
-        counts = self.rec_counts[:n].cpu().numpy()
-        raw = self.records.cpu().numpy().view(RECORD_DTYPE).reshape(self.nT, self.max_rec)
+    def result(self, sid: int, wait: bool = True) -> "TileOutputs":
+        """Outputs of a submitted batch; the caller's current stream is made to wait for them."""
+        sl = self.slots[sid]
+        if wait:
+            torch.cuda.current_stream(self.dev).wait_event(sl.ev_post)
+        sl.busy = False
+        self._last = sl
+        n = sl.n
+        return TileOutputs(sl.masks[:n], sl.class_masks[:n], sl.nlabels[:n], sl.dP[:n], sl.cellprob[:n],
+                           sl.logits[:n] if self.w.ncls > 1 else None, sl.records, sl.rec_counts)
+
+    def run(self, tiles_u8: torch.Tensor, inject=None, records: bool = True) -> "TileOutputs":
+        return self.result(self.submit(tiles_u8, inject, records))
+
+    # kept for the bench / CLI: records of the most recently collected batch
+    @property
+    def records(self):
+        return self._last.records
+
+    @property
+    def rec_counts(self):
+        return self._last.rec_counts
+
+    def fetch_records(self, n: int, out: "TileOutputs | None" = None) -> np.ndarray:
+        """Compact per-cell records of a collected batch as a structured numpy array (D2H)."""
+        recs = self._last.records if out is None else out.records
+        cnts = self._last.rec_counts if out is None else out.rec_counts
+        counts = cnts[:n].cpu().numpy()
+        raw = recs.cpu().numpy().view(RECORD_DTYPE).reshape(self.nT, self.max_rec)
         return np.concatenate([raw[t, :min(int(counts[t]), self.max_rec)] for t in range(n)]) \
             if n else raw[:0, 0]
 

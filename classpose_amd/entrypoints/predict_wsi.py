@@ -161,7 +161,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
             inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
         out = eng.run(tiles_dev, inject=inject, records=True)
         masks = out.masks.cpu().numpy().view(np.uint16)          # D2H: 2 B / pixel
-        recs = eng.fetch_records(n)
+        recs = eng.fetch_records(n, out)
         if int(out.nlabels.max()) >= 65535:
             raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
         for k, ti in enumerate(chunk):

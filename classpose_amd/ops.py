@@ -210,7 +210,7 @@ def masks_to_numpy(masks_i16: torch.Tensor) -> np.ndarray:
 
 
 # ---- network building blocks --------------------------------------------------
-EPI = dict(bf16=0, gelu=1, resid=2, f32=3, pos=4, relu=5)
+EPI = dict(bf16=0, gelu=1, resid=2, f32=3, pos=4, relu=5, qkv=6)
 
 
 def gemm(A: torch.Tensor, Wt: torch.Tensor, epilogue: str = "bf16", bias=None, aux=None):

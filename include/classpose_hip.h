@@ -143,6 +143,8 @@ int cpx_net_forward(const cpx_net_weights *w_host, const void *patches_bf16, int
 #define CPX_EPI_F32 3             /* out f32  = acc (+bias)                    */
 #define CPX_EPI_POS_BF16 4        /* out bf16 = acc + bias + pos[row%1024]     */
 #define CPX_EPI_RELU_BF16 5
+#define CPX_EPI_QKV_BF16 6        /* out bf16 [M][3072] = acc + bias; the V third (cols >= 2048) is
+                                     ALSO/INSTEAD written transposed to aux = vT [M/1024][16][64][1024] */
 int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
                   const float *bias, const void *resid_or_pos, void *out, int ld_out,
                   void *stream);

@@ -238,3 +238,22 @@ def test_engine_variants_tta_512_fp16(cuda, H, aug, precision):
     ref = dynamics.compute_masks(out.dP[0].cpu().numpy(), out.cellprob[0].cpu().numpy())
     assert np.array_equal(ops.masks_to_numpy(out.masks)[0], ref)
     _lib.lib().cpx_set_half_dtype(0)
+
+
+@pytest.mark.parametrize("nS", [2, 32])
+def test_gemm_qkv_epilogue_writes_v_transposed(cuda, nS):
+    """qkv projection epilogue: q|k columns row-major, the V third transposed to [s][head][d][t]
+    (nS = 2 takes the 128^2 kernel, nS = 32 the 256^2 kernel)"""
+    M = nS * 1024
+    g = torch.Generator().manual_seed(nS)
+    A = torch.randn(M, 1024, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(3072, 1024, generator=g) / 32).to(torch.bfloat16).to(cuda)
+    b = torch.randn(3072, generator=g).to(cuda)
+    vT = torch.zeros((nS, 16, 64, 1024), dtype=torch.bfloat16, device=cuda)
+    out = torch.zeros((M, 3072), dtype=torch.bfloat16, device=cuda)
+    _lib.check(_lib.lib().cpx_gemm_bf16(A.data_ptr(), W.data_ptr(), M, 3072, 1024, ops.EPI["qkv"], b.data_ptr(),
+                                        vT.data_ptr(), out.data_ptr(), 3072, torch.cuda.current_stream().cuda_stream))
+    ref = ops.gemm(A, W, "bf16", b)
+    assert torch.equal(out[:, :2048], ref[:, :2048])
+    exp = ref[:, 2048:].reshape(nS, 1024, 16, 64).permute(0, 2, 3, 1)
+    assert torch.equal(vT, exp)
