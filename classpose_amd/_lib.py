@@ -26,12 +26,12 @@ class CpxTiling(C.Structure):
 class CpxBlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "rel_h", "rel_w",
-        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_colsum", "fc1_colsum")]
 
 
 class CpxNetWeights(C.Structure):
     _fields_ = [("depth", C.c_int), ("ncls", C.c_int), ("n_head_cols", C.c_int),
-                ("ld_head", C.c_int), ("dtype", C.c_int),
+                ("ld_head", C.c_int), ("dtype", C.c_int), ("fuse_ln", C.c_int),
                 ("pe_w", C.c_void_p), ("pe_b", C.c_void_p), ("pos", C.c_void_p),
                 ("blocks", C.POINTER(CpxBlockWeights)),
                 ("neck0_w", C.c_void_p), ("neck_ln1_w", C.c_void_p), ("neck_ln1_b", C.c_void_p),
@@ -65,6 +65,8 @@ SIGNATURES = {
     "cpx_net_workspace_bytes": (_sz, [_i]),
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
     "cpx_gemm_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "cpx_gemm_ln": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "cpx_row_stats": (_i, [_p, _i, _p, _p]),
     "cpx_layernorm_bf16": (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
     "cpx_attention_relpos": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "cpx_postproc_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -39,7 +39,21 @@ struct GemmArgs {
     void *out;
     int ld_out;
     int tiles_n, n_blocks;
+    // LayerNorm folded into the GEMM (consumer side): out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
+    // with W pre-multiplied by gamma, bias = b + W.beta, colsum[n] = sum_k W'[n][k]
+    const float *ln_stats;   // [M][4][2] partial (sum, sum of squares) of the K = 1024 input row, or null
+    const float *ln_colsum;  // [N]
+    // producer side (RESID epilogue of the 256^2 kernel): partial row statistics of the OUTPUT rows
+    float *stats_out;        // [M][4][2], slot = column tile; or null
 };
+#define LN_SLOTS 4
+__device__ __forceinline__ void ln_row_params(const float *st, int m, float inv_k, float &mean, float &rstd) {
+    const float4 a = *reinterpret_cast<const float4 *>(st + (size_t)m * 8);
+    const float4 b = *reinterpret_cast<const float4 *>(st + (size_t)m * 8 + 4);
+    const float sum = (a.x + a.z) + (b.x + b.z), sq = (a.y + a.w) + (b.y + b.w);
+    mean = sum * inv_k;
+    rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-6f);
+}
 
 template <bool F16>
 __device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c) {
@@ -187,6 +201,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
         for (int nb = 0; nb < 4; ++nb) {
             const int n = n0 + wn * 64 + nb * 16 + fq * 4;
             f32x4 v = acc[nb][mb];
+            if (g.ln_stats) {
+                float mean, rstd;
+                ln_row_params(g.ln_stats, m, 1.0f / g.K, mean, rstd);
+                const float4 cs = *reinterpret_cast<const float4 *>(g.ln_colsum + n);
+                v[0] = (v[0] - mean * cs.x) * rstd; v[1] = (v[1] - mean * cs.y) * rstd;
+                v[2] = (v[2] - mean * cs.z) * rstd; v[3] = (v[3] - mean * cs.w) * rstd;
+            }
             if (g.bias) {
                 const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -393,6 +414,14 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     // ---- epilogue: bias/activation in f32 -> half tile in LDS -> whole rows to HBM
     const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;     // V third of the qkv projection
     const int c16 = tid & 31;                   // 16-byte chunk within a 512-byte row (store phase)
+    float ln_mean[2][4], ln_rstd[2][4];         // this lane's 8 token rows (hm, mb)
+    if (g.ln_stats) {
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                ln_row_params(g.ln_stats, m0 + hm * 128 + wm * 64 + mb * 16 + fr, 1.0f / K, ln_mean[hm][mb], ln_rstd[hm][mb]);
+    }
     uint4 rres[16];
     if constexpr (EPI == CPX_EPI_RESID_BF16) {  // residual rows: issue the loads now, consume after the LDS pass
 #pragma unroll
@@ -411,6 +440,12 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                     const int ml = hm * 128 + wm * 64 + mb * 16 + fr;
                     const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
                     f32x4 v = acc[hm][hn][mb][nb];
+                    if (g.ln_stats) {
+                        const float4 cs = *reinterpret_cast<const float4 *>(g.ln_colsum + n0 + nl);
+                        const float mu = ln_mean[hm][mb], rs = ln_rstd[hm][mb];
+                        v[0] = (v[0] - mu * cs.x) * rs; v[1] = (v[1] - mu * cs.y) * rs;
+                        v[2] = (v[2] - mu * cs.z) * rs; v[3] = (v[3] - mu * cs.w) * rs;
+                    }
                     if (g.bias) {
                         const float4 b = *reinterpret_cast<const float4 *>(g.bias + n0 + nl);
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -463,6 +498,21 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                 v = make_uint4(a[0], a[1], a[2], a[3]);
             }
             *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = v;
+            if (g.stats_out) {
+                // partial LayerNorm statistics of the (rounded) output row over this block's 256 columns:
+                // 32 lanes share a row; slot = column tile, written whole -> deterministic, no atomics
+                unsigned a[4] = {v.x, v.y, v.z, v.w};
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = from_half<F16>(a[i] & 0xFFFF), hi = from_half<F16>(a[i] >> 16);
+                    sm += lo + hi; sq += lo * lo + hi * hi;
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+                if (c16 == 0)
+                    *reinterpret_cast<float2 *>(g.stats_out + ((size_t)(m0 + ml) * LN_SLOTS + tile_n) * 2) = make_float2(sm, sq);
+            }
         }
     }
 }
@@ -508,17 +558,56 @@ static void launch_gemm(const GemmArgs &a, hipStream_t s) {
     }
 }
 
-extern "C" int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
-                             const float *bias, const void *aux, void *out, int ld_out, void *stream) {
+// row statistics (sum, sum of squares) of a half-precision [rows][1024] matrix into slot 0 of
+// the [rows][4][2] layout the LN-folded GEMMs read (slots 1..3 zeroed).  One wave per row.
+template <bool F16>
+__global__ void __launch_bounds__(256) k_row_stats(const unsigned short *__restrict__ x, int rows,
+                                                   float *__restrict__ st) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned short *xr = x + (size_t)row * 1024 + lane * 16;
+    const uint4 a = *reinterpret_cast<const uint4 *>(xr), b = *reinterpret_cast<const uint4 *>(xr + 8);
+    const unsigned u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float lo = from_half<F16>(u[i] & 0xFFFF), hi = from_half<F16>(u[i] >> 16);
+        sm += lo + hi; sq += lo * lo + hi * hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+    if (lane < 4) *reinterpret_cast<float2 *>(st + ((size_t)row * LN_SLOTS + lane) * 2) = lane == 0 ? make_float2(sm, sq) : make_float2(0.f, 0.f);
+}
+extern "C" int cpx_row_stats(const void *x, int rows, float *stats, void *stream) {
+    CPX_REQUIRE(x && stats && rows > 0);
+    if (g_gemm_f16) hipLaunchKernelGGL(k_row_stats<true>, dim3(cpx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, rows, stats);
+    else hipLaunchKernelGGL(k_row_stats<false>, dim3(cpx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, rows, stats);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+// does this shape take the 256^2 kernel (whose RESID epilogue can emit LN statistics)?
+extern "C" int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue) {
+    if (epilogue == CPX_EPI_F32 || epilogue == CPX_EPI_POS_BF16) return 0;
+    if (!g_gemm_big || M % 256 || N % 256 || (K / 64) % 2 || K < 128) return 0;
+    return (M / 256) * (N / 256) >= 256;
+}
+
+extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                           const float *bias, const void *aux, void *out, int ld_out,
+                           const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream) {
     CPX_REQUIRE(A && Wt && out);
     CPX_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0);
     CPX_REQUIRE(ld_out >= N && ld_out % 4 == 0);
     CPX_REQUIRE((epilogue != CPX_EPI_RESID_BF16 && epilogue != CPX_EPI_POS_BF16 && epilogue != CPX_EPI_QKV_BF16) || aux);
     CPX_REQUIRE(epilogue != CPX_EPI_QKV_BF16 || (N == 3072 && M % 1024 == 0));
+    CPX_REQUIRE(!ln_stats || ln_colsum);
+    CPX_REQUIRE(!stats_out || (epilogue == CPX_EPI_RESID_BF16 && N == 1024 && cpx_gemm_uses_big_tile(M, N, K, epilogue)));
     GemmArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
+    a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s); break;
@@ -532,4 +621,9 @@ extern "C" int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K,
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;
+}
+
+extern "C" int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                             const float *bias, const void *aux, void *out, int ld_out, void *stream) {
+    return cpx_gemm_ln(A, Wt, M, N, K, epilogue, bias, aux, out, ld_out, nullptr, nullptr, nullptr, stream);
 }

@@ -378,8 +378,9 @@ __global__ void __launch_bounds__(256) k_im2col3(const unsigned short *__restric
 // forward driver
 // ---------------------------------------------------------------------------
 struct NetWs {
-    size_t off_x, off_xn, off_qkv, off_vt, off_ao, off_h, off_neck, off_neck2, off_col, total;
+    size_t off_x, off_xn, off_qkv, off_vt, off_ao, off_h, off_neck, off_neck2, off_col, off_st, total;
 };
+extern "C" int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue);
 static NetWs net_ws(int nS) {
     NetWs w; size_t o = 0; const size_t M = (size_t)nS * 1024;
     auto take = [&](size_t b) { size_t r = o; o = cpx_align_up(o + b, 256); return r; };
@@ -392,6 +393,7 @@ static NetWs net_ws(int nS) {
     w.off_neck = take(M * 256 * 2);
     w.off_neck2 = take(M * 256 * 2);
     w.off_col = take(M * 2304 * 2);
+    w.off_st = take(M * 8 * sizeof(float));
     w.total = o;
     return w;
 }
@@ -400,6 +402,10 @@ extern "C" size_t cpx_net_workspace_bytes(int n_subtiles) {
 }
 
 extern "C" void cpx_set_half_dtype(int f16);
+extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                           const float *bias, const void *aux, void *out, int ld_out,
+                           const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream);
+extern "C" int cpx_row_stats(const void *x, int rows, float *stats, void *stream);
 
 // ---------------------------------------------------------------------------
 // optional per-launch timing of the dominant kernel (the fc1 GEMM, k_gemm<GELU>):
@@ -447,14 +453,33 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     // patch embed (+bias +pos_embed)
     RUN(cpx_gemm_bf16(patches, w->pe_w, M, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024, stream));
+    float *st = (float *)(ws + L.off_st);
+    // LayerNorm fusion: the RESID GEMMs emit partial row statistics of the residual stream, the
+    // next GEMM applies (x - mean) * rstd algebraically in its epilogue (weights pre-folded)
+    const bool fuse = w->fuse_ln != 0;
+    const bool big_stats = fuse && cpx_gemm_uses_big_tile(M, 1024, 1024, CPX_EPI_RESID_BF16) &&
+                           cpx_gemm_uses_big_tile(M, 1024, 4096, CPX_EPI_RESID_BF16);
+    if (fuse) RUN(cpx_row_stats(x, M, st, stream));
     for (int i = 0; i < w->depth; ++i) {
         const cpx_block_weights &b = w->blocks[i];
+        const bool prof = g_prof_ev && g_prof_n < g_prof_cap;
+        if (fuse) {
+            RUN(cpx_gemm_ln(x, b.qkv_w, M, 3072, 1024, CPX_EPI_QKV_BF16, b.qkv_b, vt, qkv, 3072, st, b.qkv_colsum, nullptr, stream));
+            RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
+            RUN(cpx_gemm_ln(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
+            if (!big_stats) RUN(cpx_row_stats(x, M, st, stream));
+            if (prof) CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n], (hipStream_t)stream));
+            RUN(cpx_gemm_ln(x, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, st, b.fc1_colsum, nullptr, stream));
+            if (prof) { CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], (hipStream_t)stream)); ++g_prof_n; }
+            RUN(cpx_gemm_ln(hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
+            if (!big_stats) RUN(cpx_row_stats(x, M, st, stream));
+            continue;
+        }
         RUN(cpx_layernorm_bf16(x, b.ln1_w, b.ln1_b, M, 1024, 1e-6f, xn, stream));
         RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, CPX_EPI_QKV_BF16, b.qkv_b, vt, qkv, 3072, stream));
         RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
         RUN(cpx_gemm_bf16(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, stream));
         RUN(cpx_layernorm_bf16(x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
-        const bool prof = g_prof_ev && g_prof_n < g_prof_cap;
         if (prof) CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n], (hipStream_t)stream));
         RUN(cpx_gemm_bf16(xn, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, stream));
         if (prof) { CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], (hipStream_t)stream)); ++g_prof_n; }

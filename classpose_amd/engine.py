@@ -113,7 +113,8 @@ class NetWeights:
         return (fts or None), n_classes, depth
 
     @classmethod
-    def from_state_dict(cls, sd: dict, precision: str = "bf16", device="cuda:0") -> "NetWeights":
+    def from_state_dict(cls, sd: dict, precision: str = "bf16", device="cuda:0",
+                        fuse_ln: bool = True) -> "NetWeights":
         if precision not in HALF_DTYPES:
             raise ValueError(f"precision {precision!r}: the MI355X engine computes in bf16 or fp16 "
                              "(fp32 has no MFMA fast path on gfx950)")
@@ -143,6 +144,20 @@ class NetWeights:
         c.n_head_cols = 192 + (ncls * 64 if ncls > 1 else 0)
         c.ld_head = (c.n_head_cols + 127) // 128 * 128
         c.dtype = 0 if precision == "bf16" else 1
+        c.fuse_ln = int(bool(fuse_ln))
+
+        def fold_ln(w, b, gamma, beta):
+            """LayerNorm folded into the following Linear: (W diag(gamma), b + W beta, row sums of
+            the folded half-rounded W).  All inputs are first rounded to the half dtype (net.to(dtype))."""
+            wq, bq = w.detach().to(hd).float(), b.detach().to(hd).float()
+            gq, btq = gamma.detach().to(hd).float(), beta.detach().to(hd).float()
+            wf = (wq * gq[None, :]).to(hd)
+            return wf, bq + wq @ btq, wf.float().sum(1)
+
+        def vec32(t):       # already float32, no re-rounding
+            x = t.detach().float().contiguous().to(dev)
+            self.keep.append(x)
+            return x.data_ptr()
         c.pe_w = half(sd["encoder.patch_embed.proj.weight"].reshape(1024, 192))
         c.pe_b = vec(sd["encoder.patch_embed.proj.bias"])
         c.pos = vec(sd["encoder.pos_embed"].reshape(1024, 1024))
@@ -151,7 +166,12 @@ class NetWeights:
             p = f"encoder.blocks.{i}."
             b = self.blocks[i]
             b.ln1_w, b.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
-            b.qkv_w, b.qkv_b = half(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
+            if fuse_ln:
+                wf, bf, cs = fold_ln(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"],
+                                     sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+                b.qkv_w, b.qkv_b, b.qkv_colsum = half(wf), vec32(bf), vec32(cs)
+            else:
+                b.qkv_w, b.qkv_b = half(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
             b.proj_w, b.proj_b = half(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
             for name, key in (("rel_h", "attn.rel_pos_h"), ("rel_w", "attn.rel_pos_w")):
                 # table interpolated to 2*32-1 rows in the half dtype (what get_rel_pos does on
@@ -160,7 +180,12 @@ class NetWeights:
                 t = torch.cat([t, torch.zeros(1, 64)], 0)
                 setattr(b, name, half(t))
             b.ln2_w, b.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
-            b.fc1_w, b.fc1_b = half(sd[p + "mlp.lin1.weight"]), vec(sd[p + "mlp.lin1.bias"])
+            if fuse_ln:
+                wf, bf, cs = fold_ln(sd[p + "mlp.lin1.weight"], sd[p + "mlp.lin1.bias"],
+                                     sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+                b.fc1_w, b.fc1_b, b.fc1_colsum = half(wf), vec32(bf), vec32(cs)
+            else:
+                b.fc1_w, b.fc1_b = half(sd[p + "mlp.lin1.weight"]), vec(sd[p + "mlp.lin1.bias"])
             b.fc2_w, b.fc2_b = half(sd[p + "mlp.lin2.weight"]), vec(sd[p + "mlp.lin2.bias"])
         c.blocks = C.cast(self.blocks, C.POINTER(CpxBlockWeights))
         c.neck0_w = half(sd["encoder.neck.0.weight"].reshape(256, 1024))

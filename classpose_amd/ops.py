@@ -239,3 +239,21 @@ def attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor):
     check(_lib.lib().cpx_attention_relpos(ptr(qkv), ptr(rel_h), ptr(rel_w), nS, ptr(vt), ptr(out),
                                           _stream(qkv.device)), "attention")
     return out
+
+
+def row_stats(x: torch.Tensor) -> torch.Tensor:
+    st = torch.empty((x.shape[0], 4, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cpx_row_stats(ptr(x), x.shape[0], ptr(st), _stream(x.device)), "row_stats")
+    return st
+
+
+def gemm_ln(A, Wt, epilogue="bf16", bias=None, aux=None, ln_stats=None, ln_colsum=None, want_stats=False):
+    """GEMM with a LayerNorm over the input row folded in / output row statistics emitted."""
+    M, K = A.shape
+    N = Wt.shape[0]
+    dev = A.device
+    out = torch.empty((M, N), dtype=torch.float32 if epilogue == "f32" else A.dtype, device=dev)
+    st = torch.zeros((M, 4, 2), dtype=torch.float32, device=dev) if want_stats else None
+    check(_lib.lib().cpx_gemm_ln(ptr(A), ptr(Wt), M, N, K, EPI[epilogue], ptr(bias), ptr(aux), ptr(out), N,
+                                 ptr(ln_stats), ptr(ln_colsum), ptr(st), _stream(dev)), "gemm_ln")
+    return (out, st) if want_stats else out

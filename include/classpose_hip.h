@@ -110,6 +110,10 @@ typedef struct cpx_block_weights {
     const float *ln2_w, *ln2_b;
     const void *fc1_w;  const float *fc1_b;   /* bf16 [4096][1024]            */
     const void *fc2_w;  const float *fc2_b;   /* bf16 [1024][4096]            */
+    /* LayerNorm folded into the consuming GEMM (cpx_net_weights.fuse_ln = 1): qkv_w / fc1_w
+     * hold W * diag(gamma), qkv_b / fc1_b hold b + W.beta, and these are the row sums of the
+     * folded (half-rounded) weights; ln*_w / ln*_b are then unused.                        */
+    const float *qkv_colsum, *fc1_colsum;     /* [3072], [4096]               */
 } cpx_block_weights;
 
 typedef struct cpx_net_weights {
@@ -118,6 +122,7 @@ typedef struct cpx_net_weights {
     int n_head_cols;        /* 192 + ncls*64                                   */
     int ld_head;            /* n_head_cols rounded up to 128                   */
     int dtype;              /* 0 = bf16, 1 = fp16                              */
+    int fuse_ln;            /* 1: norm1 / norm2 are folded into qkv / mlp.lin1 (see above) */
     const void *pe_w;       /* [1024][192]                                     */
     const float *pe_b;      /* [1024]                                          */
     const float *pos;       /* [1024 tokens][1024] float32                     */
@@ -148,6 +153,15 @@ int cpx_net_forward(const cpx_net_weights *w_host, const void *patches_bf16, int
 int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
                   const float *bias, const void *resid_or_pos, void *out, int ld_out,
                   void *stream);
+/* Same with a LayerNorm over the K = 1024 input row folded in (consumer) and/or partial row
+ * statistics of the output emitted (producer, RESID epilogue, N = 1024, 256^2-tile shapes):
+ *   out = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]     (then the epilogue)
+ * ln_stats / stats_out: [M][4][2] float partial (sum, sum of squares); cpx_row_stats fills
+ * slot 0 from a [rows][1024] half matrix.  vit_sam.py:175-176 (SAM Block: norm1/norm2). */
+int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                const float *bias, const void *resid_or_pos, void *out, int ld_out,
+                const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream);
+int cpx_row_stats(const void *x, int rows, float *stats, void *stream);
 int cpx_layernorm_bf16(const void *x, const float *w, const float *b, int rows, int C,
                        float eps, void *out, void *stream);
 /* qkv [nS*1024][3072] bf16 (q|k|v, head-major inside) -> attn out [nS*1024][1024]. */

@@ -257,3 +257,59 @@ def test_gemm_qkv_epilogue_writes_v_transposed(cuda, nS):
     assert torch.equal(out[:, :2048], ref[:, :2048])
     exp = ref[:, 2048:].reshape(nS, 1024, 16, 64).permute(0, 2, 3, 1)
     assert torch.equal(vT, exp)
+
+
+@pytest.mark.parametrize("M,N", [(512, 384), (32768, 3072)])
+def test_gemm_with_folded_layernorm(cuda, M, N):
+    """LN(x) W^T + b  ==  rstd (x W'^T - mean colsum) + b'   (both kernels)"""
+    K = 1024
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 2 + 0.3).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / 32).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).float()
+    gamma = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).float()
+    beta = (0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).float()
+    Wf = (W.float() * gamma[None]).to(torch.bfloat16)
+    bf = b + W.float() @ beta
+    cs = Wf.float().sum(1)
+    st = ops.row_stats(x)
+    xf = x.float()
+    assert torch.allclose(st[:, 0, 0], xf.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[:, 0, 1], (xf * xf).sum(1), rtol=1e-5, atol=1e-3)
+    out = ops.gemm_ln(x, Wf.to(cuda), "bf16", bf.to(cuda), None, st, cs.to(cuda))
+    ref = torch.nn.functional.layer_norm(xf, (K,), gamma.to(cuda), beta.to(cuda), 1e-6) @ W.float().to(cuda).T + b.to(cuda)
+    assert _rel(out.float(), ref) < 6e-3, _rel(out.float(), ref)
+
+
+def test_gemm_resid_emits_row_stats(cuda):
+    M, N, K = 32768 * 2, 1024, 1024
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / 32).to(torch.bfloat16).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(cuda)
+    out, st = ops.gemm_ln(A, W, "resid", b, res, want_stats=True)
+    o = out.float()
+    assert torch.allclose(st[..., 0].sum(1), o.sum(1), rtol=1e-4, atol=2e-2)
+    assert torch.allclose(st[..., 1].sum(1), (o * o).sum(1), rtol=1e-4, atol=2e-2)
+    assert torch.equal(out, ops.gemm(A, W, "resid", b, res))
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_net_forward_fused_vs_unfused_layernorm(cuda, fuse):
+    sd = synth.make_state_dict(7, None, depth=2, seed=5)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", cuda, fuse_ln=fuse)
+    nS = 32
+    x = np.random.default_rng(1).random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5) \
+        .reshape(nS * 1024, 192).to(torch.bfloat16).to(cuda)
+    L = _lib.lib()
+    import ctypes as C
+    head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+    ws = torch.empty(L.cpx_net_workspace_bytes(nS), dtype=torch.uint8, device=cuda)
+    _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), torch.cuda.current_stream().cuda_stream))
+    out = head[:1024 * 2, :640].reshape(2, 32, 32, 10, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(2, 10, 256, 256).cpu()
+    ours = torch.cat([out[:, 3:], out[:, :3]], 1)
+    ref32 = onet.class_transformer_forward(sd, torch.from_numpy(x[:2]))
+    assert _rel(ours, ref32) < 2e-2, _rel(ours, ref32)
