@@ -164,6 +164,12 @@ def main():
     avg_ms = ms_sum.value / max(cnt.value, 1)
     achieved = fc1_flops / (avg_ms * 1e-3) / 1e12 if cnt.value else 0.0
     flop_per_tile = 727.3e9 * eng.n_sub
+    traffic = None
+    try:      # HBM-side bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes, committed
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     line = {
         "metric": "wsi_tiles_per_sec",
         "value": n_tiles / dt,
@@ -185,9 +191,11 @@ def main():
                                "k %% n_gpus" % (args.depth, bt),
                    "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * eng.n_sub,
                    "tiles_per_step": bt, "records_gathered": int(allrec.shape[0])},
-        "roofline": {"bound": "mfma", "kernel": "k_gemm<GELU> (mlp.lin1 %dx4096x1024)" % M,
+        "roofline": {"bound": "mfma", "kernel": "k_gemm256<GELU> (mlp.lin1 %dx4096x1024)" % M,
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                     "algorithmic_bytes": 2.0 * (M * 1024 + 4096 * 1024 + M * 4096),
                      "launches_timed": cnt.value, "avg_launch_ms": avg_ms},
     }
     if rank == 0:
