@@ -40,6 +40,7 @@ struct GemmArgs {
     int ld_out;
     int tiles_n, n_blocks;
     int l2_block;           // 1: 8 x 4 super-tile order per XCD (debug switch, default on)
+    int dbg;                // timing-only ablations of the 256^2 epilogue (0 in production)
     // LayerNorm folded into the GEMM (consumer side): out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
     // with W pre-multiplied by gamma, bias = b + W.beta, colsum[n] = sum_k W'[n][k]
     const float *ln_stats;   // [M][4][2] partial (sum, sum of squares) of the K = 1024 input row, or null
@@ -73,7 +74,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     // gelu = 0.5 x (1 + erf(x / sqrt2)) = 0.5 x + 0.5 |x| (1 - poly(t) t exp(-x^2 / 2)),
     // t = 1 / (1 + (p / sqrt2) |x|); constants folded so that |x| is a free source modifier
     const float ax = fabsf(x);
-    const float t = __frcp_rn(__fmaf_rn(0.23164189f, ax, 1.0f));          // 0.3275911 / sqrt(2)
+    const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.23164189f, ax, 1.0f));   // 0.3275911 / sqrt(2); v_rcp_f32 (1 ulp)
     float poly = 1.061405429f;
     poly = __fmaf_rn(poly, t, -1.453152027f);
     poly = __fmaf_rn(poly, t, 1.421413741f);
@@ -466,8 +467,10 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                     if constexpr (EPI == CPX_EPI_GELU_BF16) {
+                        if (!(g.dbg & 2)) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        }
                     } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                 }
                 v = make_uint4(a[0], a[1], a[2], a[3]);
             }
-            *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = v;
+            if (!(g.dbg & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = v;
             if (g.stats_out) {
                 // partial LayerNorm statistics of the (rounded) output row over this block's 256 columns:
                 // 32 lanes share a row; slot = column tile, written whole -> deterministic, no atomics
@@ -538,6 +541,8 @@ extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
 extern "C" void cpx_set_half_dtype(int f16) { g_gemm_f16 = f16; }
 extern "C" int cpx_get_half_dtype(void) { return g_gemm_f16; }
 
+static int g_gemm_dbg = 0;
+extern "C" void cpx_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 static int g_gemm_l2 = 1;
 extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 static int g_gemm_big = 1;         // 1 = use the 256^2 kernel when the shape allows
@@ -624,7 +629,7 @@ extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, i
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
-    a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2;
+    a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s); break;
