@@ -221,10 +221,20 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     const unsigned short *vbase = vT + (((size_t)s * 16 + head) * 64 + v_d) * 1024 + v_c * 8;
     const int k_dst = k_key * 64 + ((k_c ^ (k_key & 7)) * 8);
     const int v_dst = v_d * 32 + ((v_c ^ ((v_d >> 2) & 3)) * 8);
-    uint4 kreg = *reinterpret_cast<const uint4 *>(kbase);
-    uint4 vreg = *reinterpret_cast<const uint4 *>(vbase);
-    *reinterpret_cast<uint4 *>(&sK[0][k_dst]) = kreg;
-    *reinterpret_cast<uint4 *>(&sV[0][v_dst]) = vreg;
+    // K / V^T tiles reach LDS through a 4-deep REGISTER ring: the global loads for key tile t+3 are
+    // issued in iteration t and written to LDS at the end of iteration t+2, so each load has two
+    // full iterations to land (one iteration did not cover the L2/HBM latency: a lone workgroup
+    // spent ~1800 cycles per 32-key tile waiting for it).
+    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;      // named (statically indexed) so they stay in VGPRs
+    kr0 = *reinterpret_cast<const uint4 *>(kbase);
+    vr0 = *reinterpret_cast<const uint4 *>(vbase);
+    kr1 = *reinterpret_cast<const uint4 *>(kbase + (size_t)1 * 32 * 3072);
+    vr1 = *reinterpret_cast<const uint4 *>(vbase + 1 * 32);
+    kr2 = *reinterpret_cast<const uint4 *>(kbase + (size_t)2 * 32 * 3072);
+    vr2 = *reinterpret_cast<const uint4 *>(vbase + 2 * 32);
+    kr3 = kr0; vr3 = vr0;
+    *reinterpret_cast<uint4 *>(&sK[0][k_dst]) = kr0;
+    *reinterpret_cast<uint4 *>(&sV[0][v_dst]) = vr0;
     __syncthreads();
 
     f32x16 O[2], GW, Lacc;                                   // Lacc row 0 = running softmax denominator
@@ -239,11 +249,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     const float RESCALE_THR = 6.0f;                         // defer-max: tolerate p <= 2^6 (exp2 domain)
     const int krow = pi_perm(r);                            // key row this lane feeds to the K operand
 
-    for (int kh = 0; kh < 32; ++kh) {
-        const int buf = kh & 1;
-        if (kh + 1 < 32) {
-            kreg = *reinterpret_cast<const uint4 *>(kbase + (size_t)(kh + 1) * 32 * 3072);
-            vreg = *reinterpret_cast<const uint4 *>(vbase + (kh + 1) * 32);
+    auto tile = [&](const int kh, const int buf, uint4 &k_ld, uint4 &v_ld, const uint4 &k_st, const uint4 &v_st) {
+        if (kh + 3 < 32) {
+            k_ld = *reinterpret_cast<const uint4 *>(kbase + (size_t)(kh + 3) * 32 * 3072);
+            v_ld = *reinterpret_cast<const uint4 *>(vbase + (kh + 3) * 32);
         }
         // S' = K . Q^T + Gw   (Gw rides in as the MFMA C operand; Gh is one scalar per lane and
         // is folded into the exponent offset, so the bias costs no per-element VALU work)
@@ -307,10 +316,16 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
         Lacc = mfma32<F16>(ones_f, pf[0], Lacc);
         Lacc = mfma32<F16>(ones_f, pf[1], Lacc);
         if (kh + 1 < 32) {
-            *reinterpret_cast<uint4 *>(&sK[buf ^ 1][k_dst]) = kreg;
-            *reinterpret_cast<uint4 *>(&sV[buf ^ 1][v_dst]) = vreg;
+            *reinterpret_cast<uint4 *>(&sK[buf ^ 1][k_dst]) = k_st;
+            *reinterpret_cast<uint4 *>(&sV[buf ^ 1][v_dst]) = v_st;
         }
         __syncthreads();
+    };
+    for (int kh0 = 0; kh0 < 32; kh0 += 4) {          // ring slot of tile t is t & 3
+        tile(kh0 + 0, 0, kr3, vr3, kr1, vr1);
+        tile(kh0 + 1, 1, kr0, vr0, kr2, vr2);
+        tile(kh0 + 2, 0, kr1, vr1, kr3, vr3);
+        tile(kh0 + 3, 1, kr2, vr2, kr0, vr0);
     }
     // row 0 of Lacc sits in register 0 of the lower half-wave (row = (reg&3)+8*(reg>>2)+4*h2)
     const float l_tot = __shfl(Lacc[0], r);
