@@ -85,6 +85,7 @@ SIGNATURES = {
 _PRIVATE = {
     "cpx_gemm_set_variant": (None, [_i]),
     "cpx_gemm_set_big": (None, [_i]),
+    "cpx_attention_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),
     "cpx_set_half_dtype": (None, [_i]),

@@ -164,12 +164,33 @@ __global__ void __launch_bounds__(256) k_v_transpose(const unsigned short *__res
 #define GS_LD 65                       // padded row of the per-wave G scratch (floats)
 __device__ __forceinline__ int pi_perm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <bool F16>
+// DBG = true: diagnostic build with s_memtime stamps per loop segment (never used in production;
+// stamp values only go to `dbg`, no output depends on them)
+#define ATT_STAMP(i)                                                                           \
+    do {                                                                                       \
+        if constexpr (DBG) {                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            seg[i] += (unsigned)(t_ - tprev);                                                  \
+            tprev = t_;                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    } while (0)
+#define ATT_FORCE(x)                                                                           \
+    do {                                                                                       \
+        if constexpr (DBG) { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(x)); asm volatile("" ::"v"(d_)); } \
+    } while (0)
+template <bool F16, bool DBG = false>
 __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short *__restrict__ qkv,
                                                            const unsigned short *__restrict__ vT,
                                                            const unsigned short *__restrict__ relh,
                                                            const unsigned short *__restrict__ relw,
-                                                           unsigned short *__restrict__ out) {
+                                                           unsigned short *__restrict__ out,
+                                                           unsigned *__restrict__ dbg = nullptr) {
+    unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0, tstart = 0;
+    if constexpr (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory"); tprev = tstart; }
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][32 * 64];
     __shared__ __attribute__((aligned(16))) unsigned short sV[2][64 * 32];
     __shared__ float sG[4][32 * GS_LD];
@@ -249,6 +270,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     const float RESCALE_THR = 6.0f;                         // defer-max: tolerate p <= 2^6 (exp2 domain)
     const int krow = pi_perm(r);                            // key row this lane feeds to the K operand
 
+    ATT_STAMP(7);                                      // prologue (Q load, G products, first tiles)
     auto tile = [&](const int kh, const int buf, uint4 &k_ld, uint4 &v_ld, const uint4 &k_st, const uint4 &v_st) {
         if (kh + 3 < 32) {
             k_ld = *reinterpret_cast<const uint4 *>(kbase + (size_t)(kh + 3) * 32 * 3072);
@@ -267,6 +289,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
             uint4 kf = *reinterpret_cast<const uint4 *>(&sK[buf][krow * 64 + (((2 * ks + h2) ^ (krow & 7)) * 8)]);
             S = mfma32<F16>(kf, qf[ks], S);
         }
+        ATT_FORCE(S[15]); ATT_STAMP(0);                 // gh + K fragment reads + 4 QK MFMAs
         // online softmax (per lane = per query; the two half-waves hold different keys)
         float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
 #pragma unroll
@@ -285,6 +308,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
             for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
             m_run = m_new;
         }
+        ATT_FORCE(m_run); ATT_STAMP(1);                 // max chain + half swap + vote (+ rescale)
         const float off = (gh - m_run) * cexp;
         float p[16];
         const f32x2_t c2 = {cexp, cexp}, off2 = {off, off};
@@ -304,6 +328,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
             for (int jj = 0; jj < 4; ++jj) u[jj] = pack2<F16>(p[8 * st + 2 * jj], p[8 * st + 2 * jj + 1]);
             pf[st] = make_uint4(u[0], u[1], u[2], u[3]);
         }
+        ATT_FORCE(__uint_as_float(pf[1].w)); ATT_STAMP(2);   // fma + exp + pack
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
             const int d = db * 32 + r;
@@ -315,17 +340,29 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
         }
         Lacc = mfma32<F16>(ones_f, pf[0], Lacc);
         Lacc = mfma32<F16>(ones_f, pf[1], Lacc);
+        ATT_FORCE(O[1][15]); ATT_FORCE(Lacc[15]); ATT_STAMP(3);   // V fragment reads + 6 PV / ones MFMAs
         if (kh + 1 < 32) {
             *reinterpret_cast<uint4 *>(&sK[buf ^ 1][k_dst]) = k_st;
             *reinterpret_cast<uint4 *>(&sV[buf ^ 1][v_dst]) = v_st;
         }
+        ATT_STAMP(4);                                   // wait for the prefetched tile + LDS writes
         __syncthreads();
+        ATT_STAMP(5);                                   // barrier
     };
     for (int kh0 = 0; kh0 < 32; kh0 += 4) {          // ring slot of tile t is t & 3
         tile(kh0 + 0, 0, kr3, vr3, kr1, vr1);
         tile(kh0 + 1, 1, kr0, vr0, kr2, vr2);
         tile(kh0 + 2, 0, kr1, vr1, kr3, vr3);
         tile(kh0 + 3, 1, kr2, vr2, kr0, vr0);
+    }
+    if constexpr (DBG) {
+        unsigned long long tend;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
+        if (lane == 0) {
+            unsigned *d = dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 * 9 + wave * 9;
+            for (int i = 0; i < 8; ++i) d[i] = seg[i];
+            d[8] = (unsigned)(tend - tstart);
+        }
     }
     // row 0 of Lacc sits in register 0 of the lower half-wave (row = (reg&3)+8*(reg>>2)+4*h2)
     const float l_tot = __shfl(Lacc[0], r);
@@ -345,6 +382,18 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
 
 static int attention_launch(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                             void *vT_ws, void *out, void *stream, bool transpose_v);
+// diagnostic: per-wave cycle counts of the loop segments -> dbg [n_subtiles*16*8 blocks][4 waves][9]
+extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                                   void *vT_ws, void *out, unsigned *dbg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
+                       (const unsigned short *)qkv, (unsigned short *)vT_ws);
+    hipLaunchKernelGGL((k_attention<false, true>), dim3(8, 16, n_subtiles), dim3(ATT_THREADS), 0, s,
+                       (const unsigned short *)qkv, (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
+                       (const unsigned short *)rel_w, (unsigned short *)out, dbg);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
 extern "C" int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w,
                                     int n_subtiles, void *vT_ws, void *out, void *stream) {
     return attention_launch(qkv, rel_h, rel_w, n_subtiles, vT_ws, out, stream, true);
@@ -359,13 +408,13 @@ static int attention_launch(const void *qkv, const void *rel_h, const void *rel_
                            (const unsigned short *)qkv, (unsigned short *)vT_ws);
     dim3 grid(8, 16, n_subtiles);
     if (cpx_get_half_dtype())
-        hipLaunchKernelGGL(k_attention<true>, grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
+        hipLaunchKernelGGL((k_attention<true, false>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
                            (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                           (const unsigned short *)rel_w, (unsigned short *)out);
+                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr);
     else
-        hipLaunchKernelGGL(k_attention<false>, grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
+        hipLaunchKernelGGL((k_attention<false, false>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
                            (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                           (const unsigned short *)rel_w, (unsigned short *)out);
+                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
