@@ -29,6 +29,12 @@ class CpxBlockWeights(C.Structure):
         "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_colsum", "fc1_colsum")]
 
 
+class CpxConvOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("src_a", C.c_int), ("src_b", C.c_int), ("dst", C.c_int),
+                ("cin_a", C.c_int), ("cin_b", C.c_int), ("cout", C.c_int), ("h", C.c_int), ("w", C.c_int),
+                ("relu", C.c_int), ("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
 class CpxNetWeights(C.Structure):
     _fields_ = [("depth", C.c_int), ("ncls", C.c_int), ("n_head_cols", C.c_int),
                 ("ld_head", C.c_int), ("dtype", C.c_int), ("fuse_ln", C.c_int),
@@ -36,7 +42,8 @@ class CpxNetWeights(C.Structure):
                 ("blocks", C.POINTER(CpxBlockWeights)),
                 ("neck0_w", C.c_void_p), ("neck_ln1_w", C.c_void_p), ("neck_ln1_b", C.c_void_p),
                 ("neck2_w", C.c_void_p), ("neck_ln2_w", C.c_void_p), ("neck_ln2_b", C.c_void_p),
-                ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+                ("n_unet_ops", C.c_int), ("unet_ops", C.POINTER(CpxConvOp))]
 
 
 class CpxRecord(C.Structure):
@@ -64,6 +71,8 @@ SIGNATURES = {
     "cpx_blend_subtiles_nchw": (_i, [_p, _p, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
     "cpx_net_workspace_bytes": (_sz, [_i]),
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
+    "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i]),
+    "cpx_unet_head_forward": (_i, [C.POINTER(CpxConvOp), _i, _p, _i, _p, _i, _i, _p, _sz, _p]),
     "cpx_gemm_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
     "cpx_gemm_ln": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_row_stats": (_i, [_p, _i, _p, _p]),

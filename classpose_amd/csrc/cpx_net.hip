@@ -18,6 +18,7 @@
 //     in the permuted order pi(r) = swap bits 2,3 so that the accumulator's
 //     register order is the natural key order of the V^T operand.
 #include "cpx_common.h"
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -464,6 +465,9 @@ static NetWs net_ws(int nS) {
 extern "C" size_t cpx_net_workspace_bytes(int n_subtiles) {
     return n_subtiles > 0 ? net_ws(n_subtiles).total : 0;
 }
+extern "C" size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops, int n_ops, int nS);
+extern "C" int cpx_unet_head_forward(const cpx_conv_op *ops, int n_ops, const void *feat, int nS, float *head,
+                                     int ld_head, int col0, void *workspace, size_t ws_bytes, void *stream);
 
 extern "C" void cpx_set_half_dtype(int f16);
 extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
@@ -562,6 +566,156 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
     RUN(cpx_layernorm_bf16(nk, w->neck_ln2_w, w->neck_ln2_b, M, 256, 1e-6f, nk2, stream));
     // heads: out (192) | out_class (ncls*64), f32 token-major
     RUN(cpx_gemm_bf16(nk2, w->head_w, M, w->ld_head, 256, CPX_EPI_F32, w->head_b, nullptr, head, w->ld_head, stream));
+    if (w->n_unet_ops > 0) {        // UNet semantic head overwrites the class columns (head_w rows there are zero)
+        const size_t need = cpx_unet_workspace_bytes(w->unet_ops, w->n_unet_ops, nS);
+        CPX_REQUIRE(workspace_bytes >= L.total + need);
+        RUN(cpx_unet_head_forward(w->unet_ops, w->n_unet_ops, nk2, nS, head, w->ld_head, 192, ws + L.total, need, stream));
+    }
 #undef RUN
+    return CPX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// UNet semantic head (unet.py:121-196) as a list of convolutions on token-major tensors
+// ---------------------------------------------------------------------------
+// gather for conv3x3 (pad 1) / conv2x2 stride 2 from up to two channel-concatenated sources
+__global__ void __launch_bounds__(256) k_conv_gather(const unsigned short *__restrict__ a, int lda, int ca,
+                                                     const unsigned short *__restrict__ b, int ldb, int cb,
+                                                     int kind, int h, int w, size_t rows_out, int kpad,
+                                                     unsigned short *__restrict__ out) {
+    const int ctot = ca + cb, c8n = ctot >> 3, taps = kind == 0 ? 9 : (kind == 1 ? 4 : 1);   // kind 3: plain repack
+    const int chunks_per_row = kpad >> 3;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows_out * chunks_per_row) return;
+    size_t row = i / chunks_per_row;
+    int ch = (int)(i - row * chunks_per_row);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int ho = kind == 1 ? h >> 1 : h, wo = kind == 1 ? w >> 1 : w;
+    if (ch < taps * c8n) {
+        int tap = ch / c8n, c8 = ch - tap * c8n;
+        size_t s_ = row / (size_t)(ho * wo);
+        int t = (int)(row - s_ * ho * wo), y = t / wo, x = t - y * wo;
+        int yy, xx;
+        if (kind == 0) { yy = y + tap / 3 - 1; xx = x + tap % 3 - 1; }
+        else if (kind == 1) { yy = 2 * y + (tap >> 1); xx = 2 * x + (tap & 1); }
+        else { yy = y; xx = x; }
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+            size_t src_row = s_ * h * w + (size_t)yy * w + xx;
+            int c = c8 * 8;
+            v = c < ca ? *reinterpret_cast<const uint4 *>(a + src_row * lda + c)
+                       : *reinterpret_cast<const uint4 *>(b + src_row * ldb + (c - ca));
+        }
+    }
+    *reinterpret_cast<uint4 *>(out + row * kpad + (size_t)ch * 8) = v;
+}
+
+// depth-to-space for convT2x2 s2: in [rows][ld_in] cols (tap, co) -> half [4*rows][ld_out] or f32 head columns
+template <bool F16>
+__global__ void __launch_bounds__(256) k_depth2space(const unsigned short *__restrict__ in, int ld_in, int cout,
+                                                     int h, int w, size_t rows_in, unsigned short *__restrict__ out,
+                                                     int ld_out, float *__restrict__ out_f32, int ld_f32, int col0) {
+    const int c8n = cout >> 3;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows_in * 4 * c8n) return;
+    size_t row = i / (4 * c8n);
+    int rem = (int)(i - row * 4 * c8n), tap = rem / c8n, c8 = rem - tap * c8n;
+    size_t s_ = row / (size_t)(h * w);
+    int t = (int)(row - s_ * h * w), y = t / w, x = t - y * w;
+    size_t orow = s_ * 4 * h * w + (size_t)(2 * y + (tap >> 1)) * (2 * w) + 2 * x + (tap & 1);
+    uint4 v = *reinterpret_cast<const uint4 *>(in + row * ld_in + tap * cout + c8 * 8);
+    if (out_f32) {
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        float *o = out_f32 + orow * ld_f32 + col0 + c8 * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[2 * k] = f32_from_h<F16>(u[k] & 0xFFFF); o[2 * k + 1] = f32_from_h<F16>(u[k] >> 16); }
+    } else {
+        *reinterpret_cast<uint4 *>(out + orow * ld_out + c8 * 8) = v;
+    }
+}
+
+static inline int up128(long long x) { return (int)((x + 127) / 128 * 128); }
+static inline int up64(int x) { return (x + 63) / 64 * 64; }
+
+// workspace: tensors [rows_pad][ld] half, one per op, + the largest im2col / GEMM staging buffers
+extern "C" size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops, int n_ops, int nS) {
+    size_t tot = 0, col_max = 0, g_max = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        const cpx_conv_op &o = ops[i];
+        const int ho = o.kind == 0 ? o.h : (o.kind == 1 ? o.h / 2 : o.h * 2), wo = o.kind == 0 ? o.w : (o.kind == 1 ? o.w / 2 : o.w * 2);
+        const size_t rows_out = (size_t)nS * ho * wo;
+        tot += cpx_align_up((size_t)up128(rows_out) * up128(o.cout) * 2, 256);
+        if (o.kind != 2) col_max = std::max(col_max, (size_t)up128(rows_out) * up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)) * 2);
+        else {
+            g_max = std::max(g_max, (size_t)up128((size_t)nS * o.h * o.w) * up128(4 * o.cout) * 2);
+            col_max = std::max(col_max, (size_t)up128((size_t)nS * o.h * o.w) * up64(o.cin_a) * 2);
+        }
+    }
+    return tot + cpx_align_up(col_max, 256) + cpx_align_up(g_max, 256) + 1024;
+}
+
+// feat: neck output [nS*1024][256] half (tensor id 0).  The LAST op must be a convT producing
+// ncls*64 channels at 32x32: it is written as float32 into head[:, col0 : col0 + cout].
+extern "C" int cpx_unet_head_forward(const cpx_conv_op *ops, int n_ops, const void *feat, int nS, float *head,
+                                     int ld_head, int col0, void *workspace, size_t ws_bytes, void *stream) {
+    CPX_REQUIRE(ops && n_ops > 0 && n_ops <= 64 && feat && head && workspace && nS > 0);
+    CPX_REQUIRE(ws_bytes >= cpx_unet_workspace_bytes(ops, n_ops, nS));
+    hipStream_t s = (hipStream_t)stream;
+    const bool f16 = cpx_get_half_dtype();
+    struct T { const unsigned short *p; int ld, c, h, w; } tens[66];
+    tens[0] = {(const unsigned short *)feat, 256, 256, 32, 32};
+    char *ws = (char *)workspace;
+    size_t off = 0, col_max = 0, g_max = 0;
+    for (int i = 0; i < n_ops; ++i) {     // sizes of the shared staging buffers first
+        const cpx_conv_op &o = ops[i];
+        const int ho = o.kind == 0 ? o.h : (o.kind == 1 ? o.h / 2 : o.h * 2), wo = o.kind == 0 ? o.w : (o.kind == 1 ? o.w / 2 : o.w * 2);
+        if (o.kind != 2) col_max = std::max(col_max, (size_t)up128((size_t)nS * ho * wo) * up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)) * 2);
+        else {
+            g_max = std::max(g_max, (size_t)up128((size_t)nS * o.h * o.w) * up128(4 * o.cout) * 2);
+            col_max = std::max(col_max, (size_t)up128((size_t)nS * o.h * o.w) * up64(o.cin_a) * 2);
+        }
+    }
+    unsigned short *colbuf = (unsigned short *)ws; off = cpx_align_up(col_max, 256);
+    unsigned short *gbuf = (unsigned short *)(ws + off); off += cpx_align_up(g_max, 256);
+    int rc;
+    for (int i = 0; i < n_ops; ++i) {
+        const cpx_conv_op &o = ops[i];
+        CPX_REQUIRE(o.dst > 0 && o.dst < 66 && o.src_a >= 0 && o.src_a < 66 && o.src_b < 66);
+        CPX_REQUIRE(o.cin_a % 8 == 0 && o.cin_b % 8 == 0 && o.cout % 8 == 0 && o.weight && o.bias);
+        const T &A = tens[o.src_a];
+        const T Bz = {nullptr, 0, 0, 0, 0};
+        const T &B = o.src_b >= 0 ? tens[o.src_b] : Bz;
+        CPX_REQUIRE(A.c == o.cin_a && A.h == o.h && A.w == o.w && (o.src_b < 0 || (B.c == o.cin_b && B.h == o.h && B.w == o.w)));
+        if (o.kind != 2) {
+            const int ho = o.kind == 0 ? o.h : o.h / 2, wo = o.kind == 0 ? o.w : o.w / 2;
+            const size_t rows = (size_t)nS * ho * wo;
+            const int Mp = up128(rows), Kp = up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)), Np = up128(o.cout);
+            const size_t n_chunks = rows * (Kp / 8);
+            hipLaunchKernelGGL(k_conv_gather, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, A.p, A.ld, o.cin_a,
+                               B.p, B.ld, o.cin_b, o.kind, o.h, o.w, rows, Kp, colbuf);
+            unsigned short *dst = (unsigned short *)(ws + off);
+            off += cpx_align_up((size_t)Mp * Np * 2, 256);
+            rc = cpx_gemm_bf16(colbuf, o.weight, Mp, Np, Kp, o.relu ? CPX_EPI_RELU_BF16 : CPX_EPI_BF16, o.bias, nullptr, dst, Np, stream);
+            if (rc) return rc;
+            tens[o.dst] = {dst, Np, o.cout, ho, wo};
+        } else {
+            const size_t rows = (size_t)nS * o.h * o.w;
+            const int Mp = up128(rows), Kp = up64(o.cin_a), Np = up128(4 * o.cout);
+            CPX_REQUIRE(o.src_b < 0);
+            const size_t n_chunks = rows * (Kp / 8);
+            hipLaunchKernelGGL(k_conv_gather, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, A.p, A.ld, o.cin_a,
+                               (const unsigned short *)nullptr, 0, 0, 3, o.h, o.w, rows, Kp, colbuf);
+            rc = cpx_gemm_bf16(colbuf, o.weight, Mp, Np, Kp, CPX_EPI_BF16, o.bias, nullptr, gbuf, Np, stream);
+            if (rc) return rc;
+            const bool last = i == n_ops - 1;
+            unsigned short *dst = (unsigned short *)(ws + off);
+            const int ldo = up128(o.cout);
+            if (!last) off += cpx_align_up((size_t)up128(rows * 4) * ldo * 2, 256);
+            const size_t n_thr = rows * 4 * (o.cout / 8);
+            if (f16) hipLaunchKernelGGL(k_depth2space<true>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, gbuf, Np, o.cout, o.h, o.w, rows, dst, ldo, last ? head : nullptr, ld_head, col0);
+            else hipLaunchKernelGGL(k_depth2space<false>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, gbuf, Np, o.cout, o.h, o.w, rows, dst, ldo, last ? head : nullptr, ld_head, col0);
+            tens[o.dst] = {dst, ldo, o.cout, o.h * 2, o.w * 2};
+        }
+    }
+    CPX_CHECK_LAUNCH();
     return CPX_OK;
 }

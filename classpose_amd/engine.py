@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CpxBlockWeights, CpxNetWeights, CpxRecord, CpxTiling, check, ptr
+from ._lib import CpxBlockWeights, CpxConvOp, CpxNetWeights, CpxRecord, CpxTiling, check, ptr
 
 PS = 8
 BSIZE = 256
@@ -121,9 +121,8 @@ class NetWeights:
         sd = {k.removeprefix("module."): v for k, v in sd.items()}
         hd = HALF_DTYPES[precision]
         fts, ncls, depth = cls.infer_structure(sd)
-        if fts is not None:
-            raise NotImplementedError("UNet semantic head (feature_transformation_structure) "
-                                      "is not yet built for the HIP engine")
+        if fts is not None and (any(c % 8 for c in fts) or len(fts) > 3):
+            raise NotImplementedError("UNet semantic head: channel counts must be multiples of 8, at most 3 levels")
         if sd["encoder.patch_embed.proj.weight"].shape != (1024, 3, 8, 8):
             raise ValueError("only the vit_l / ps=8 Cellpose-SAM backbone is supported")
         self = cls()
@@ -194,7 +193,10 @@ class NetWeights:
         c.neck_ln2_w, c.neck_ln2_b = vec(sd["encoder.neck.3.weight"]), vec(sd["encoder.neck.3.bias"])
         hw = [sd["out.weight"].reshape(192, 256)]
         hb = [sd["out.bias"]]
-        if ncls > 1:
+        if fts is not None:
+            hw.append(torch.zeros(ncls * 64, 256))       # class columns come from the UNet head below
+            hb.append(torch.zeros(ncls * 64))
+        elif ncls > 1:
             hw.append(sd["out_class.weight"].reshape(ncls * 64, 256))
             hb.append(sd["out_class.bias"])
         hw = torch.cat(hw, 0)
@@ -202,8 +204,73 @@ class NetWeights:
         padn = c.ld_head - hw.shape[0]
         c.head_w = half(torch.cat([hw, torch.zeros(padn, 256)], 0))
         c.head_b = vec(torch.cat([hb, torch.zeros(padn)], 0))
+        c.n_unet_ops = 0
+        if fts is not None:
+            self._build_unet_ops(sd, fts, ncls * 64, half, vec32)
         self.ncls, self.depth, self.precision, self.device = ncls, depth, precision, dev
+        self.fts = fts
         return self
+
+    def _build_unet_ops(self, sd, fts, out_ch, half, vec32):
+        """Flatten classpose.unet.UNet (unet.py:146-196) into the conv list of cpx_conv_op."""
+        hd = HALF_DTYPES["bf16" if self.c.dtype == 0 else "fp16"]
+        up = lambda x, m: (x + m - 1) // m * m
+        ops = []
+
+        def rounded(t):
+            return t.detach().to(hd).float()
+
+        def add(kind, src_a, src_b, cin_a, cin_b, cout, h, relu, wkey):
+            w, b = rounded(sd[wkey + ".weight"]), rounded(sd[wkey + ".bias"])
+            if kind == 2:       # ConvTranspose2d [cin][cout][2][2] -> rows (dy, dx, co), cols ci
+                wm = w.permute(2, 3, 1, 0).reshape(4 * cout, cin_a)
+                bm = b.repeat(4)
+            else:               # Conv2d [cout][cin][k][k] -> cols (ky, kx, ci)
+                wm = w.permute(0, 2, 3, 1).reshape(cout, -1)
+                bm = b
+            n_pad, k_pad = up(wm.shape[0], 128), up(wm.shape[1], 64)
+            wp = torch.zeros(n_pad, k_pad)
+            wp[: wm.shape[0], : wm.shape[1]] = wm
+            bp = torch.zeros(n_pad)
+            bp[: bm.shape[0]] = bm
+            op = CpxConvOp()
+            op.kind, op.src_a, op.src_b, op.dst = kind, src_a, src_b, len(ops) + 1
+            op.cin_a, op.cin_b, op.cout, op.h, op.w, op.relu = cin_a, cin_b, cout, h, h, int(relu)
+            op.weight, op.bias = half(wp), vec32(bp)
+            ops.append(op)
+            return op.dst
+
+        def block(pfx, src_a, src_b, cin_a, cin_b, cout, h, last_relu=True):
+            t = add(0, src_a, src_b, cin_a, cin_b, cout, h, True, pfx + "block.conv1")
+            return add(0, t, -1, cout, 0, cout, h, last_relu, pfx + "block.conv2")
+
+        cur, cin, h, feats = 0, 256, 32, []
+        for n, c in enumerate(fts):
+            p = f"out_class.encoder_blocks.{n}."
+            t = block(p, cur, -1, cin, 0, c, h)
+            cur = add(1, t, -1, c, 0, c, h, False, p + "downconv")
+            h //= 2
+            feats.append((cur, c))
+            cin = c
+        c = fts[-1]
+        t = block("out_class.bottleneck_down.", cur, -1, c, 0, c, h)
+        cur = add(1, t, -1, c, 0, c, h, False, "out_class.bottleneck_down.downconv")
+        h //= 2
+        t = block("out_class.bottleneck_up.", cur, -1, c, 0, c, h)
+        cur = add(2, t, -1, c, 0, c, h, False, "out_class.bottleneck_up.upconv")
+        h *= 2
+        seq = [*fts[::-1], out_ch]
+        feats = feats[::-1]
+        for i in range(len(fts)):
+            p = f"out_class.decoder_blocks.{i}."
+            fid, fc = feats[i]
+            t = block(p, cur, fid, seq[i], fc, seq[i + 1], h, last_relu=(i != len(fts) - 1))
+            cur = add(2, t, -1, seq[i + 1], 0, seq[i + 1], h, False, p + "upconv")
+            h *= 2
+        assert h == 32
+        self.unet_ops = (CpxConvOp * len(ops))(*ops)
+        self.c.n_unet_ops = len(ops)
+        self.c.unet_ops = C.cast(self.unet_ops, C.POINTER(CpxConvOp))
 
 
 # --------------------------------------------------------------------------
@@ -277,6 +344,9 @@ class Engine:
         hi = percentile_params(H * W, 99)
         self.pct = (lo[0], lo[1], hi[0], hi[1])
         self.net_ws_bytes = self.L.cpx_net_workspace_bytes(nT * self.n_sub)
+        if weights.c.n_unet_ops:
+            self.net_ws_bytes += self.L.cpx_unet_workspace_bytes(weights.c.unet_ops, weights.c.n_unet_ops,
+                                                                nT * self.n_sub)
         self.net_ws = torch.empty(self.net_ws_bytes, dtype=torch.uint8, device=d)
         self.taper = torch.from_numpy(taper_1d(BSIZE)).to(d)
         self.pp_ws_bytes = self.L.cpx_postproc_workspace_bytes(nT, H, W)

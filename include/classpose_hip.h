@@ -116,6 +116,21 @@ typedef struct cpx_block_weights {
     const float *qkv_colsum, *fc1_colsum;     /* [3072], [4096]               */
 } cpx_block_weights;
 
+/* Optional UNet semantic head (classpose/unet.py:121-196, chosen when the checkpoint has
+ * out_class.encoder_blocks.* keys, predict_wsi.py:1393-1405).  The host flattens it into a list
+ * of convolutions over token-major [sub-tile*h*w][C] half tensors; each runs as (im2col |
+ * space-to-depth | nothing) + the MFMA GEMM (+ depth-to-space for the transposed convs).    */
+typedef struct cpx_conv_op {
+    int kind;              /* 0: conv3x3 pad 1, 1: conv2x2 stride 2, 2: convT2x2 stride 2      */
+    int src_a, src_b;      /* tensor ids (src_b = -1: none; channel concat a|b); 0 = neck output */
+    int dst;               /* tensor id produced (> 0)                                         */
+    int cin_a, cin_b, cout;
+    int h, w;              /* INPUT spatial size per sub-tile                                  */
+    int relu;
+    const void *weight;    /* half [Npad][Kpad]; k = tap*(cin_a+cin_b)+c (kinds 0,1), n = tap*cout+co (kind 2) */
+    const float *bias;     /* [Npad]                                                           */
+} cpx_conv_op;
+
 typedef struct cpx_net_weights {
     int depth;              /* 24 for vit_l                                    */
     int ncls;               /* n_cell_classes (W3.shape[1])                    */
@@ -133,9 +148,16 @@ typedef struct cpx_net_weights {
     const float *neck_ln2_w, *neck_ln2_b;
     const void *head_w;     /* [ld_head][256] rows: out (192) then out_class   */
     const float *head_b;    /* [ld_head]                                       */
+    int n_unet_ops;         /* 0: 1x1-conv class head inside head_w; > 0: UNet head below      */
+    const cpx_conv_op *unet_ops;   /* HOST array; the last op writes the ncls*64 class columns  */
 } cpx_net_weights;
 
 size_t cpx_net_workspace_bytes(int n_subtiles);
+/* extra bytes (appended to the network workspace) when w->n_unet_ops > 0 */
+size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops_host, int n_ops, int n_subtiles);
+int cpx_unet_head_forward(const cpx_conv_op *ops_host, int n_ops, const void *feat, int n_subtiles,
+                          float *head, int ld_head, int col0, void *workspace, size_t workspace_bytes,
+                          void *stream);
 /* patches_bf16 [nS*1024][192] -> head [nS*1024][ld_head] float32.           */
 int cpx_net_forward(const cpx_net_weights *w_host, const void *patches_bf16, int n_subtiles,
                     float *head, void *workspace, size_t workspace_bytes, void *stream);

@@ -313,3 +313,42 @@ def test_net_forward_fused_vs_unfused_layernorm(cuda, fuse):
     ours = torch.cat([out[:, 3:], out[:, :3]], 1)
     ref32 = onet.class_transformer_forward(sd, torch.from_numpy(x[:2]))
     assert _rel(ours, ref32) < 2e-2, _rel(ours, ref32)
+
+
+@pytest.mark.parametrize("fts,nS", [([64, 128], 2), ([32], 1), ([64, 128], 8)])
+def test_unet_semantic_head_vs_oracle(cuda, fts, nS):
+    """feature_transformation_structure checkpoints: UNet head as conv list on the MFMA GEMM"""
+    sd = synth.make_state_dict(7, fts, depth=1, seed=11)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", cuda)
+    assert w.c.n_unet_ops == 3 * (2 * len(fts) + 2)
+    x = np.random.default_rng(2).random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5) \
+        .reshape(nS * 1024, 192).to(torch.bfloat16).to(cuda)
+    L = _lib.lib()
+    import ctypes as C
+    head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+    nbytes = L.cpx_net_workspace_bytes(nS) + L.cpx_unet_workspace_bytes(w.c.unet_ops, w.c.n_unet_ops, nS)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cuda)
+    _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), torch.cuda.current_stream().cuda_stream))
+    out = head[:, :640].reshape(nS, 32, 32, 10, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(nS, 10, 256, 256).cpu()
+    ours = torch.cat([out[:, 3:], out[:, :3]], 1)
+    ref32 = onet.class_transformer_forward(sd, torch.from_numpy(x))
+    assert _rel(ours[:, 7:], ref32[:, 7:]) < 2e-2           # flow head unchanged
+    assert _rel(ours[:, :7], ref32[:, :7]) < 2e-2, _rel(ours[:, :7], ref32[:, :7])   # UNet class logits
+
+
+def test_engine_with_unet_head(cuda):
+    from oracle import dynamics
+    sd = synth.make_state_dict(7, [64, 128], depth=1, seed=12)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", cuda)
+    eng = engine.Engine(w, 256, batch_tiles=2)
+    tiles = np.stack([synth.render_region(99, 0, 0, 256, 256), synth.render_region(99, 300, 300, 256, 256)])
+    out = eng.run(torch.from_numpy(tiles).to(cuda))
+    fw = onet.make_forward(sd)
+    for i in range(2):
+        dP, cp, yc = tiling.run_net(fw, tiling.normalize_img(tiles[i:i + 1]), batch_size=8)
+        assert _rel(out.logits[i].cpu(), torch.from_numpy(yc)) < 2e-2
+        assert _rel(out.dP[i].cpu(), torch.from_numpy(dP)) < 2e-2
+        ref = dynamics.compute_masks(out.dP[i].cpu().numpy(), out.cellprob[i].cpu().numpy())
+        assert np.array_equal(ops.masks_to_numpy(out.masks)[i], ref)
