@@ -95,7 +95,7 @@ def main():
     rank, world, local = parallel.init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))   # (dry runs may map 2 ranks to 1 GPU)
     torch.cuda.set_device(dev)
     L = _lib.lib()
 

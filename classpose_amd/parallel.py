@@ -29,7 +29,7 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CPX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -49,10 +49,15 @@ def barrier() -> None:
         dist.barrier()
 
 
+def _coll_device(device):
+    """gloo (CPU tests / single-GPU dry runs) moves collectives through host tensors."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def allreduce_max(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -60,7 +65,7 @@ def allreduce_max(value: float, device) -> float:
 def allreduce_sum(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -77,7 +82,9 @@ def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
     if not dist.is_initialized():
         return rec
     world = dist.get_world_size()
-    dev = rec.device
+    out_dev = rec.device
+    dev = _coll_device(rec.device)
+    rec = rec.to(dev)
     n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
     counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, n)
@@ -88,4 +95,4 @@ def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
     out = torch.empty((world * mx, width), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, padded)
     out = out.view(world, mx, width)
-    return torch.cat([out[r, : int(counts[r])] for r in range(world)], 0)
+    return torch.cat([out[r, : int(counts[r])] for r in range(world)], 0).to(out_dev)
