@@ -66,3 +66,29 @@ def test_classpose_model_eval_api(cuda):
     assert np.array_equal(masks[0], masks[1])                           # deterministic
     m1, f1, c1, s1 = model.eval(tile)
     assert np.array_equal(m1, masks[0]) and np.array_equal(c1, class_masks[0])
+
+
+def test_predict_wsi_cli_default_tile_1024(cuda, tmp_path, monkeypatch):
+    """the reference's DEFAULT geometry: --tile_size 1024 --overlap 64 (25 sub-tiles per tile)"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs = 2100, 1100                                   # 2 x 1 tiles at stride 960
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "puma", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.22&seed=5",
+        "--output_folder", str(tmp_path), "--device", "cuda:0"])
+    assert args.tile_size == 1024 and args.overlap == 64
+    predict_wsi.main(args)
+    cont = json.load(open(next(tmp_path.glob("*contours.geojson"))))
+    cx, cy, r, ident = synth.nuclei_in_region(5, 0, 0, 1984, 1024)
+    inner = (cx - r > 12) & (cx + r < 1984 - 12) & (cy - r > 12) & (cy + r < 1024 - 12)
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[inner], cy[inner]], 1))
+    assert np.all(d < 1.5) and len(np.unique(idx)) == inner.sum()
+    names = ["Apoptosis", "Tumor", "Endothelial", "Stroma", "Lymphocyte", "Histocyte", "Epithelial", "Melanophage", "Other"]
+    assert [cont["features"][j]["properties"]["classification"]["name"] for j in idx] == \
+        [names[int(i % np.uint64(9))] for i in ident[inner]]

@@ -184,3 +184,15 @@ def test_remove_border_instances_golden(cuda, golden):
             o1, o2 = ops.remove_border_instances(inst, cls)
             assert np.array_equal(o1.cpu().numpy()[0], exp[..., 0]), i
             assert np.array_equal(o2.cpu().numpy()[0], exp[..., 1]), i
+
+
+def test_compute_masks_maximum_tile_1024(cuda):
+    """the CLI's default tile (1024 x 1024): ~1300 cells, label tables of 95k entries"""
+    dP, cp, lg = _fields("noisy_discs", 1024, 1024, 21)
+    ref = dynamics.compute_masks(dP, cp)
+    m, cm, nlab = ops.compute_masks(torch.from_numpy(dP).to(cuda)[None], torch.from_numpy(cp).to(cuda)[None],
+                                    torch.from_numpy(lg).to(cuda)[None])
+    assert ref.max() > 500
+    assert np.array_equal(ops.masks_to_numpy(m)[0], ref)
+    cref_, _ = classmask.compute_class_masks(ref, lg)
+    assert np.array_equal(cm.cpu().numpy()[0], cref_.astype(np.uint8))
