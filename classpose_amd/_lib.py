@@ -65,6 +65,7 @@ SIGNATURES = {
     "cpx_last_error": (C.c_char_p, []),
     "cpx_normalize_stats_u8": (_i, [_p, _i, _i, _i, _i, _f, _i, _f, _p, _p, _p]),
     "cpx_normalize_apply_u8": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "cpx_resize_linear_u8": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "cpx_make_subtiles": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
     "cpx_make_subtiles_f32": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
     "cpx_blend_subtiles": (_i, [_p, _i, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),

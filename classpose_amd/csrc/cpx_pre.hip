@@ -9,6 +9,73 @@
 #define NTHR 256
 
 // ---------------------------------------------------------------------------
+// a3/f4 residual mpp rescale: cv2.resize(tile, (dw, dh), INTER_LINEAR) for 8UC3
+// ---------------------------------------------------------------------------
+// OpenCV's classic fixed-point bilinear (imgproc resize.cpp: resizeGeneric_ with
+// HResizeLinear<uchar,int,short,2048> + VResizeLinear<uchar,int,short,FixedPtCast>):
+// taps and 11-bit weights come from the float32 source coordinate
+// (dx+0.5)*scale-0.5, columns beyond the last source column collapse to one tap,
+// rows clamp; an exact 2x2 decimation is re-dispatched to INTER_AREA
+// ((a+b+c+d+2)>>2).  One thread per output pixel, 3 channels.
+__device__ __forceinline__ void cv_linear_tap(int d, double scale, int slen, bool clamp_weight,
+                                              int &s0, int &s1, int &w0, int &w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_weight) {             // horizontal: xmin / xmax handling zeroes the fraction
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= slen - 1) { f = 0.f; s = slen - 1; }
+    }
+    w0 = __float2int_rn((1.f - f) * 2048.f);
+    w1 = __float2int_rn(f * 2048.f);
+    s0 = min(max(s, 0), slen - 1);
+    s1 = min(max(s + 1, 0), slen - 1);
+}
+
+__global__ void k_resize_linear_u8(const uint8_t *__restrict__ src, int sh, int sw,
+                                   uint8_t *__restrict__ dst, int dh, int dw, double scale_x,
+                                   double scale_y, int area2) {
+    int p = blockIdx.x * NTHR + threadIdx.x;
+    if (p >= dh * dw) return;
+    int dy = p / dw, dx = p - dy * dw;
+    const uint8_t *s = src + (size_t)blockIdx.y * sh * sw * 3;
+    uint8_t *o = dst + ((size_t)blockIdx.y * dh * dw + p) * 3;
+    if (area2) {
+        const uint8_t *r0 = s + ((size_t)(2 * dy) * sw + 2 * dx) * 3, *r1 = r0 + (size_t)sw * 3;
+        for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((r0[c] + r0[3 + c] + r1[c] + r1[3 + c] + 2) >> 2);
+        return;
+    }
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    cv_linear_tap(dx, scale_x, sw, true, x0, x1, a0, a1);
+    cv_linear_tap(dy, scale_y, sh, false, y0, y1, b0, b1);
+    const uint8_t *r0 = s + (size_t)y0 * sw * 3, *r1 = s + (size_t)y1 * sw * 3;
+    for (int c = 0; c < 3; ++c) {
+        int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+        int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+        o[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+extern "C" int cpx_resize_linear_u8(const uint8_t *src, int nT, int sh, int sw, uint8_t *dst, int dh,
+                                    int dw, void *stream) {
+    CPX_REQUIRE(src && dst && nT > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0);
+    CPX_REQUIRE((long long)dh * dw < (1ll << 31) && (long long)sh * sw < (1ll << 31));
+    hipStream_t s = (hipStream_t)stream;
+    if (sh == dh && sw == dw) {
+        hipError_t e = hipMemcpyAsync(dst, src, (size_t)nT * sh * sw * 3, hipMemcpyDeviceToDevice, s);
+        CPX_REQUIRE(e == hipSuccess);
+        return CPX_OK;
+    }
+    // cv::resize: inv_scale = dsize/ssize in double, scale = 1/inv_scale
+    double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
+    int area2 = (sw == 2 * dw && sh == 2 * dh) ? 1 : 0;
+    hipLaunchKernelGGL(k_resize_linear_u8, dim3(cpx_cdiv((long long)dh * dw, NTHR), nT), dim3(NTHR), 0, s,
+                       src, sh, sw, dst, dh, dw, scale_x, scale_y, area2);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // a6 normalisation
 // ---------------------------------------------------------------------------
 __global__ void k_hist_u8(const uint8_t *__restrict__ tiles, int HW, uint32_t *__restrict__ hist) {

@@ -33,7 +33,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import engine, geojson, parallel, postprocess, wsi
+from .. import engine, geojson, ops, parallel, postprocess, wsi
 from ..log import get_logger
 from ..model_configs import DEFAULT_MODEL_CONFIGS, ModelConfig
 
@@ -137,12 +137,13 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         logger.info(f"Slide MPP: {plan.mpp}; model MPP: {model_config.mpp}; tiles: {len(plan.coords)}; "
                     f"slide dimensions: {plan.slide_dim}; tile {args.tile_size}/{args.overlap}")
     weights = engine.NetWeights.from_state_dict(sd, args.precision, device)
-    H = W = args.tile_size
+    R = plan.read_tile_size                                  # pixels read per tile side
+    H, W = ops.resized_shape(R, R, plan.resize_factor)       # what the network sees
     n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
     nT = max(1, max(args.batch_size, 32) // n_sub)
     eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
     mine = list(parallel.shard_indices(len(plan.coords), rank, world))
-    stream = TileStream(slide, plan, mine, nT, H, W, device)
+    stream = TileStream(slide, plan, mine, nT, R, R, device)
     pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
     futures = []
     scale = plan.prediction_to_slide_scale
@@ -151,12 +152,13 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     for chunk, tiles_dev, ev in stream:
         torch.cuda.current_stream(device).wait_event(ev)
         n = len(chunk)
+        tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
         inject = None
         if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
             # test / bench mode for synthetic slides with random weights: the dynamics consume
             # analytic fields of the procedural nuclei, the network still runs on the pixels
             from .. import synth
-            f = [synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], W, H, n_classes)
+            f = [synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R, n_classes, W, H)
                  for ti in chunk]
             inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
         out = eng.run(tiles_dev, inject=inject, records=True)

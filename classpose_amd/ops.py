@@ -62,6 +62,27 @@ def normalize_img(tiles_u8: torch.Tensor) -> torch.Tensor:
     return out if was else out[0]
 
 
+# ---- a3 -------------------------------------------------------------------
+def resized_shape(h: int, w: int, resize_factor: float) -> tuple[int, int]:
+    """Output (h, w) of resize_tile_to_target_mpp (predict_wsi.py:117-118)."""
+    return max(1, int(round(h * resize_factor))), max(1, int(round(w * resize_factor)))
+
+
+def resize_tile_to_target_mpp(tiles_u8: torch.Tensor, resize_factor: float,
+                              out: torch.Tensor | None = None) -> torch.Tensor:
+    """predict_wsi.resize_tile_to_target_mpp on uint8 (n,h,w,3) / (h,w,3) device tiles:
+    cv2.resize(..., INTER_LINEAR) to round(h*f) x round(w*f); factor 1.0 returns the input."""
+    if resize_factor == 1.0:
+        return tiles_u8
+    t, was = _batched(tiles_u8.contiguous(), 3)
+    dh, dw = resized_shape(t.shape[1], t.shape[2], resize_factor)
+    if out is None:
+        out = torch.empty((t.shape[0], dh, dw, 3), dtype=torch.uint8, device=t.device)
+    check(_lib.lib().cpx_resize_linear_u8(ptr(t), t.shape[0], t.shape[1], t.shape[2], ptr(out), dh, dw,
+                                          _stream(t.device)), "resize_linear_u8")
+    return out if was else out[0]
+
+
 # ---- a7 -------------------------------------------------------------------
 def make_subtiles(tiles_u8: torch.Tensor, bsize: int = 256, augment: bool = False,
                   tile_overlap: float = 0.1):

@@ -68,28 +68,30 @@ def nuclei_in_region(seed: int, x0: int, y0: int, w: int, h: int, margin: float 
     return cx[keep], cy[keep], r[keep], ident[keep]
 
 
-def _owner_map(seed, x0, y0, w, h):
-    """Per pixel: index of the nucleus containing the pixel centre, else -1."""
+def _owner_map(seed, x0, y0, w, h, out_w=None, out_h=None):
+    """Per sample: index of the nucleus containing the sample point, else -1.  Samples are
+    the pixel centres of the region, or (out_w x out_h given) the centres of the pixels of
+    the region rescaled to that size, in slide coordinates."""
     cx, cy, r, ident = nuclei_in_region(seed, x0, y0, w, h)
-    owner = np.full((h, w), -1, np.int64)
-    ys = np.arange(y0, y0 + h)[:, None].astype(np.float64)
-    xs = np.arange(x0, x0 + w)[None, :].astype(np.float64)
+    ow, oh = (w, h) if out_w is None else (out_w, out_h)
+    ys = (y0 + (np.arange(oh) + 0.5) * (h / oh) - 0.5)[:, None]
+    xs = (x0 + (np.arange(ow) + 0.5) * (w / ow) - 0.5)[None, :]
+    owner = np.full((oh, ow), -1, np.int64)
     for k in range(len(cx)):
-        ya = max(int(np.floor(cy[k] - r[k])) - y0, 0)
-        yb = min(int(np.ceil(cy[k] + r[k])) + 1 - y0, h)
-        xa = max(int(np.floor(cx[k] - r[k])) - x0, 0)
-        xb = min(int(np.ceil(cx[k] + r[k])) + 1 - x0, w)
+        ya, yb = np.searchsorted(ys[:, 0], [cy[k] - r[k], cy[k] + r[k]], side="left")
+        xa, xb = np.searchsorted(xs[0], [cx[k] - r[k], cx[k] + r[k]], side="left")
+        yb, xb = min(yb + 1, oh), min(xb + 1, ow)
         if ya >= yb or xa >= xb:
             continue
         d2 = (ys[ya:yb] - cy[k]) ** 2 + (xs[:, xa:xb] - cx[k]) ** 2
         sub = owner[ya:yb, xa:xb]
         sub[d2 <= r[k] ** 2] = k
-    return owner, cx, cy, r, ident
+    return owner, cx, cy, r, ident, ys, xs
 
 
 def render_region(seed: int, x0: int, y0: int, w: int, h: int) -> np.ndarray:
     """uint8 (h, w, 3) H&E-like pixels, pure function of absolute coordinates."""
-    owner, *_ = _owner_map(seed, x0, y0, w, h)
+    owner = _owner_map(seed, x0, y0, w, h)[0]
     base = np.where((owner >= 0)[..., None], FG, BG)
     ys = np.arange(y0, y0 + h, dtype=np.int64)[:, None, None] + (1 << 20)
     xs = np.arange(x0, x0 + w, dtype=np.int64)[None, :, None] + (1 << 20)
@@ -100,19 +102,21 @@ def render_region(seed: int, x0: int, y0: int, w: int, h: int) -> np.ndarray:
     return np.clip(np.rint(base + noise), 0, 255).astype(np.uint8)
 
 
-def analytic_fields(seed: int, x0: int, y0: int, w: int, h: int, n_classes: int):
+def analytic_fields(seed: int, x0: int, y0: int, w: int, h: int, n_classes: int,
+                    out_w: int | None = None, out_h: int | None = None):
     """Flow-injection tensors for the region, as the network would emit them.
 
     Returns dP (2,h,w) float32 [dY,dX] (x5 scale like the network output),
     cellprob (h,w) float32 (+6 inside, -6 outside), logits (n_classes,h,w)
     float32 (one-hot x4, class = id % (n_classes-1) + 1 inside, 0 outside) and
-    the number of nuclei whose discs lie fully inside the region.
+    the number of nuclei whose discs lie fully inside the region.  With out_w/out_h the
+    fields are sampled on the region rescaled to that size (slide mpp != model mpp).
     """
-    owner, cx, cy, r, ident = _owner_map(seed, x0, y0, w, h)
+    owner, cx, cy, r, ident, ys, xs = _owner_map(seed, x0, y0, w, h, out_w, out_h)
+    rw, rh = w, h
+    h, w = owner.shape
     inside = owner >= 0
     oc = np.where(inside, owner, 0)
-    ys = np.arange(y0, y0 + h)[:, None].astype(np.float64)
-    xs = np.arange(x0, x0 + w)[None, :].astype(np.float64)
     vy = np.where(inside, cy[oc] - ys, 0.0) if len(cx) else np.zeros((h, w))
     vx = np.where(inside, cx[oc] - xs, 0.0) if len(cx) else np.zeros((h, w))
     nrm = np.maximum(np.sqrt(vy * vy + vx * vx), 1.0)
@@ -126,7 +130,7 @@ def analytic_fields(seed: int, x0: int, y0: int, w: int, h: int, n_classes: int)
         cl_px = np.zeros((h, w), np.int64)
     for c in range(n_classes):
         logits[c][cl_px == c] = 4.0
-    full = (cx - r >= x0) & (cx + r <= x0 + w - 1) & (cy - r >= y0) & (cy + r <= y0 + h - 1)
+    full = (cx - r >= x0) & (cx + r <= x0 + rw - 1) & (cy - r >= y0) & (cy + r <= y0 + rh - 1)
     return dP, cellprob, logits, int(full.sum())
 
 

@@ -90,8 +90,10 @@ def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePl
     scale = min(train_mpp / mpp[0], train_mpp / mpp[1])
     level = slide.get_best_level_for_downsample(scale)
     dim = tuple(slide.level_dimensions[level])
-    ts = float(slide.level_downsamples[level])
-    resize_factor = ts / scale
+    # the reference keeps both in manager.Value("f", ...) slots, i.e. C floats
+    # (predict_wsi.py:184,191,245-246): every later use sees the float32-rounded value
+    ts = float(np.float32(slide.level_downsamples[level]))
+    resize_factor = float(np.float32(ts / scale))
     read_tile = max(1, round(tile_size / resize_factor))
     read_ov = max(0, round(overlap / resize_factor))
     return SlidePlan(mpp, bounds, scale, level, dim, ts, resize_factor, read_tile, read_ov,
@@ -99,12 +101,12 @@ def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePl
 
 
 def read_tile(slide, plan: SlidePlan, coords) -> np.ndarray:
-    """``fill_queue`` body for one tile: read_region -> drop alpha (uint8 H x W x 3)."""
+    """``fill_queue`` body for one tile up to the rescale: read_region -> drop alpha
+    (uint8 h x w x 3 at the pyramid level's resolution).  The residual rescale to the
+    model mpp (resize_tile_to_target_mpp) runs on the device after the H2D copy
+    (``ops.resize_tile_to_target_mpp``)."""
     (x0, y0), ts = coords
     tile = np.array(slide.read_region((x0, y0), plan.level, (ts, ts)))
     if tile.shape[-1] == 4:
         tile = tile[:, :, :3]
-    if plan.resize_factor != 1.0:
-        raise NotImplementedError("slide mpp != model mpp needs the INTER_LINEAR rescale "
-                                  "(SURVEY 8f4, next row); synthetic slides are rendered at model mpp")
     return np.ascontiguousarray(tile)

@@ -56,6 +56,19 @@ int cpx_normalize_apply_u8(const uint8_t *tiles_u8, const float *stats, int nT, 
                            float *out_f32, void *stream);
 
 /* ------------------------------------------------------------------------
+ * a3  residual rescale of a tile read from the pyramid level to the model mpp
+ * replaces resize_tile_to_target_mpp -> cv2.resize(tile, (dw, dh), INTER_LINEAR),
+ * /root/reference/src/classpose/entrypoints/predict_wsi.py:102-123 (and 462-483)
+ * ---------------------------------------------------------------------- */
+/* src_u8 [nT][sh][sw][3] -> dst_u8 [nT][dh][dw][3], OpenCV's 8-bit fixed-point
+ * bilinear (11-bit weights from the float32 source coordinate, exact 2x2
+ * decimation dispatched to the area average like cv::resize does).  Equal sizes
+ * copy.  The caller computes dw = max(1, round(sw * resize_factor)) as the
+ * reference does.                                                          */
+int cpx_resize_linear_u8(const uint8_t *src_u8, int nT, int sh, int sw,
+                         uint8_t *dst_u8, int dh, int dw, void *stream);
+
+/* ------------------------------------------------------------------------
  * a7  sub-tiling and taper blending
  * replaces transforms.get_pad_yx + np.pad + transforms.make_tiles in
  * core.run_net, /root/reference/src/classpose/core.py:129-178, and

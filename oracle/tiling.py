@@ -36,6 +36,45 @@ def get_coords(tile_size: int, overlap: int, slide_dim: tuple[int, int], ts: flo
 # --------------------------------------------------------------------------
 # a6: normalisation  (models.py:615-666 -> cellpose transforms.normalize_img)
 # --------------------------------------------------------------------------
+def resize_linear_u8(tile: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv2.resize(tile, (dw, dh), interpolation=cv2.INTER_LINEAR) for uint8 HxWx3
+    (/root/reference/src/classpose/entrypoints/predict_wsi.py:119-123).
+
+    OpenCV is a third-party dependency of the reference that is absent from this image
+    (opencv-python-headless 4.x in the reference's pyproject): this restates its published
+    8-bit algorithm (modules/imgproc/src/resize.cpp: resizeGeneric_ + HResizeLinear /
+    VResizeLinear with INTER_RESIZE_COEF_BITS = 11; exact 2x2 decimation -> INTER_AREA
+    fast path).  PARITY UNPINNED: no cv2 here to mint golden vectors against.
+    """
+    sh, sw = tile.shape[:2]
+    if (sh, sw) == (dh, dw):
+        return tile.copy()
+    if sw == 2 * dw and sh == 2 * dh:
+        t = tile.astype(np.int32)
+        return ((t[0::2, 0::2] + t[0::2, 1::2] + t[1::2, 0::2] + t[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+    def taps(dlen, slen, clamp_weight):
+        scale = 1.0 / (np.float64(dlen) / np.float64(slen))
+        f = ((np.arange(dlen, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        if clamp_weight:
+            lo = s < 0
+            f[lo], s[lo] = 0, 0
+            hi = s >= slen - 1
+            f[hi], s[hi] = 0, slen - 1
+        w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int32)
+        w1 = np.rint(f * np.float32(2048)).astype(np.int32)
+        return np.clip(s, 0, slen - 1), np.clip(s + 1, 0, slen - 1), w0, w1
+
+    x0, x1, a0, a1 = taps(dw, sw, True)
+    y0, y1, b0, b1 = taps(dh, sh, False)
+    t = tile.astype(np.int32)
+    hrow = t[:, x0] * a0[None, :, None] + t[:, x1] * a1[None, :, None]        # [sh][dw][3]
+    v = ((b0[:, None, None] * (hrow[y0] >> 4)) >> 16) + ((b1[:, None, None] * (hrow[y1] >> 4)) >> 16)
+    return ((v + 2) >> 2).astype(np.uint8)
+
+
 def normalize99(Y: np.ndarray, lower: float = 1, upper: float = 99) -> np.ndarray:
     """cellpose.transforms.normalize99 (copy=False semantics on a float32 view)."""
     X = Y

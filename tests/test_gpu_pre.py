@@ -77,3 +77,20 @@ def test_blend_subtiles_bit_exact(cuda, H, W, aug):
                                      .transpose(0, 2, 4, 1, 3, 5).reshape(nT * nsub, 1024, -1))
     dP2, cp2, lg2 = ops.blend_head(torch.from_numpy(head).to(cuda), ld, ncls, til, nT)
     assert torch.equal(dP2, dP) and torch.equal(cp2, cp) and torch.equal(lg2, lg)
+
+
+@pytest.mark.parametrize("shape,factor", [((427, 427), 0.6), ((512, 512), 0.5), ((300, 260), 0.486),
+                                          ((151, 200), 1.7), ((1024, 1024), 0.25), ((257, 255), 0.999),
+                                          ((64, 64), 1.0), ((2107, 2107), 0.486)])
+def test_resize_tile_to_target_mpp_bit_exact(cuda, shape, factor):
+    """device rescale == the oracle's restatement of cv2.resize INTER_LINEAR (8UC3), bit for bit"""
+    from oracle import tiling as otiling
+    rng = np.random.default_rng(hash((shape, factor)) % (1 << 31))
+    tiles = rng.integers(0, 256, (2,) + shape + (3,), dtype=np.uint8)
+    tiles[1] = synth.render_region(3, 11, 17, shape[1], shape[0])
+    got = ops.resize_tile_to_target_mpp(torch.from_numpy(tiles).to(cuda), factor).cpu().numpy()
+    dh, dw = ops.resized_shape(shape[0], shape[1], factor)
+    assert got.shape == (2, dh, dw, 3)
+    for k in range(2):
+        want = otiling.resize_linear_u8(tiles[k], dw, dh) if factor != 1.0 else tiles[k]
+        assert np.array_equal(got[k], want)

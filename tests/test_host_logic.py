@@ -95,3 +95,36 @@ def test_state_dict_layout_matches_infer_structure():
     assert (fts, ncls, depth) == ([64, 128], 10, 1)
     assert sd["W3"].shape == (640, 10, 8, 8)
     assert sd["encoder.blocks.0.attn.rel_pos_h"].shape == (27, 64)
+
+
+def test_oracle_resize_linear_properties():
+    """cv2.INTER_LINEAR restatement (unpinned: no cv2 here): identity, constant images,
+    the 2x2 area dispatch, monotone ramps within 1 LSB of real-valued bilinear"""
+    from oracle.tiling import resize_linear_u8
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, 256, (90, 70, 3), dtype=np.uint8)
+    assert np.array_equal(resize_linear_u8(t, 70, 90), t)
+    c = np.full((61, 47, 3), 201, np.uint8)
+    assert np.all(resize_linear_u8(c, 29, 33) == 201) and np.all(resize_linear_u8(c, 100, 120) == 201)
+    a = resize_linear_u8(t, 35, 45).astype(int)
+    blk = t.astype(int).reshape(45, 2, 35, 2, 3).sum((1, 3))
+    assert np.array_equal(a, (blk + 2) >> 2)
+    yy, xx = np.mgrid[0:100, 0:120]
+    ramp = np.stack([yy * 2, xx * 2, xx + yy], -1).astype(np.uint8)
+    o = resize_linear_u8(ramp, 77, 53).astype(float)
+    fy = np.clip((np.arange(53) + 0.5) * 100 / 53 - 0.5, 0, 99)[:, None]
+    fx = np.clip((np.arange(77) + 0.5) * 120 / 77 - 0.5, 0, 119)[None, :]
+    ref = np.stack([fy * 2 + 0 * fx, fx * 2 + 0 * fy, fx + fy], -1)
+    assert np.abs(o - ref).max() <= 1.0
+
+
+def test_plan_slide_rescaled():
+    """_init_slide arithmetic with slide mpp != model mpp (float32 shared values)"""
+    from classpose_amd import wsi
+    plan = wsi.plan_slide(wsi.WSIReader("synthetic://9000x7000?mpp=0.2431"), 1024, 64, 0.5)
+    scale = 0.5 / 0.2431
+    rf = float(np.float32(1.0 / scale))
+    assert plan.resize_factor == rf and plan.read_tile_size == round(1024 / rf) == 2106
+    assert plan.read_overlap == round(64 / rf)
+    assert max(1, int(round(plan.read_tile_size * rf))) == 1024
+    assert plan.coords[0] == ((0, 0), 2106) and plan.coords[1][0] == (0, 2106 - plan.read_overlap)
