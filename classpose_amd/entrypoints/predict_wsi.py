@@ -33,7 +33,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import engine, geojson, ops, parallel, postprocess, wsi
+from .. import engine, geojson, ops, parallel, postprocess, roi, wsi
 from ..log import get_logger
 from ..model_configs import DEFAULT_MODEL_CONFIGS, ModelConfig
 
@@ -136,43 +136,62 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     if rank == 0:
         logger.info(f"Slide MPP: {plan.mpp}; model MPP: {model_config.mpp}; tiles: {len(plan.coords)}; "
                     f"slide dimensions: {plan.slide_dim}; tile {args.tile_size}/{args.overlap}")
+    rois = None
+    if args.roi_geojson:
+        # ROI mode (predict_wsi.py:233-236,251-256,441-446): ROI-driven grid, tiles that miss
+        # every ROI are skipped; ROI tiles may be smaller than --tile_size (one engine per size)
+        rois = roi.load_roi_polygons(args.roi_geojson)
+        if rois is None:
+            raise ValueError(f"no polygons in {args.roi_geojson}")
+        if plan.bounds != (0.0, 0.0):
+            rois = [g.translate(*plan.bounds) for g in rois]
+        coords = roi.get_coords_roi(rois, plan.read_tile_size, plan.read_overlap, args.overlap, plan.ts)
+        plan.coords = [c for c in coords if roi.check_tile_in_cnts(c[0], c[1], plan.ts, rois)]
+        if rank == 0:
+            logger.info(f"Selecting tiles using ROI with {len(rois)} polygons: {len(plan.coords)} tiles")
+    plan.rois = rois
     weights = engine.NetWeights.from_state_dict(sd, args.precision, device)
-    R = plan.read_tile_size                                  # pixels read per tile side
-    H, W = ops.resized_shape(R, R, plan.resize_factor)       # what the network sees
-    n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
-    nT = max(1, max(args.batch_size, 32) // n_sub)
-    eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
     mine = list(parallel.shard_indices(len(plan.coords), rank, world))
-    stream = TileStream(slide, plan, mine, nT, R, R, device)
+    by_size: dict[int, list[int]] = {}
+    for ti in mine:
+        by_size.setdefault(plan.coords[ti][1], []).append(ti)
     pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
     futures = []
     scale = plan.prediction_to_slide_scale
     t0 = time.time()
     n_done = 0
-    for chunk, tiles_dev, ev in stream:
-        torch.cuda.current_stream(device).wait_event(ev)
-        n = len(chunk)
-        tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
-        inject = None
-        if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
-            # test / bench mode for synthetic slides with random weights: the dynamics consume
-            # analytic fields of the procedural nuclei, the network still runs on the pixels
-            from .. import synth
-            f = [synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R, n_classes, W, H)
-                 for ti in chunk]
-            inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
-        out = eng.run(tiles_dev, inject=inject, records=True)
-        masks = out.masks.cpu().numpy().view(np.uint16)          # D2H: 2 B / pixel
-        recs = eng.fetch_records(n, out)
-        if int(out.nlabels.max()) >= 65535:
-            raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
-        for k, ti in enumerate(chunk):
-            origin = plan.coords[ti][0]
-            futures.append(pool.submit(postprocess.polygonize_tile, masks[k].copy(),
-                                       recs[recs["tile"] == k], scale, origin))
-        n_done += n
-        if rank == 0 and (n_done // nT) % 20 == 0:
-            logger.info(f"Predicted tiles: {n_done}/{len(mine)} ({n_done / max(time.time() - t0, 1e-9):.1f} tiles/s/GPU)")
+    for R, idxs in by_size.items():                              # R: pixels read per tile side
+        H, W = ops.resized_shape(R, R, plan.resize_factor)       # what the network sees
+        n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
+        nT = max(1, max(args.batch_size, 32) // n_sub)
+        eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
+        stream = TileStream(slide, plan, idxs, nT, R, R, device)
+        for chunk, tiles_dev, ev in stream:
+            torch.cuda.current_stream(device).wait_event(ev)
+            n = len(chunk)
+            tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
+            inject = None
+            if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
+                # test / bench mode for synthetic slides with random weights: the dynamics consume
+                # analytic fields of the procedural nuclei, the network still runs on the pixels
+                from .. import synth
+                f = [synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R,
+                                           n_classes, W, H) for ti in chunk]
+                inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
+            out = eng.run(tiles_dev, inject=inject, records=True)
+            masks = out.masks.cpu().numpy().view(np.uint16)          # D2H: 2 B / pixel
+            recs = eng.fetch_records(n, out)
+            if int(out.nlabels.max()) >= 65535:
+                raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
+            for k, ti in enumerate(chunk):
+                origin = plan.coords[ti][0]
+                futures.append(pool.submit(postprocess.polygonize_tile, masks[k].copy(),
+                                           recs[recs["tile"] == k], scale, origin))
+            n_done += n
+            if rank == 0 and (n_done // nT) % 20 == 0:
+                logger.info(f"Predicted tiles: {n_done}/{len(mine)} "
+                            f"({n_done / max(time.time() - t0, 1e-9):.1f} tiles/s/GPU)")
+        del eng, stream
     cells_all, xy_all, n_invalid = [], [], 0
     for f in futures:
         cells, xy = f.result()
@@ -215,6 +234,10 @@ def write_outputs(args, cells, xy, labels, plan):
         return None
     polygons = geojson.deduplicate(polygons)
     logger.info(f"Number of cells after de-duplication: {len(polygons)}")
+    if getattr(plan, "rois", None):
+        logger.info("Filtering cells based on ROI contours")
+        polygons = roi.filter_cells_by_contours(polygons, plan.rois)
+        logger.info(f"Number of cells after filtering: {len(polygons)}")
     if args.min_area and args.min_area > 0:
         pass   # --min_area only applies to tissue polygons in the reference (predict_wsi.py:1948-1955)
     bx, by = plan.bounds
@@ -235,7 +258,7 @@ def write_outputs(args, cells, xy, labels, plan):
 
 
 def _check_unsupported(args):
-    for name in ("tissue_detection_model_path", "artefact_detection_model_path", "roi_geojson"):
+    for name in ("tissue_detection_model_path", "artefact_detection_model_path"):
         if getattr(args, name):
             raise NotImplementedError(f"--{name} is not built yet on the MI355X engine (SURVEY 8f next rows)")
     if args.filter_artefacts or args.output_type:

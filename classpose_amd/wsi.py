@@ -80,6 +80,7 @@ class SlidePlan:
     read_tile_size: int
     read_overlap: int
     coords: list
+    rois: list | None = None
 
 
 def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePlan:

@@ -132,3 +132,51 @@ def test_predict_wsi_cli_rescaled_slide(cuda, tmp_path, monkeypatch):
     rel = np.abs(areas[idx] - np.pi * r_in ** 2) / (np.pi * r_in ** 2)
     # (vertices run through boundary pixel centres: ~1/r of the disc is lost; unscaled areas would be off by 0.46)
     assert np.median(rel) < 0.3, np.median(rel)
+
+
+def test_predict_wsi_cli_roi(cuda, tmp_path, monkeypatch):
+    """--roi_geojson: ROI-driven tile grid (300 px tiles here), tiles outside skipped, cells kept
+    only when their centroid is inside an ROI"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    rois = [[[400, 300], [1000, 300], [1000, 600], [400, 600], [400, 300]],                 # 600 x 300
+            [[1200, 900], [1500, 900], [1500, 1300], [1350, 1400], [1200, 1300], [1200, 900]]]
+    roi_path = tmp_path / "roi.geojson"
+    roi_path.write_text(json.dumps({"type": "FeatureCollection", "features": [
+        {"type": "Feature", "geometry": {"type": "Polygon", "coordinates": [r]}, "properties": {}} for r in rois]}))
+    out = tmp_path / "out"
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "conic", "--slide_path", "synthetic://2000x1600?mpp=0.5&seed=21",
+        "--output_folder", str(out), "--tile_size", "512", "--overlap", "64", "--device", "cuda:0",
+        "--roi_geojson", str(roi_path)])
+    predict_wsi.main(args)
+    cont = json.load(open(next(out.glob("*contours.geojson"))))
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    from classpose_amd import roi
+    polys = [roi.RoiPolygon(r) for r in rois]
+    assert all(any(p.contains_point_strict(x, y) for p in polys) for x, y in found)
+    cx, cy, r, ident = synth.nuclei_in_region(21, 0, 0, 2000, 1600)
+    # nuclei whose whole disc is inside an ROI must all be there, once
+    def disc_inside(p, x, y, rad):
+        return all(p.contains_point_strict(x + dx * (rad + 1.5), y + dy * (rad + 1.5))
+                   for dx, dy in [(1, 0), (-1, 0), (0, 1), (0, -1), (.7, .7), (-.7, .7), (.7, -.7), (-.7, -.7)])
+    inner = np.array([any(disc_inside(p, x, y, rr) for p in polys) for x, y, rr in zip(cx, cy, r)])
+    assert inner.sum() > 150
+    # the pulled-back last row/column of an ROI grid overlaps its neighbour heavily, so a nucleus
+    # can be detected 4-6 times with identical area; the reference's greedy de-duplication
+    # (predict_wsi.py:931-960, mirrored verbatim) can then drop EVERY copy.  Nuclei seen by at most
+    # three tiles never hit that quirk and must be there exactly once.
+    tiles = roi.get_coords_roi(polys, 512, 64, 64, 1.0)
+    copies = sum(((cx + r >= x0) & (cx - r <= x0 + s) & (cy + r >= y0) & (cy - r <= y0 + s)).astype(int)
+                 for (x0, y0), s in tiles)
+    safe = inner & (copies <= 3)
+    assert safe.sum() > 100
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[safe], cy[safe]], 1))
+    assert np.all(d < 1.5) and len(np.unique(idx)) == safe.sum()
+    counts = cKDTree(found).query_ball_point(np.stack([cx[inner], cy[inner]], 1), 7.5, return_length=True)
+    assert np.all(counts <= 1) and (counts == 1).mean() > 0.9

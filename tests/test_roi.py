@@ -1,0 +1,110 @@
+"""Host ROI geometry (classpose_amd.roi): predicates, ROI tile grid, cell filter.
+
+The reference computes these with shapely (absent here): the expectations below are
+hand-derived from the definitions of intersects / within / intersection length."""
+import json
+
+import numpy as np
+import pytest
+
+from classpose_amd import roi
+
+
+def _square(x0, y0, s):
+    return [[x0, y0], [x0 + s, y0], [x0 + s, y0 + s], [x0, y0 + s], [x0, y0]]
+
+
+L_SHAPE = [[0, 0], [100, 0], [100, 40], [40, 40], [40, 100], [0, 100]]
+
+
+def test_locate_and_within():
+    p = roi.RoiPolygon(_square(10, 10, 80), holes=[_square(40, 40, 20)])
+    assert p.locate(20, 20) == 1 and p.locate(50, 50) == -1 and p.locate(5, 50) == -1
+    assert p.locate(10, 30) == 0 and p.locate(40, 45) == 0 and p.locate(90, 90) == 0
+    assert p.contains_point_strict(39.9, 50) and not p.contains_point_strict(40, 50)
+    assert abs(p.area - (6400 - 400)) < 1e-9
+    q = roi.RoiPolygon(L_SHAPE)
+    assert q.locate(20, 80) == 1 and q.locate(80, 80) == -1 and q.locate(40, 40) == 0 and q.locate(70, 40) == 0
+
+
+def test_intersects_square_closed_semantics():
+    p = roi.RoiPolygon(_square(10, 10, 80), holes=[_square(40, 40, 20)])
+    assert p.intersects_square(0, 0, 10)            # touches at the corner (10, 10): closed sets intersect
+    assert not p.intersects_square(0, 0, 9.99)
+    assert p.intersects_square(-50, -50, 500)       # square contains the polygon
+    assert p.intersects_square(20, 20, 5)           # square inside the polygon
+    assert not p.intersects_square(45, 45, 10)      # square strictly inside the hole
+    assert p.intersects_square(45, 45, 15)          # reaches the hole's boundary
+    assert p.intersects_square(85, 50, 30) and not p.intersects_square(91, 50, 30)
+    q = roi.RoiPolygon(L_SHAPE)
+    assert not q.intersects_square(50, 50, 40) and q.intersects_square(30, 30, 40)
+
+
+def test_chords_and_maximum_lengths():
+    q = roi.RoiPolygon(L_SHAPE)
+    assert q.chord_lengths(20.0, 0) == [100.0] and q.chord_lengths(70.0, 0) == [40.0]
+    assert q.chord_lengths(0.0, 0) == [100.0]               # collinear boundary edge counts (closed polygon)
+    assert q.chord_lengths(100.0, 0) == [40.0]
+    p = roi.RoiPolygon(_square(0, 0, 90), holes=[_square(30, 30, 30)])
+    assert p.chord_lengths(45.0, 1) == [30.0, 30.0]          # split by the hole
+    assert roi.get_maximum_lengths(q) == (100.0, 100.0)
+    r = roi.RoiPolygon([[0, 0], [600, 0], [600, 300], [0, 300]])
+    assert roi.get_maximum_lengths(r) == (300.0, 600.0)
+
+
+def test_invalid_ring_raises():
+    with pytest.raises(ValueError):
+        roi.RoiPolygon([[0, 0], [10, 10], [10, 0], [0, 10]])    # bow tie
+    with pytest.raises(ValueError):
+        roi.RoiPolygon([[0, 0], [1, 1]])
+
+
+def test_get_coords_roi_hand_derived():
+    """600 x 300 ROI at (1000, 2000), ts=1, read tile 512 / overlap 64, model overlap 64:
+    box padded by 32 -> x in [968, 1632), y in [1968, 2332); narrowest max chord 300 ->
+    cts = 300; stride 236; last row/column pulled back to cmax - cts"""
+    r = roi.RoiPolygon([[1000, 2000], [1600, 2000], [1600, 2300], [1000, 2300]])
+    got = roi.get_coords_roi([r], 512, 64, 64, 1.0)
+    xs = [968, 968 + 236, 1632 - 300]
+    ys = [1968, 2332 - 300]
+    assert got == [((x, y), 300) for x in xs for y in ys]
+    assert all(roi.check_tile_in_cnts(c, s, 1.0, [r]) for c, s in got)
+    # tiny ROI -> MIN_TILE_SIZE; huge ROI -> tile_size; downsampled level scales coordinates
+    small = roi.RoiPolygon(_square(500, 500, 40))
+    (c0, s0), = roi.get_coords_roi([small], 512, 64, 64, 1.0)[:1]
+    assert s0 == 256 and c0 == (572 - 256, 572 - 256)      # box 468..572 is narrower than the tile: pulled back
+    big = roi.RoiPolygon(_square(0, 0, 4000))
+    got = roi.get_coords_roi([big], 512, 64, 64, 2.0)
+    assert got[0] == ((-64, -64), 512) and got[1][0] == (-64, int((-32 + 448) * 2.0))
+
+
+def test_load_roi_polygons_and_filter(tmp_path):
+    fc = {"type": "FeatureCollection", "features": [
+        {"type": "Feature", "geometry": {"type": "Polygon", "coordinates": [_square(0, 0, 100)]},
+         "properties": {"classification": {"name": "tumour"}}},
+        {"type": "Feature", "geometry": {"type": "MultiPolygon",
+                                         "coordinates": [[_square(50, 50, 100)], [_square(300, 300, 10)]]},
+         "properties": {}},
+        {"type": "Feature", "geometry": {"type": "LineString", "coordinates": [[400, 400], [420, 400], [410, 420]]},
+         "properties": {}},
+        {"type": "Feature", "geometry": None, "properties": {}}]}
+    path = tmp_path / "roi.geojson"
+    path.write_text(json.dumps(fc))
+    polys, by_class = roi.load_roi_polygons(str(path), group_by_class=True)
+    assert len(polys) == 4 and sorted(by_class) == ["tumour", "unknown"] and len(by_class["unknown"]) == 3
+    path2 = tmp_path / "single.geojson"
+    path2.write_text(json.dumps(fc["features"][0]))
+    assert len(roi.load_roi_polygons(str(path2))) == 1
+    empty = tmp_path / "empty.geojson"
+    empty.write_text(json.dumps({"type": "FeatureCollection", "features": []}))
+    assert roi.load_roi_polygons(str(empty)) is None
+
+    def cell(x, y):
+        return {"properties": {"measurements": [{"name": "area", "value": 1.0}, {"name": "centroidX", "value": x},
+                                                {"name": "centroidY", "value": y}]}}
+    cells = [cell(10, 10), cell(75, 75), cell(200, 200), cell(100, 20), cell(305, 305), cell(410, 405)]
+    kept = roi.filter_cells_by_contours(cells, polys)
+    # (75,75) lies in two overlapping ROIs -> returned twice, like STRtree.query(..., "within");
+    # (100,20) is on a boundary -> not within; (200,200) is outside everything
+    assert [roi.get_cell_centroid(c) for c in kept] == [[10, 10], [75, 75], [75, 75], [305, 305], [410, 405]]
+    assert roi.filter_cells_by_contours(cells, []) == cells
