@@ -35,6 +35,16 @@ class CpxConvOp(C.Structure):
                 ("relu", C.c_int), ("weight", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class CpxQcOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("act", C.c_int),
+                ("h_in", C.c_int), ("w_in", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int),
+                ("src_a", C.c_size_t), ("src_b", C.c_size_t), ("gate", C.c_size_t), ("res", C.c_size_t),
+                ("dst", C.c_size_t),
+                ("c_a", C.c_int), ("ld_a", C.c_int), ("up_a", C.c_int), ("c_b", C.c_int), ("ld_b", C.c_int),
+                ("ld_res", C.c_int), ("c_out", C.c_int), ("ld_dst", C.c_int), ("c_red", C.c_int),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p)]
+
+
 class CpxNetWeights(C.Structure):
     _fields_ = [("depth", C.c_int), ("ncls", C.c_int), ("n_head_cols", C.c_int),
                 ("ld_head", C.c_int), ("dtype", C.c_int), ("fuse_ln", C.c_int),
@@ -70,6 +80,7 @@ SIGNATURES = {
     "cpx_make_subtiles_f32": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
     "cpx_blend_subtiles": (_i, [_p, _i, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
     "cpx_blend_subtiles_nchw": (_i, [_p, _p, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
+    "cpx_qc_forward": (_i, [C.POINTER(CpxQcOp), _i, _p, _i, _i, _i, _sz, _sz, _i, _i, _p, _p, _p, _sz, _p]),
     "cpx_net_workspace_bytes": (_sz, [_i]),
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
     "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i]),

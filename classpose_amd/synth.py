@@ -269,3 +269,31 @@ def make_state_dict(n_classes: int = 7, fts: list[int] | None = None, depth: int
         convT("out_class.bottleneck_up.upconv", c, c, 2)
     sd["W3"] = torch.eye(oc).reshape(oc, n_classes, 8, 8)
     return sd
+
+
+def make_grandqc_state_dict(n_classes: int = 2, seed: int = 0):
+    """Seeded random UNet++/EfficientNet-B0 state dict with the key layout smp/timm produce
+    (``classpose_amd.qc_arch.expected_shapes``): He-style conv scales, BatchNorm statistics near
+    identity, so activations stay O(1) through the ~100 layers."""
+    import torch
+    from . import qc_arch
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shape in qc_arch.expected_shapes(n_classes).items():
+        leaf = k.rsplit(".", 1)[1]
+        if leaf == "running_var":
+            sd[k] = 0.8 + 0.4 * torch.rand(shape, generator=g)
+        elif leaf == "running_mean":
+            sd[k] = 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1 and leaf == "weight":                 # BN gamma
+            sd[k] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:                                      # BN beta / conv bias
+            sd[k] = 0.1 * torch.randn(shape, generator=g)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            sd[k] = torch.randn(shape, generator=g) * (1.6 / fan_in) ** 0.5
+    # tensors real checkpoints carry but the forward pass never reads
+    sd["encoder.conv_head.weight"] = torch.zeros(1280, 320, 1, 1)
+    for n in ("weight", "bias", "running_mean", "running_var"):
+        sd["encoder.bn2." + n] = torch.ones(1280)
+    return sd

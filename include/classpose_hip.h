@@ -175,6 +175,39 @@ int cpx_unet_head_forward(const cpx_conv_op *ops_host, int n_ops, const void *fe
 int cpx_net_forward(const cpx_net_weights *w_host, const void *patches_bf16, int n_subtiles,
                     float *head, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------
+ * a20  GrandQC tissue / artefact networks: UNet++ decoder on an EfficientNet-B0 encoder
+ * replaces model.predict(x_tensor) + np.argmax in detect_tissue_wsi / detect_artefacts_wsi,
+ * /root/reference/src/classpose/grandqc/wsi_tissue_detection.py:153-158 and
+ * wsi_artefact_detection.py:190-195 (smp.UnetPlusPlus("timm-efficientnet-b0"), float32)
+ * ---------------------------------------------------------------------- */
+/* The host flattens the network into float32 NHWC operations over one workspace (BatchNorm
+ * folded into weights/bias; byte offsets, (size_t)-1 = none).
+ *  kind 0  dense k x k convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32.  Input
+ *          channels = source A (c_a channels, row stride ld_a floats, read through a nearest
+ *          x2 upsample if up_a, scaled by gate[n][c] if gate) followed by source B (c_b, ld_b;
+ *          the UNet++ concat buffer slice).  w [c_out rounded up to 32|64][k*k][pad16(c_a)+pad16(c_b)],
+ *          bias [same rounding]; out = act(acc + bias) (+ res) -> dst with row stride ld_dst.
+ *  kind 1  depthwise k x k convolution over source A; w [k*k][c_a], bias [c_a]; dst stride c_a.
+ *  kind 2  squeeze-excite gate of source A: dst [nB][c_a] = sigmoid(w2 silu(w mean + bias) + bias2),
+ *          w [c_red][c_a], w2 [c_a][c_red]; res = scratch of 16*nB*c_a floats.
+ * h_in/w_in are the LOGICAL input grid (after the upsample).  act: 0 none, 1 ReLU, 2 SiLU.   */
+typedef struct cpx_qc_op {
+    int kind, k, stride, pad, act;
+    int h_in, w_in, h_out, w_out;
+    size_t src_a, src_b, gate, res, dst;
+    int c_a, ld_a, up_a, c_b, ld_b, ld_res, c_out, ld_dst, c_red;
+    const float *w, *bias, *w2, *bias2;
+} cpx_qc_op;
+/* patches_u8 [nB][H][W][3] (H, W multiples of 32) -> ImageNet preprocessing into
+ * workspace+input_off ([nB][H][W][4] float, 4th channel 0) -> ops -> argmax of the first
+ * n_classes floats of each ld_logits-wide row at workspace+logits_off -> class_map int8
+ * [nB][H][W] (first maximum wins, like np.argmax); logits_out (optional) [nB][H][W][n_classes]. */
+int cpx_qc_forward(const cpx_qc_op *ops_host, int n_ops, const uint8_t *patches_u8, int nB, int H, int W,
+                   size_t input_off, size_t logits_off, int n_classes, int ld_logits,
+                   int8_t *class_map, float *logits_out, void *workspace, size_t workspace_bytes,
+                   void *stream);
+
 /* Building blocks (exposed for parity tests / rooflines).
  * C[M][N] = A[M][K] * W[N][K]^T (+epilogue).  M%128==0, N%128==0, K%64==0.    */
 #define CPX_EPI_BF16 0            /* out bf16 = acc (+bias if bias)            */
