@@ -185,3 +185,103 @@ extern "C" int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, con
     }
     return used;
 }
+
+// ---------------------------------------------------------------------------------------------
+// cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_SIMPLE) for the GrandQC tissue / artefact maps
+// (/root/reference/src/classpose/grandqc/wsi_tissue_detection.py:209-213,
+//  wsi_artefact_detection.py:262-265): Suzuki-Abe raster scan with border marking (outer border
+// where a 1 follows a 0, hole border where a 0 follows a positive pixel), every border followed
+// once with the 8-direction rule above and stored with the CHAIN_APPROX_SIMPLE vertex rule.
+// Two-level hierarchy: parent[i] = index of the outer border of the component a hole border
+// belongs to, -1 for outer borders.  Contours come out in discovery (raster) order; OpenCV's own
+// ordering of the list is not reproduced (the reference only iterates over it).
+// ---------------------------------------------------------------------------------------------
+namespace {
+void trace_marked(std::vector<int32_t> &f, int PW, int sx, int sy, bool is_hole, int32_t nbd, std::vector<Pt> &out) {
+    auto at = [&](int x, int y) -> int32_t & { return f[(size_t)y * PW + x]; };
+    int s_end = is_hole ? 0 : 4, s = s_end;
+    int x1 = 0, y1 = 0;
+    do {
+        s = (s - 1) & 7;
+        x1 = sx + DX[s]; y1 = sy + DY[s];
+    } while (at(x1, y1) == 0 && s != s_end);
+    Pt pt{sx, sy};
+    if (s == s_end) { at(sx, sy) = -nbd; out.push_back(pt); return; }   // isolated pixel
+    int x3 = sx, y3 = sy, prev_s = s ^ 4;
+    for (;;) {
+        s_end = s;
+        int x4 = 0, y4 = 0;
+        for (;;) {
+            ++s;
+            x4 = x3 + DX[s & 7]; y4 = y3 + DY[s & 7];
+            if (at(x4, y4) != 0) break;
+            if (s >= 15) break;
+        }
+        s &= 7;
+        // the east neighbour was examined and found empty on this visit -> right edge of this border
+        if ((unsigned)(s - 1) < (unsigned)s_end) at(x3, y3) = -nbd;
+        else if (at(x3, y3) == 1) at(x3, y3) = nbd;
+        if (s != prev_s) { out.push_back(pt); prev_s = s; }
+        pt.x += DX[s]; pt.y += DY[s];
+        if (x4 == sx && y4 == sy && x3 == x1 && y3 == y1) break;
+        x3 = x4; y3 = y4;
+        s = (s + 4) & 7;
+    }
+}
+}  // namespace
+
+// mask [H][W] uint8 (non-zero = foreground).  Vertices (x, y int32 pairs, image coordinates) go to
+// xy_pool, contour c is xy_pool[offsets[c] .. offsets[c] + n_pts[c]).  Returns the number of contours
+// (>= 0), CPX_ENOMEM if max_pts / max_contours are too small.
+extern "C" int cpx_find_contours_ccomp_host(const uint8_t *mask, int H, int W, int32_t *xy_pool, int max_pts,
+                                            int32_t *offsets, int32_t *n_pts, int32_t *parent, int max_contours) {
+    if (!mask || !xy_pool || !offsets || !n_pts || !parent || H <= 0 || W <= 0) return CPX_EINVAL;
+    const int PW = W + 2, PH = H + 2;
+    std::vector<int32_t> f((size_t)PW * PH, 0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) f[(size_t)(y + 1) * PW + x + 1] = mask[(size_t)y * W + x] ? 1 : 0;
+    // 8-connected components -> the outer border that owns each component
+    std::vector<int32_t> comp(f.size(), 0);
+    std::vector<int> stack;
+    int ncomp = 0;
+    for (int y = 1; y <= H; ++y)
+        for (int x = 1; x <= W; ++x) {
+            const size_t i0 = (size_t)y * PW + x;
+            if (!f[i0] || comp[i0]) continue;
+            ++ncomp;
+            comp[i0] = ncomp; stack.clear(); stack.push_back((int)i0);
+            while (!stack.empty()) {
+                const int i = stack.back(); stack.pop_back();
+                const int yy = i / PW, xx = i % PW;
+                for (int k = 0; k < 8; ++k) {
+                    const size_t j = (size_t)(yy + DY[k]) * PW + xx + DX[k];
+                    if (f[j] && !comp[j]) { comp[j] = ncomp; stack.push_back((int)j); }
+                }
+            }
+        }
+    std::vector<int32_t> outer_of(ncomp + 1, -1);
+    std::vector<Pt> pts;
+    int nc = 0, used = 0;
+    int32_t nbd = 1;
+    for (int y = 1; y <= H; ++y) {
+        for (int x = 1; x <= W; ++x) {
+            const int32_t p = f[(size_t)y * PW + x];
+            if (p == 0) continue;
+            const bool outer = (p == 1 && f[(size_t)y * PW + x - 1] == 0);
+            const bool hole = (!outer && p >= 1 && f[(size_t)y * PW + x + 1] == 0);
+            if (!outer && !hole) continue;
+            if (nc >= max_contours) return CPX_ENOMEM;
+            ++nbd;
+            pts.clear();
+            trace_marked(f, PW, x, y, hole, nbd, pts);
+            if (used + (int)pts.size() > max_pts) return CPX_ENOMEM;
+            offsets[nc] = used; n_pts[nc] = (int32_t)pts.size();
+            for (const Pt &q : pts) { xy_pool[2 * (size_t)used] = q.x - 1; xy_pool[2 * (size_t)used + 1] = q.y - 1; ++used; }
+            const int32_t c = comp[(size_t)y * PW + x];
+            if (outer) { parent[nc] = -1; outer_of[c] = nc; }
+            else parent[nc] = outer_of[c];
+            ++nc;
+        }
+    }
+    return nc;
+}

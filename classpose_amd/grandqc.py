@@ -257,3 +257,389 @@ class QcNet:
                                         ptr(logits) if logits is not None else None, ptr(pl["ws"]), pl["ws_bytes"],
                                         torch.cuda.current_stream(self.device).cuda_stream), "qc_forward")
         return (cls, logits) if return_logits else cls
+
+
+# =============================================================================================
+# host pipeline
+# =============================================================================================
+import io
+import os
+import pickle
+import uuid
+
+from .log import get_logger
+
+grandqc_logger = get_logger("classpose.grandqc")
+
+ARTIFACT_COLORS = [[0, 0, 0], [0, 0, 0], [255, 99, 71], [0, 255, 0], [255, 0, 0], [255, 0, 255], [75, 0, 130],
+                   [255, 255, 255]]
+ARTIFACT_CLASS_MAPPING = {0: "Unused", 1: "Normal Tissue", 2: "Fold", 3: "Darkspot & Foreign Object",
+                          4: "PenMarking", 5: "Edge & Air Bubble", 6: "OOF", 7: "Background"}
+QC_BATCH = 8
+
+
+# ---- checkpoints ------------------------------------------------------------------------------
+class _Stub:
+    """Stand-in for smp / timm classes of a pickled module: keeps the instance state only."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {})
+
+
+class _StateOnlyUnpickler(pickle.Unpickler):
+    """Resolves torch / collections / builtins normally and every other class to ``_Stub``: a
+    pickled ``nn.Module`` tree (``torch.save(model)``, wsi_artefact_detection.py:124) can be read
+    for its tensors without importing -- or executing -- the packages that defined it."""
+    SAFE_PREFIXES = ("torch", "collections", "numpy", "_codecs")
+    SAFE_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes",
+                     "bytearray", "complex", "slice", "range", "object", "getattr"}
+
+    def find_class(self, module, name):
+        root = module.split(".")[0]
+        if root in self.SAFE_PREFIXES:
+            return super().find_class(module, name)
+        if module == "builtins":
+            if name in self.SAFE_BUILTINS:
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"refusing builtins.{name} in a model checkpoint")
+        if root in ("copyreg", "functools"):
+            return super().find_class(module, name)
+        return type(name, (_Stub,), {"__module__": module})
+
+
+class _StatePickle:
+    __name__ = "classpose_amd_state_pickle"
+    Unpickler = _StateOnlyUnpickler
+
+    @staticmethod
+    def load(f, **kw):
+        return _StateOnlyUnpickler(f, **kw).load()
+
+
+def _module_tree_to_state_dict(obj, prefix: str = "", out: dict | None = None) -> dict:
+    out = {} if out is None else out
+    d = getattr(obj, "__dict__", {})
+    for name, p in (d.get("_parameters") or {}).items():
+        if p is not None:
+            out[prefix + name] = p.detach()
+    for name, b in (d.get("_buffers") or {}).items():
+        if b is not None:
+            out[prefix + name] = b.detach()
+    for name, m in (d.get("_modules") or {}).items():
+        if m is not None:
+            _module_tree_to_state_dict(m, prefix + name + ".", out)
+    return out
+
+
+def load_qc_state_dict(path: str, n_classes: int, seed: int) -> dict:
+    """Tissue model: ``torch.save(state_dict)``; artefact model: a pickled smp module.  Both come
+    back as a flat state dict with smp's key names.  Without the file (no network here) seeded
+    synthetic weights are used when CLASSPOSE_SYNTHETIC_WEIGHTS=1, else FileNotFoundError."""
+    if not os.path.exists(path):
+        if os.getenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "0") == "1":
+            from . import synth
+            grandqc_logger.warning(f"No weights at {path}: using seeded synthetic GrandQC weights")
+            return synth.make_grandqc_state_dict(n_classes, seed)
+        raise FileNotFoundError(f"{path} not found (downloads are not available: fetch the GrandQC checkpoint "
+                                "manually, see the reference's MODEL_URL_PATH)")
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_StatePickle)
+    if isinstance(obj, dict):
+        sd = obj.get("state_dict", obj)
+        return {k: v for k, v in sd.items() if torch.is_tensor(v)}
+    return _module_tree_to_state_dict(obj)
+
+
+# ---- helpers (wsi_qc_helpers.py) ----------------------------------------------------------------
+def simulate_jpeg_compression(image: np.ndarray) -> np.ndarray:
+    """JPEG quality-80 round trip (wsi_qc_helpers.py:7-23).  The reference hands the RGB array to
+    ``cv2.imencode``, which reads it as BGR: the codec sees red and blue swapped.  PIL (libjpeg,
+    4:2:0, same quality scaling) stands in for OpenCV's codec, with the same channel swap."""
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(image[..., ::-1])).save(buf, format="JPEG", quality=80)
+    buf.seek(0)
+    return np.ascontiguousarray(np.asarray(Image.open(buf).convert("RGB"))[..., ::-1])
+
+
+def extract_slide_info(slide, mpp_model: float):
+    from .wsi import get_slide_resolution
+    w_l0, h_l0 = slide.level_dimensions[0]
+    mpp = get_slide_resolution(slide)[0]
+    reduction_factor = mpp_model / mpp
+    return w_l0, h_l0, mpp, (int(w_l0 // reduction_factor), int(h_l0 // reduction_factor))
+
+
+def _thumbnail_rgb(slide, dims) -> np.ndarray:
+    img = slide.get_thumbnail(dims)
+    if not isinstance(img, np.ndarray):
+        img = np.asarray(img.convert("RGB"))
+    return np.ascontiguousarray(img[..., :3])
+
+
+def resize_nearest(mask: np.ndarray, width: int, height: int) -> np.ndarray:
+    """cv2.resize(mask, (width, height), interpolation=cv2.INTER_NEAREST): src = min(floor(dst * scale), n-1)"""
+    sh, sw = mask.shape[:2]
+    ys = np.minimum(np.floor(np.arange(height) * (1.0 / (height / sh))).astype(np.int64), sh - 1)
+    xs = np.minimum(np.floor(np.arange(width) * (1.0 / (width / sw))).astype(np.int64), sw - 1)
+    return mask[ys][:, xs]
+
+
+def find_contours_ccomp(mask: np.ndarray):
+    """cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_SIMPLE) -> (list of (n, 2) int32 arrays, parent index
+    array); host C++ (``cpx_find_contours_ccomp_host``)."""
+    m = np.ascontiguousarray(mask != 0, dtype=np.uint8)
+    H, W = m.shape
+    max_pts, max_c = max(4096, 2 * int(m.sum()) + 16), max(1024, int(m.sum()) // 2 + 16)
+    while True:
+        xy = np.empty((max_pts, 2), np.int32)
+        offs, npts, par = (np.empty(max_c, np.int32) for _ in range(3))
+        n = _lib.lib().cpx_find_contours_ccomp_host(m.ctypes.data, H, W, xy.ctypes.data, max_pts, offs.ctypes.data,
+                                                    npts.ctypes.data, par.ctypes.data, max_c)
+        if n == -12:                                        # CPX_ENOMEM: grow and retry
+            max_pts, max_c = max_pts * 2, max_c * 2
+            continue
+        if n < 0:
+            raise _lib.CpxError(f"cpx_find_contours_ccomp_host failed ({n})")
+        return [xy[offs[i]: offs[i] + npts[i]].copy() for i in range(n)], par[:n].copy()
+
+
+def contour_area(cnt: np.ndarray) -> float:
+    """cv2.contourArea: |shoelace| / 2"""
+    x, y = cnt[:, 0].astype(np.float64), cnt[:, 1].astype(np.float64)
+    return abs(float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))) / 2.0
+
+
+def _patch_specs(width: int, height: int, p: int):
+    """the reference's (he_n + 1) x (wi_n + 1) loop: full grid + re-anchored last row / column
+    (wsi_tissue_detection.py:133-151).  Yields (h, w, crop box)."""
+    wi_n, he_n = width // p, height // p
+    for h in range(he_n + 1):
+        for w in range(wi_n + 1):
+            x0 = w * p if w != wi_n else width - p
+            y0 = h * p if h != he_n else height - p
+            yield h, w, (x0, y0, x0 + p, y0 + p)
+
+
+def _crop_pil_like(image: np.ndarray, box) -> np.ndarray:
+    """PIL Image.crop: regions outside the image are black"""
+    x0, y0, x1, y1 = box
+    H, W = image.shape[:2]
+    out = np.zeros((y1 - y0, x1 - x0, 3), np.uint8)
+    sx0, sy0, sx1, sy1 = max(x0, 0), max(y0, 0), min(x1, W), min(y1, H)
+    if sx1 > sx0 and sy1 > sy0:
+        out[sy0 - y0: sy1 - y0, sx0 - x0: sx1 - x0] = image[sy0:sy1, sx0:sx1]
+    return out
+
+
+def _run_patches(net: QcNet, patches: list[np.ndarray]) -> list[np.ndarray]:
+    out = []
+    for s in range(0, len(patches), QC_BATCH):
+        chunk = np.stack(patches[s: s + QC_BATCH])
+        cls = net.forward(torch.from_numpy(chunk).to(net.device))
+        out.extend(cls.cpu().numpy())
+    return out
+
+
+def _as_net(model, n_classes: int, device, seed: int) -> QcNet:
+    if isinstance(model, QcNet):
+        return model
+    sd = model if isinstance(model, dict) else load_qc_state_dict(str(model), n_classes, seed)
+    return QcNet.from_state_dict(sd, device)
+
+
+# ---- detect_tissue_wsi ------------------------------------------------------------------------
+def tissue_class_map(image: np.ndarray, net: QcNet, p_s: int = 512) -> np.ndarray:
+    """patch loop + assembly of detect_tissue_wsi (:131-196): int8 class map of the thumbnail"""
+    height, width = image.shape[:2]
+    wi_n, he_n = width // p_s, height // p_s
+    over_w, over_h = width - wi_n * p_s, height - he_n * p_s
+    specs = list(_patch_specs(width, height, p_s))
+    # a re-anchored edge patch only contributes its last `overhang` columns / rows: skip it when that is nothing
+    used = [(h, w, box) for h, w, box in specs if not ((w == wi_n and over_w == 0) or (h == he_n and over_h == 0))]
+    masks = _run_patches(net, [_crop_pil_like(image, box) for _, _, box in used])
+    out = np.zeros((height, width), np.int8)
+    for (h, w, box), m in zip(used, masks):
+        ys = slice(p_s - over_h, p_s) if h == he_n else slice(0, p_s)
+        xs = slice(p_s - over_w, p_s) if w == wi_n else slice(0, p_s)
+        y0 = height - over_h if h == he_n else h * p_s
+        x0 = width - over_w if w == wi_n else w * p_s
+        sub = m[ys, xs]
+        out[y0: y0 + sub.shape[0], x0: x0 + sub.shape[1]] = sub
+    return out
+
+
+def tissue_contours(class_map: np.ndarray, mpp_model_td: int, min_area: int, scaling):
+    """connected components of class 0 (tissue) with the real-area filter, then RETR_CCOMP contours
+    with holes attached to their parents (:198-250).  Returns (filtered_mask, output_cnts)."""
+    from scipy import ndimage
+    fg = (1 - class_map.astype(np.uint8)).astype(np.uint8)      # cv2.connectedComponents(1 - map): tissue = class 0
+    cc, n_c = ndimage.label(fg != 0, structure=np.ones((3, 3), int))
+    filtered = np.zeros_like(fg, dtype=np.uint8)
+    if n_c:
+        areas = np.bincount(cc.ravel(), minlength=n_c + 1) * (mpp_model_td ** 2)
+        keep = areas >= min_area
+        keep[0] = False
+        filtered[keep[cc]] = 1
+    cnts, parent = find_contours_ccomp(filtered)
+    output_cnts: dict = {}
+    scaling = np.asarray(scaling, dtype=np.float64)
+    for i, cnt in enumerate(cnts):
+        if cnt.shape[0] < 4:
+            grandqc_logger.warning(f"Invalid polygon detected: fewer than 4 points detected ({cnt.shape})")
+            continue
+        if parent[i] == -1:
+            c = cnt * scaling
+            output_cnts[i] = {"contour": np.concatenate([c, c[0:1]], 0), "holes": []}
+    for i in np.nonzero(parent != -1)[0]:
+        if int(parent[i]) in output_cnts:                       # the reference raises KeyError here when the parent was < 4 points
+            output_cnts[int(parent[i])]["holes"].append(cnts[i] * scaling)
+    return filtered, output_cnts
+
+
+def _cnts_to_geojson(output_cnts: dict, name: str, color: list[int]) -> dict:
+    feats = []
+    for cnt in output_cnts.values():
+        coords = cnt["contour"].tolist()
+        coords.append(coords[0])
+        rings = []
+        for hole in cnt["holes"]:
+            hc = hole.tolist()
+            if len(hc) < 4:
+                continue
+            if hc[0] != hc[-1]:
+                hc.append(hc[0])
+            rings.append(hc)
+        feats.append({"type": "Feature", "id": str(uuid.uuid4()),
+                      "geometry": {"type": "Polygon", "coordinates": [coords, *rings]},
+                      "properties": {"objectType": "annotation", "isLocked": False,
+                                     "classification": {"name": name, "color": color}}})
+    return {"type": "FeatureCollection", "features": feats}
+
+
+def _shift_outputs(output_cnts: dict, geojson: dict, bx: float, by: float):
+    off = np.array([bx, by])
+    for cnt in output_cnts.values():
+        cnt["contour"] = cnt["contour"] - off
+        cnt["holes"] = [h - off for h in cnt["holes"]]
+    for f in geojson["features"]:
+        f["geometry"]["coordinates"] = [[[pt[0] - bx, pt[1] - by] for pt in ring]
+                                        for ring in f["geometry"]["coordinates"]]
+
+
+def detect_tissue_wsi(slide, model_td_path="./models/tissue_detection/Tissue_Detection_MPP10.pth",
+                      mpp_model_td: int = 10, m_p_s_model_td: int = 512, device="cuda:0", min_area: int = 0,
+                      apply_bounds_offset: bool = False, class_map_override=None):
+    """Same return tuple as the reference: (image, filtered_mask, filled_class_map, output_cnts,
+    geojson, mpp_model_td).  ``filled_class_map`` (a cv2.drawContours rendering nothing downstream
+    reads) is returned as zeros.  ``class_map_override(image) -> int8 map`` replaces the network's
+    decision in flow-injection style tests (the network still runs)."""
+    net = _as_net(model_td_path, 2, device, seed=101)
+    bx = float(slide.properties.get("openslide.bounds-x", 0.0))
+    by = float(slide.properties.get("openslide.bounds-y", 0.0))
+    w_l0, h_l0, mpp, dims = extract_slide_info(slide, mpp_model_td)
+    grandqc_logger.info(f"Extracting thumbnail with size {dims}")
+    image = simulate_jpeg_compression(_thumbnail_rgb(slide, dims))
+    height, width = image.shape[:2]
+    class_map = tissue_class_map(image, net, m_p_s_model_td)
+    if class_map_override is not None:
+        class_map = np.asarray(class_map_override(image), dtype=np.int8)
+    filtered, output_cnts = tissue_contours(class_map, mpp_model_td, min_area, (w_l0 / width, h_l0 / height))
+    filled = np.zeros_like(filtered)
+    if not output_cnts:
+        grandqc_logger.warning("No tissue contours detected in slide.")
+        return image, filtered, filled, {}, {"type": "FeatureCollection", "features": []}, mpp_model_td
+    geojson = _cnts_to_geojson(output_cnts, "tissue", [0, 0, 0])
+    if apply_bounds_offset and (bx != 0 or by != 0):
+        _shift_outputs(output_cnts, geojson, bx, by)
+    return image, filtered, filled, output_cnts, geojson, mpp_model_td
+
+
+# ---- detect_artefacts_wsi ---------------------------------------------------------------------
+def artefact_class_map(image: np.ndarray, tissue_mask_art: np.ndarray, net: QcNet, p_s: int = 512,
+                       class_map_override=None) -> np.ndarray:
+    """tissue-gated patch loop + padding of detect_artefacts_wsi (:175-229): class 7 = background"""
+    height, width = image.shape[:2]
+    n_w, n_h = width // p_s, height // p_s
+    out = np.full((height, width), 7, dtype=np.int64)
+    todo = []
+    for h in range(n_h):
+        for w in range(n_w):
+            td = tissue_mask_art[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s]
+            if np.count_nonzero(td == 1) > 50:
+                todo.append((h, w))
+    masks = _run_patches(net, [image[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s] for h, w in todo])
+    if class_map_override is not None:
+        full = np.asarray(class_map_override(image))
+        masks = [full[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s] for h, w in todo]
+    for (h, w), m in zip(todo, masks):
+        td = tissue_mask_art[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s]
+        out[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s] = np.where(td == 1, m, 7)
+    return out
+
+
+def artefact_contours(artefact_mask: np.ndarray, scaling):
+    """per-class RETR_CCOMP contours (:252-325): GeoJSON features for classes 1-6, filter polygons
+    (``artefact_cnts``) for classes 2-6 with area > 10 px"""
+    scaling = np.asarray(scaling, dtype=np.float64)
+    geojson = {"type": "FeatureCollection", "features": []}
+    artefact_cnts: dict = {}
+    n_small = 0
+    for cv in range(1, 7):
+        cnts, parent = find_contours_ccomp((artefact_mask == cv).astype(np.uint8))
+        if not cnts:
+            continue
+        for i, cnt in enumerate(cnts):
+            if cnt.shape[0] < 4:
+                continue
+            if cv >= 2 and contour_area(cnt) <= 10:
+                n_small += 1
+                continue
+            pts = (cnt * scaling).tolist()
+            if pts[0] != pts[-1]:
+                pts.append(pts[0])
+            geojson["features"].append({"type": "Feature", "id": str(uuid.uuid4()),
+                                        "geometry": {"type": "Polygon", "coordinates": [pts]},
+                                        "properties": {"objectType": "annotation", "isLocked": False,
+                                                       "classification": {"name": ARTIFACT_CLASS_MAPPING.get(cv, "Unknown"),
+                                                                          "color": ARTIFACT_COLORS[cv]}}})
+            if 2 <= cv <= 6 and parent[i] == -1:
+                c = cnt * scaling
+                artefact_cnts[f"{cv}_{i}"] = {"contour": np.concatenate([c, c[0:1]], 0), "holes": []}
+        if 2 <= cv <= 6:
+            for i in np.nonzero(parent != -1)[0]:
+                key = f"{cv}_{int(parent[i])}"
+                if key in artefact_cnts:
+                    artefact_cnts[key]["holes"].append(cnts[i] * scaling)
+    grandqc_logger.info(f"Filtered {n_small} small artifacts (<= 10 pixels)")
+    return artefact_cnts, geojson
+
+
+def detect_artefacts_wsi(slide, model_art_path="./models/artefact_detection/GrandQC_MPP1.pth",
+                         mpp_model_art: float = 1.0, m_p_s_model_art: int = 512, device="cuda:0",
+                         model_td_path="./models/tissue_detection/Tissue_Detection_MPP10.pth", mpp_model_td: int = 10,
+                         m_p_s_model_td: int = 512, min_area: int = 0, apply_bounds_offset: bool = False,
+                         tissue_override=None, artefact_override=None):
+    """(artefact_mask, artefact_map, artefact_cnts, geojson) like the reference; ``artefact_map`` (a
+    LANCZOS-resized colour rendering nothing downstream reads) is None."""
+    grandqc_logger.info("Performing tissue detection...")
+    _, tissue_mask, _, _, _, _ = detect_tissue_wsi(slide, model_td_path, mpp_model_td, m_p_s_model_td, device,
+                                                   min_area, False, class_map_override=tissue_override)
+    net = _as_net(model_art_path, 8, device, seed=202)
+    bx = float(slide.properties.get("openslide.bounds-x", 0.0))
+    by = float(slide.properties.get("openslide.bounds-y", 0.0))
+    w_l0, h_l0, mpp, dims = extract_slide_info(slide, mpp_model_art)
+    grandqc_logger.info(f"Extracting thumbnail with size {dims} for artifact detection")
+    image = simulate_jpeg_compression(_thumbnail_rgb(slide, dims))
+    height, width = image.shape[:2]
+    tissue_mask_art = resize_nearest(tissue_mask, width, height)
+    artefact_mask = artefact_class_map(image, tissue_mask_art, net, m_p_s_model_art, artefact_override)
+    artefact_cnts, geojson = artefact_contours(artefact_mask, (w_l0 / width, h_l0 / height))
+    if apply_bounds_offset and (bx != 0 or by != 0):
+        _shift_outputs(artefact_cnts, geojson, bx, by)
+    return artefact_mask, None, artefact_cnts, geojson

@@ -310,6 +310,16 @@ int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, const cpx_reco
                         double scale, double off_x, double off_y, double *xy_pool, int max_pts,
                         cpx_cell *cells);
 
+/* cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_SIMPLE) of the GrandQC class maps
+ * (/root/reference/src/classpose/grandqc/wsi_tissue_detection.py:209-213,
+ * wsi_artefact_detection.py:262-265), host code.  mask [H][W] uint8, non-zero = foreground.
+ * Contour c = xy_pool[2*offsets[c] .. 2*(offsets[c]+n_pts[c])) as (x, y) int32 pairs;
+ * parent[c] = -1 for outer borders, else the index of the enclosing component's outer border
+ * (hierarchy[0, c, 3] of RETR_CCOMP).  Discovery (raster) order.  Returns #contours or < 0. */
+int cpx_find_contours_ccomp_host(const uint8_t *mask_host, int H, int W, int32_t *xy_pool, int max_pts,
+                                 int32_t *offsets, int32_t *n_pts, int32_t *parent, int max_contours);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,3 +127,63 @@ def predict_mask(sd: dict, patch_u8: np.ndarray) -> np.ndarray:
     with torch.no_grad():
         pred = forward(sd, preprocess(patch_u8))[0].numpy()
     return np.argmax(pred, axis=0).astype("int8")
+
+
+# ---- patch loops of the reference, restated literally (np.concatenate assembly) -------------------
+def tissue_class_map_ref(image: np.ndarray, predict, p_s: int = 512) -> np.ndarray:
+    """wsi_tissue_detection.py:113-196 with ``predict(patch_u8) -> int8 mask`` in place of the model."""
+    from PIL import Image
+    img = Image.fromarray(image)
+    width, height = img.size
+    wi_n, he_n = width // p_s, height // p_s
+    overhang_wi, overhang_he = width - wi_n * p_s, height - he_n * p_s
+    for h in range(he_n + 1):
+        for w in range(wi_n + 1):
+            if w != wi_n and h != he_n:
+                box = (w * p_s, h * p_s, (w + 1) * p_s, (h + 1) * p_s)
+            elif w == wi_n and h != he_n:
+                box = (width - p_s, h * p_s, width, (h + 1) * p_s)
+            elif w != wi_n and h == he_n:
+                box = (w * p_s, height - p_s, (w + 1) * p_s, height)
+            else:
+                box = (width - p_s, height - p_s, width, height)
+            mask = predict(np.array(img.crop(box)))
+            if w == 0:
+                temp = mask
+            elif w == wi_n:
+                temp = np.concatenate((temp, mask[:, p_s - overhang_wi: p_s]), axis=1)
+            else:
+                temp = np.concatenate((temp, mask), axis=1)
+        if h == 0:
+            end = temp
+        elif h == he_n:
+            end = np.concatenate((end, temp[p_s - overhang_he: p_s]), axis=0)
+        else:
+            end = np.concatenate((end, temp), axis=0)
+    ah, aw = end.shape
+    if (ah, aw) != (height, width):
+        end = end[ah - height: ah, aw - width: aw]
+    return end
+
+
+def artefact_mask_ref(image: np.ndarray, tissue_mask_art: np.ndarray, predict, p_s: int = 512) -> np.ndarray:
+    """wsi_artefact_detection.py:175-229"""
+    height, width = image.shape[:2]
+    n_w, n_h = width // p_s, height // p_s
+    rows = []
+    for h in range(n_h):
+        cols = []
+        for w in range(n_w):
+            td = tissue_mask_art[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s]
+            if np.count_nonzero(td == 1) > 50:
+                raw = predict(image[h * p_s:(h + 1) * p_s, w * p_s:(w + 1) * p_s])
+                cols.append(np.where(td == 1, raw, 7))
+            else:
+                cols.append(np.full(td.shape, 7))
+        rows.append(np.concatenate(cols, axis=1))
+    out = np.concatenate(rows, axis=0)
+    if height - n_h * p_s > 0:
+        out = np.concatenate((out, np.full((height - n_h * p_s, out.shape[1]), 7, dtype=out.dtype)), axis=0)
+    if width - n_w * p_s > 0:
+        out = np.concatenate((out, np.full((out.shape[0], width - n_w * p_s), 7, dtype=out.dtype)), axis=1)
+    return out
