@@ -150,6 +150,24 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         if rank == 0:
             logger.info(f"Selecting tiles using ROI with {len(rois)} polygons: {len(plan.coords)} tiles")
     plan.rois = rois
+    plan.tissue_cnts = None
+    if args.tissue_detection_model_path is not None:
+        # SlideLoader._get_tissue_contours (predict_wsi.py:305-322): GrandQC tissue detection on the
+        # 10 um/px thumbnail before the first tile is read; tiles that miss every tissue polygon are skipped
+        from .. import grandqc
+        logger.info("Detecting tissue contours using GrandQC")
+        _, _, _, tissue_cnts, _, _ = grandqc.detect_tissue_wsi(
+            wsi.WSIReader(args.slide_path), model_td_path=args.tissue_detection_model_path,
+            min_area=args.min_area, device=device, class_map_override=_qc_override("tissue"))
+        plan.tissue_cnts = roi.polygons_from_cnts(tissue_cnts)
+        logger.info(f"Number of tissue contours: {len(plan.tissue_cnts)}")
+        if not plan.tissue_cnts:
+            logger.warning("No tissue detected in slide. Skipping inference.")
+            plan.coords = []
+        else:
+            plan.coords = [c for c in plan.coords if roi.check_tile_in_cnts(c[0], c[1], plan.ts, plan.tissue_cnts)]
+        if rank == 0:
+            logger.info(f"Tiles to predict after the tissue filter: {len(plan.coords)}")
     weights = engine.NetWeights.from_state_dict(sd, args.precision, device)
     mine = list(parallel.shard_indices(len(plan.coords), rank, world))
     by_size: dict[int, list[int]] = {}
@@ -220,7 +238,16 @@ def gather_cells(cells: np.ndarray, xy: np.ndarray, device) -> tuple[np.ndarray,
     return c.reshape(-1).view(CELL_ROW), v.reshape(-1).view(np.float64).reshape(-1, 2)
 
 
-def write_outputs(args, cells, xy, labels, plan):
+def _qc_override(kind: str):
+    """CLASSPOSE_QC_INJECTION=1 (tests on synthetic slides with random GrandQC weights): the class map
+    comes from ``synth.analytic_qc_map`` instead of the network's argmax; the network still runs."""
+    if os.getenv("CLASSPOSE_QC_INJECTION", "0") != "1":
+        return None
+    from .. import synth
+    return lambda image: synth.analytic_qc_map(kind, image.shape[0], image.shape[1])
+
+
+def write_outputs(args, cells, xy, labels, plan, device=None):
     offs = np.concatenate([[0], np.cumsum(cells["n_pts"])]).astype(np.int64)
     curr = []
     for i, c in enumerate(cells):
@@ -238,15 +265,52 @@ def write_outputs(args, cells, xy, labels, plan):
         logger.info("Filtering cells based on ROI contours")
         polygons = roi.filter_cells_by_contours(polygons, plan.rois)
         logger.info(f"Number of cells after filtering: {len(polygons)}")
-    if args.min_area and args.min_area > 0:
-        pass   # --min_area only applies to tissue polygons in the reference (predict_wsi.py:1948-1955)
     bx, by = plan.bounds
-    if bx != 0 or by != 0:
-        polygons = [geojson.apply_bounds_offset_to_feature(p, bx, by) for p in polygons]
     out = Path(args.output_folder)
     out.mkdir(parents=True, exist_ok=True)
     base = Path(args.slide_path.split("?")[0]).stem if "://" not in args.slide_path else \
         args.slide_path.split("://", 1)[1].split("?")[0].replace("/", "_")
+    if plan.tissue_cnts is not None:
+        # predict_wsi.py:1637-1676: tissue filter + <stem>_tissue_contours.geojson (display coordinates)
+        logger.info("Filtering cells based on tissue contours")
+        polygons = roi.filter_cells_by_contours(polygons, plan.tissue_cnts)
+        shown = [c.translate(-bx, -by) for c in plan.tissue_cnts] if (bx != 0 or by != 0) else plan.tissue_cnts
+        feats = []
+        for i, cnt in enumerate(shown):
+            feats.extend(roi.polygon_to_geojson(cnt, id=f"tissue_{i}", object_type="annotation",
+                                                additional_properties={"classification": {"name": "tissue", "color": [0, 0, 0]}}))
+        logger.info(f"Total tissue area: {sum(c.area for c in shown)}")
+        logger.info(f"Number of cells after filtering: {len(polygons)}")
+        with open(out / get_geojson_output_filename("tissue_contours", base), "w") as f:
+            json.dump({"type": "FeatureCollection", "features": feats}, f)
+    if args.artefact_detection_model_path is not None:
+        if args.tissue_detection_model_path is None:
+            logger.warning("Skipping artefact detection as --tissue_detection_model_path was not provided.")
+        else:
+            # predict_wsi.py:1678-1760: artefact detection, optional cell filter, <stem>_artefact_contours.geojson
+            from .. import grandqc
+            logger.info("Running artefact detection")
+            _, _, artefact_cnts, _ = grandqc.detect_artefacts_wsi(
+                wsi.WSIReader(args.slide_path), model_art_path=args.artefact_detection_model_path,
+                model_td_path=args.tissue_detection_model_path, device=device,
+                tissue_override=_qc_override("tissue"), artefact_override=_qc_override("artefact"))
+            logger.info(f"Found {len(artefact_cnts)} artefact contours")
+            art = roi.polygons_from_cnts(artefact_cnts)
+            if args.filter_artefacts:
+                polygons, removed = roi.filter_cells_by_artefacts(polygons, art)
+                logger.info(f"Removed {removed} cells in artefact regions")
+                logger.info(f"Cells remaining after artefact filtering: {len(polygons)}")
+            if bx != 0 or by != 0:
+                art = [a.translate(-bx, -by) for a in art]
+            feats = []
+            for i, poly in enumerate(art):
+                feats.extend(roi.polygon_to_geojson(poly, id=f"artefact_{i}", object_type="annotation",
+                                                    additional_properties={"classification": {"name": "artefact", "color": [255, 0, 0]}}))
+            logger.info(f"Total artefact area: {sum(a.area for a in art)}")
+            with open(out / get_geojson_output_filename("artefact_contours", base), "w") as f:
+                json.dump({"type": "FeatureCollection", "features": feats}, f)
+    if bx != 0 or by != 0:
+        polygons = [geojson.apply_bounds_offset_to_feature(p, bx, by) for p in polygons]
     contours = out / get_geojson_output_filename("cell_contours", base)
     centroids = out / get_geojson_output_filename("cell_centroids", base)
     with open(contours, "w") as f:
@@ -258,11 +322,8 @@ def write_outputs(args, cells, xy, labels, plan):
 
 
 def _check_unsupported(args):
-    for name in ("tissue_detection_model_path", "artefact_detection_model_path"):
-        if getattr(args, name):
-            raise NotImplementedError(f"--{name} is not built yet on the MI355X engine (SURVEY 8f next rows)")
-    if args.filter_artefacts or args.output_type:
-        raise NotImplementedError("--filter_artefacts / --output_type are not built yet")
+    if args.output_type:
+        raise NotImplementedError("--output_type csv / spatialdata is not built yet")
     if args.tile_size < MIN_TILE_SIZE:
         raise ValueError(f"Tile size must be at least {MIN_TILE_SIZE}, got {args.tile_size}")
 
@@ -292,7 +353,7 @@ def main(args, spawned: bool = False):
     if world > 1:
         cells, xy = gather_cells(cells, xy, device)
     if rank == 0:
-        write_outputs(args, cells, xy, labels, plan)
+        write_outputs(args, cells, xy, labels, plan, device)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

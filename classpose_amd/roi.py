@@ -23,13 +23,18 @@ MIN_TILE_SIZE = 256
 class RoiPolygon:
     """One polygon: closed exterior ring + closed hole rings, float64 (n, 2) arrays."""
 
-    def __init__(self, exterior, holes=()):
+    def __init__(self, exterior, holes=(), validate: bool = True):
+        """validate=False accepts rings that touch or retrace themselves (border-following contours of
+        raster masks do): the predicates below are even-odd point-set tests and stay well defined;
+        the reference repairs such rings with GEOS make_valid / buffer(0), which differs on
+        measure-zero spikes only."""
         self.exterior = self._close(np.asarray(exterior, dtype=np.float64)[:, :2])
         self.holes = [self._close(np.asarray(h, dtype=np.float64)[:, :2]) for h in holes]
+        self.holes = [h for h in self.holes if len(h) >= 4]
         for ring in self.rings:
             if len(ring) < 4:
                 raise ValueError("ROI ring needs at least three distinct vertices")
-            if not _ring_is_simple(ring):
+            if validate and not _ring_is_simple(ring):
                 raise ValueError("ROI ring self-intersects; repair it (e.g. shapely.make_valid) "
                                  "before passing it: GEOS' repair is not restated here")
 
@@ -50,9 +55,30 @@ class RoiPolygon:
     def area(self) -> float:
         return abs(_ring_area(self.exterior)) - sum(abs(_ring_area(h)) for h in self.holes)
 
+    @property
+    def length(self) -> float:
+        return float(sum(np.hypot(*np.diff(r, axis=0).T).sum() for r in self.rings))
+
+    @property
+    def centroid(self) -> tuple[float, float]:
+        """area-weighted centroid (holes subtract), what shapely's Polygon.centroid returns"""
+        a6 = cx = cy = 0.0
+        for k, r in enumerate(self.rings):
+            x, y = r[:-1, 0] - self.exterior[0, 0], r[:-1, 1] - self.exterior[0, 1]
+            x1, y1 = r[1:, 0] - self.exterior[0, 0], r[1:, 1] - self.exterior[0, 1]
+            cr = x * y1 - x1 * y
+            sign = 1.0 if k == 0 else -1.0
+            orient = 1.0 if cr.sum() >= 0 else -1.0
+            a6 += sign * orient * cr.sum() * 3
+            cx += sign * orient * ((x + x1) * cr).sum()
+            cy += sign * orient * ((y + y1) * cr).sum()
+        if a6 == 0:
+            return float(self.exterior[0, 0]), float(self.exterior[0, 1])
+        return float(self.exterior[0, 0] + cx / a6), float(self.exterior[0, 1] + cy / a6)
+
     def translate(self, xoff: float, yoff: float) -> "RoiPolygon":
         off = np.array([xoff, yoff])
-        return RoiPolygon(self.exterior + off, [h + off for h in self.holes])
+        return RoiPolygon(self.exterior + off, [h + off for h in self.holes], validate=False)
 
     # -- predicates ----------------------------------------------------------------
     def locate(self, x: float, y: float) -> int:
@@ -70,26 +96,89 @@ class RoiPolygon:
         """shapely ``Point.within(polygon)``: interior only."""
         return self.locate(x, y) > 0
 
+    def _edge_index(self, nbins: int = 512):
+        """edges of all rings bucketed by the y range they span (built once, for the vectorised tests)"""
+        if getattr(self, "_eidx", None) is None:
+            a = np.concatenate([r[:-1] for r in self.rings])
+            b = np.concatenate([r[1:] for r in self.rings])
+            y0, y1 = self.bounds[1], self.bounds[3]
+            nb = int(max(1, min(nbins, len(a) // 4)))
+            h = (y1 - y0) / nb if y1 > y0 else 1.0
+            lo = np.clip(np.floor((np.minimum(a[:, 1], b[:, 1]) - y0) / h).astype(np.int64), 0, nb - 1)
+            hi = np.clip(np.floor((np.maximum(a[:, 1], b[:, 1]) - y0) / h).astype(np.int64), 0, nb - 1)
+            buckets = [[] for _ in range(nb)]
+            for e in range(len(a)):
+                for k in range(lo[e], hi[e] + 1):
+                    buckets[k].append(e)
+            self._eidx = (a, b, y0, h, nb, [np.asarray(k, dtype=np.int64) for k in buckets])
+        return self._eidx
+
+    def contains_points_strict(self, xs, ys) -> np.ndarray:
+        """vectorised ``contains_point_strict`` (even-odd over all rings, boundary points excluded)"""
+        xs, ys = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+        out = np.zeros(len(xs), bool)
+        bx0, by0, bx1, by1 = self.bounds
+        cand = np.nonzero((xs >= bx0) & (xs <= bx1) & (ys >= by0) & (ys <= by1))[0]
+        if len(cand) == 0:
+            return out
+        a, b, y0, h, nb, buckets = self._edge_index()
+        bins = np.clip(np.floor((ys[cand] - y0) / h).astype(np.int64), 0, nb - 1)
+        order = np.argsort(bins, kind="stable")
+        cand, bins = cand[order], bins[order]
+        starts = np.searchsorted(bins, np.arange(nb)); ends = np.searchsorted(bins, np.arange(nb), side="right")
+        for k in range(nb):
+            if starts[k] == ends[k] or len(buckets[k]) == 0:
+                continue
+            idx = cand[starts[k]:ends[k]]
+            ea, eb = a[buckets[k]], b[buckets[k]]
+            for s0 in range(0, len(idx), 8192):
+                ii = idx[s0:s0 + 8192]
+                px, py = xs[ii][:, None], ys[ii][:, None]
+                ax, ay, bx, by = ea[None, :, 0], ea[None, :, 1], eb[None, :, 0], eb[None, :, 1]
+                orient = (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+                on = (orient == 0) & (px >= np.minimum(ax, bx)) & (px <= np.maximum(ax, bx)) & \
+                     (py >= np.minimum(ay, by)) & (py <= np.maximum(ay, by))
+                span = (ay > py) != (by > py)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    xi = ax + (py - ay) * (bx - ax) / (by - ay)
+                cross = span & (xi > px)
+                out[ii] = (cross.sum(1) % 2 == 1) & ~on.any(1)
+        return out
+
     def intersects_square(self, x0: float, y0: float, size: float) -> bool:
         """shapely ``polygon.intersects(square)`` (closed sets share at least one point)."""
         x1, y1 = x0 + size, y0 + size
         bx0, by0, bx1, by1 = self.bounds
         if bx1 < x0 or bx0 > x1 or by1 < y0 or by0 > y1:
             return False
-        sq = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1], [x0, y0]])
-        for ring in self.rings:
-            for k in range(len(ring) - 1):
-                ax, ay, bx, by = *ring[k], *ring[k + 1]
-                if max(ax, bx) < x0 or min(ax, bx) > x1 or max(ay, by) < y0 or min(ay, by) > y1:
-                    continue
-                for j in range(4):
-                    if _segments_intersect(ring[k], ring[k + 1], sq[j], sq[j + 1]):
-                        return True
+        if getattr(self, "_edges", None) is None:
+            self._edges = (np.concatenate([r[:-1] for r in self.rings]), np.concatenate([r[1:] for r in self.rings]))
+        a, b = self._edges
+        near = ~((np.maximum(a[:, 0], b[:, 0]) < x0) | (np.minimum(a[:, 0], b[:, 0]) > x1) |
+                 (np.maximum(a[:, 1], b[:, 1]) < y0) | (np.minimum(a[:, 1], b[:, 1]) > y1))
+        if near.any():
+            ea, eb = a[near], b[near]
+            sq = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1], [x0, y0]])
+            for j in range(4):
+                c, d = sq[j], sq[j + 1]
+                o1 = (eb[:, 0] - ea[:, 0]) * (c[1] - ea[:, 1]) - (eb[:, 1] - ea[:, 1]) * (c[0] - ea[:, 0])
+                o2 = (eb[:, 0] - ea[:, 0]) * (d[1] - ea[:, 1]) - (eb[:, 1] - ea[:, 1]) * (d[0] - ea[:, 0])
+                o3 = (d[0] - c[0]) * (ea[:, 1] - c[1]) - (d[1] - c[1]) * (ea[:, 0] - c[0])
+                o4 = (d[0] - c[0]) * (eb[:, 1] - c[1]) - (d[1] - c[1]) * (eb[:, 0] - c[0])
+                proper = ((o1 > 0) != (o2 > 0)) & ((o3 > 0) != (o4 > 0)) & (o1 != 0) & (o2 != 0) & (o3 != 0) & (o4 != 0)
+                lo, hi = np.minimum(ea, eb), np.maximum(ea, eb)
+                slo, shi = np.minimum(c, d), np.maximum(c, d)
+                t1 = (o1 == 0) & (lo[:, 0] <= c[0]) & (c[0] <= hi[:, 0]) & (lo[:, 1] <= c[1]) & (c[1] <= hi[:, 1])
+                t2 = (o2 == 0) & (lo[:, 0] <= d[0]) & (d[0] <= hi[:, 0]) & (lo[:, 1] <= d[1]) & (d[1] <= hi[:, 1])
+                t3 = (o3 == 0) & (slo[0] <= ea[:, 0]) & (ea[:, 0] <= shi[0]) & (slo[1] <= ea[:, 1]) & (ea[:, 1] <= shi[1])
+                t4 = (o4 == 0) & (slo[0] <= eb[:, 0]) & (eb[:, 0] <= shi[0]) & (slo[1] <= eb[:, 1]) & (eb[:, 1] <= shi[1])
+                if (proper | t1 | t2 | t3 | t4).any():
+                    return True
         # no boundary crossing: one contains the other, or they are disjoint
         if self.locate(x0, y0) >= 0:
             return True
         ex, ey = self.exterior[0]
-        return x0 <= ex <= x1 and y0 <= ey <= y1
+        return bool(x0 <= ex <= x1 and y0 <= ey <= y1)
 
     def chord_lengths(self, c: float, axis: int) -> list[float]:
         """Lengths of the pieces of the line {coord[axis] == c} inside the closed polygon."""
@@ -141,6 +230,17 @@ def _segments_intersect(a, b, c, d) -> bool:
 
 
 def _locate_in_ring(ring: np.ndarray, x: float, y: float) -> int:
+    if len(ring) > 64:                                    # long rings (raster contours): numpy over the edges
+        a, b = ring[:-1], ring[1:]
+        orient = (b[:, 0] - a[:, 0]) * (y - a[:, 1]) - (b[:, 1] - a[:, 1]) * (x - a[:, 0])
+        on = (orient == 0) & (np.minimum(a[:, 0], b[:, 0]) <= x) & (x <= np.maximum(a[:, 0], b[:, 0])) & \
+             (np.minimum(a[:, 1], b[:, 1]) <= y) & (y <= np.maximum(a[:, 1], b[:, 1]))
+        if on.any():
+            return 0
+        span = (a[:, 1] > y) != (b[:, 1] > y)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xi = a[:, 0] + (y - a[:, 1]) * (b[:, 0] - a[:, 0]) / (b[:, 1] - a[:, 1])
+        return 1 if int((span & (xi > x)).sum()) % 2 == 1 else -1
     inside = False
     p = (x, y)
     for k in range(len(ring) - 1):
@@ -240,6 +340,49 @@ def check_tile_in_cnts(coords, tile_size: int, ts: float, cnts: list[RoiPolygon]
     return any(c.intersects_square(coords[0], coords[1], size0) for c in cnts)
 
 
+def polygon_to_geojson(polygon: RoiPolygon, id: str | None = None, object_type: str = "annotation",
+                       additional_properties: dict | None = None) -> list[dict]:
+    """``shapely_polygon_to_geojson`` (predict_wsi.py:966-1023) for one polygon with holes"""
+    import uuid
+    cx, cy = polygon.centroid
+    props = {"objectType": object_type, "isLocked": False,
+             "measurements": [{"name": "area", "value": polygon.area}, {"name": "perimeter", "value": polygon.length},
+                              {"name": "centroidX", "value": cx}, {"name": "centroidY", "value": cy}]}
+    if additional_properties is not None:
+        props.update(additional_properties)
+    return [{"type": "Feature", "id": id if id is not None else str(uuid.uuid4()),
+             "geometry": {"type": "Polygon", "coordinates": [r.tolist() for r in polygon.rings]},
+             "properties": props}]
+
+
+def polygons_from_cnts(cnts: dict) -> list[RoiPolygon]:
+    """{"contour", "holes"} dicts of detect_tissue_wsi / detect_artefacts_wsi -> polygons
+    (``make_valid(shapely.Polygon(cnt["contour"], cnt["holes"]))``, predict_wsi.py:314-319, and
+    ``create_valid_polygon``, outputs.py:17-55); degenerate contours are dropped."""
+    out = []
+    for c in cnts.values():
+        try:
+            poly = RoiPolygon(c["contour"], c.get("holes", []), validate=False)
+        except ValueError:
+            continue
+        if poly.area > 0:
+            out.append(poly)
+    return out
+
+
+def filter_cells_by_artefacts(cells: list[dict], artefact_polys: list[RoiPolygon]):
+    """predict_wsi.py:1281-1333: drop cells whose centroid lies strictly inside an artefact polygon"""
+    if not artefact_polys:
+        return cells, 0
+    if len(cells) == 0:
+        return cells, 0
+    pts = np.array([get_cell_centroid(cell) for cell in cells], dtype=np.float64)
+    hit = np.zeros(len(cells), bool)
+    for c in artefact_polys:
+        hit |= c.contains_points_strict(pts[:, 0], pts[:, 1])
+    return [cell for cell, h in zip(cells, hit) if not h], int(hit.sum())
+
+
 def get_cell_centroid(cell: dict) -> list[float]:
     m = cell["properties"]["measurements"]
     return [[x for x in m if x["name"] == "centroidX"][0]["value"],
@@ -252,12 +395,10 @@ def filter_cells_by_contours(polygons: list[dict], contours: list[RoiPolygon]) -
     returned k times."""
     if len(contours) == 0:
         return polygons
-    boxes = np.array([c.bounds for c in contours])
-    keep = []
-    for i, cell in enumerate(polygons):
-        x, y = get_cell_centroid(cell)
-        cand = np.nonzero((boxes[:, 0] <= x) & (x <= boxes[:, 2]) & (boxes[:, 1] <= y) & (y <= boxes[:, 3]))[0]
-        for k in cand:
-            if contours[k].contains_point_strict(x, y):
-                keep.append(i)
-    return [polygons[i] for i in keep]
+    if len(polygons) == 0:
+        return polygons
+    pts = np.array([get_cell_centroid(cell) for cell in polygons], dtype=np.float64)
+    counts = np.zeros(len(polygons), np.int64)
+    for c in contours:
+        counts += c.contains_points_strict(pts[:, 0], pts[:, 1])
+    return [polygons[i] for i in range(len(polygons)) for _ in range(int(counts[i]))]

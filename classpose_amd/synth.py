@@ -297,3 +297,19 @@ def make_grandqc_state_dict(n_classes: int = 2, seed: int = 0):
     for n in ("weight", "bias", "running_mean", "running_var"):
         sd["encoder.bn2." + n] = torch.ones(1280)
     return sd
+
+
+def analytic_qc_map(kind: str, height: int, width: int) -> np.ndarray:
+    """Class maps for QC-injection tests on synthetic slides, in thumbnail pixels.
+
+    tissue: class 0 (tissue) inside an ellipse covering the central part of the slide with a
+    circular hole, class 1 (background) elsewhere.  artefact: class 1 (normal tissue) everywhere
+    except a rectangle of class 2 (fold) in the upper-left part of the ellipse."""
+    yy, xx = np.mgrid[0:height, 0:width]
+    u, v = (xx + 0.5) / width, (yy + 0.5) / height
+    ell = ((u - 0.5) / 0.40) ** 2 + ((v - 0.5) / 0.36) ** 2 <= 1.0
+    hole = (u - 0.62) ** 2 + ((v - 0.55) * height / width) ** 2 <= 0.06 ** 2
+    if kind == "tissue":
+        return np.where(ell & ~hole, 0, 1).astype(np.int8)
+    fold = (u > 0.30) & (u < 0.42) & (v > 0.30) & (v < 0.45)
+    return np.where(fold, 2, 1).astype(np.int8)

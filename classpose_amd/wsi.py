@@ -81,6 +81,7 @@ class SlidePlan:
     read_overlap: int
     coords: list
     rois: list | None = None
+    tissue_cnts: list | None = None
 
 
 def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePlan:

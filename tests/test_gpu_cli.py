@@ -180,3 +180,54 @@ def test_predict_wsi_cli_roi(cuda, tmp_path, monkeypatch):
     assert np.all(d < 1.5) and len(np.unique(idx)) == safe.sum()
     counts = cKDTree(found).query_ball_point(np.stack([cx[inner], cy[inner]], 1), 7.5, return_length=True)
     assert np.all(counts <= 1) and (counts == 1).mean() > 0.9
+
+
+def test_predict_wsi_cli_tissue_and_artefacts(cuda, tmp_path, monkeypatch):
+    """--tissue_detection_model_path / --artefact_detection_model_path / --filter_artefacts: GrandQC nets
+    run on the thumbnails (synthetic weights), class maps injected analytically; tiles outside tissue are
+    skipped, cells are filtered by tissue and artefact polygons, both contour files are written"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_QC_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs = 3000, 2400
+    out = tmp_path / "out"
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "conic", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.5&seed=31",
+        "--output_folder", str(out), "--tile_size", "256", "--overlap", "32", "--device", "cuda:0",
+        "--tissue_detection_model_path", str(tmp_path / "td.pth"),
+        "--artefact_detection_model_path", str(tmp_path / "art.pth"), "--filter_artefacts"])
+    predict_wsi.main(args)
+    cont = json.load(open(next(out.glob("*cell_contours.geojson"))))
+    tissue = json.load(open(next(out.glob("*tissue_contours.geojson"))))
+    art = json.load(open(next(out.glob("*artefact_contours.geojson"))))
+    assert len(tissue["features"]) == 1 and len(tissue["features"][0]["geometry"]["coordinates"]) == 2   # ellipse + hole
+    assert tissue["features"][0]["id"] == "tissue_0"
+    assert [m["name"] for m in tissue["features"][0]["properties"]["measurements"]] == ["area", "perimeter", "centroidX", "centroidY"]
+    assert len(art["features"]) == 1 and art["features"][0]["properties"]["classification"]["name"] == "artefact"
+    t_area = tissue["features"][0]["properties"]["measurements"][0]["value"]
+    ell_area = np.pi * 0.40 * W * 0.36 * Hs - np.pi * (0.06 * W) ** 2
+    assert abs(t_area - ell_area) / ell_area < 0.05
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    u, v = found[:, 0] / W, found[:, 1] / Hs
+
+    def in_tissue(u, v, grow):
+        ell = ((u - 0.5) / (0.40 + grow)) ** 2 + ((v - 0.5) / (0.36 + grow)) ** 2 <= 1.0
+        hole = (u - 0.62) ** 2 + ((v - 0.55) * Hs / W) ** 2 <= (0.06 - grow) ** 2
+        return ell & ~hole
+
+    def in_fold(u, v, grow):
+        return (u > 0.30 - grow) & (u < 0.42 + grow) & (v > 0.30 - grow) & (v < 0.45 + grow)
+    tol = 1.5 * 20 / W                                       # 1.5 thumbnail pixels of the 10 um/px tissue map
+    assert np.all(in_tissue(u, v, tol)) and not np.any(in_fold(u, v, -tol))
+    cx, cy, r, ident = synth.nuclei_in_region(31, 0, 0, W, Hs)
+    safe = in_tissue(cx / W, cy / Hs, -3 * tol) & ~in_fold(cx / W, cy / Hs, 3 * tol) & \
+        (cx > 300) & (cx < W - 300) & (cy > 300) & (cy < Hs - 300)
+    assert safe.sum() > 2000
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[safe], cy[safe]], 1))
+    # (a nucleus in a 4-tile corner overlap can lose every copy to the reference's greedy de-duplication)
+    assert (d < 1.5).mean() > 0.995 and len(np.unique(idx[d < 1.5])) == (d < 1.5).sum()

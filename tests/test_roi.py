@@ -108,3 +108,41 @@ def test_load_roi_polygons_and_filter(tmp_path):
     # (100,20) is on a boundary -> not within; (200,200) is outside everything
     assert [roi.get_cell_centroid(c) for c in kept] == [[10, 10], [75, 75], [75, 75], [305, 305], [410, 405]]
     assert roi.filter_cells_by_contours(cells, []) == cells
+
+
+def test_vectorised_predicates_match_scalar():
+    """numpy paths (long raster rings, many points) == the scalar definitions, incl. boundary points"""
+    from scipy import ndimage
+    from classpose_amd import grandqc
+    rng = np.random.default_rng(5)
+    m = (ndimage.gaussian_filter(rng.standard_normal((60, 80)), 3.0) > 0).astype(np.uint8)
+    cnts, parent = grandqc.find_contours_ccomp(m)
+    outer = int(np.argmax([len(c) if p == -1 else 0 for c, p in zip(cnts, parent)]))
+    poly = roi.RoiPolygon(cnts[outer] * 3.0, [cnts[j] * 3.0 for j in np.nonzero(parent == outer)[0]], validate=False)
+    assert len(poly.exterior) > 64
+    xs = np.concatenate([rng.uniform(-5, 245, 3000), rng.integers(0, 80, 500) * 3.0])   # random + on-lattice (boundary) points
+    ys = np.concatenate([rng.uniform(-5, 185, 3000), rng.integers(0, 60, 500) * 3.0])
+    got = poly.contains_points_strict(xs, ys)
+
+    def scalar_locate(p, x, y):
+        inside = False
+        for ring in p.rings:
+            ins = False
+            for k in range(len(ring) - 1):
+                a, b = ring[k], ring[k + 1]
+                if roi._orient(a, b, (x, y)) == 0 and roi._on_segment(a, b, (x, y)):
+                    return 0
+                if (a[1] > y) != (b[1] > y) and a[0] + (y - a[1]) * (b[0] - a[0]) / (b[1] - a[1]) > x:
+                    ins = not ins
+            inside ^= ins
+        return 1 if inside else -1
+    want = np.array([scalar_locate(poly, x, y) > 0 for x, y in zip(xs, ys)])
+    assert np.array_equal(got, want) and want.any() and not want.all()
+    assert all(poly.locate(x, y) == scalar_locate(poly, x, y) for x, y in zip(xs[::7], ys[::7]))
+    for _ in range(300):
+        x0, y0, s = rng.uniform(-20, 240), rng.uniform(-20, 180), rng.choice([2.0, 9.0, 40.0])
+        sq = [[x0, y0], [x0 + s, y0], [x0 + s, y0 + s], [x0, y0 + s], [x0, y0]]
+        brute = any(roi._segments_intersect(r[k], r[k + 1], sq[j], sq[j + 1])
+                    for r in poly.rings for k in range(len(r) - 1) for j in range(4)) \
+            or scalar_locate(poly, x0, y0) >= 0 or (x0 <= poly.exterior[0][0] <= x0 + s and y0 <= poly.exterior[0][1] <= y0 + s)
+        assert poly.intersects_square(x0, y0, s) == brute
