@@ -30,4 +30,9 @@ Parity status
   reference's call bottoms out in a library that IS in this image
   (``torch.nn.functional.grid_sample``, ``np.percentile``, ``scipy.ndimage``),
   the oracle calls that library itself rather than restating it.
+  Also unpinned: ``grandqc.py`` (``smp.UnetPlusPlus("timm-efficientnet-b0")`` of
+  segmentation-models-pytorch 0.3.1 / timm 0.4.12, restated from their published layer
+  tables; the reference's own test asserts output types only,
+  tests/test_grandqc_integration.py:39-124) and ``tiling.resize_linear_u8``
+  (opencv-python-headless 4.13 ``cv2.resize`` INTER_LINEAR).
 """
