@@ -140,9 +140,11 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     if args.roi_geojson:
         # ROI mode (predict_wsi.py:233-236,251-256,441-446): ROI-driven grid, tiles that miss
         # every ROI are skipped; ROI tiles may be smaller than --tile_size (one engine per size)
-        rois = roi.load_roi_polygons(args.roi_geojson)
-        if rois is None:
+        need_classes = bool(args.output_type) and "csv" in args.output_type
+        loaded = roi.load_roi_polygons(args.roi_geojson, group_by_class=need_classes)
+        if loaded is None:
             raise ValueError(f"no polygons in {args.roi_geojson}")
+        rois, plan.roi_class_dict = loaded if need_classes else (loaded, None)
         if plan.bounds != (0.0, 0.0):
             rois = [g.translate(*plan.bounds) for g in rois]
         coords = roi.get_coords_roi(rois, plan.read_tile_size, plan.read_overlap, args.overlap, plan.ts)
@@ -266,6 +268,7 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
         polygons = roi.filter_cells_by_contours(polygons, plan.rois)
         logger.info(f"Number of cells after filtering: {len(polygons)}")
     bx, by = plan.bounds
+    total_tissue_area = total_artefact_area = 0
     out = Path(args.output_folder)
     out.mkdir(parents=True, exist_ok=True)
     base = Path(args.slide_path.split("?")[0]).stem if "://" not in args.slide_path else \
@@ -279,7 +282,8 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
         for i, cnt in enumerate(shown):
             feats.extend(roi.polygon_to_geojson(cnt, id=f"tissue_{i}", object_type="annotation",
                                                 additional_properties={"classification": {"name": "tissue", "color": [0, 0, 0]}}))
-        logger.info(f"Total tissue area: {sum(c.area for c in shown)}")
+        total_tissue_area = sum(c.area for c in shown)
+        logger.info(f"Total tissue area: {total_tissue_area}")
         logger.info(f"Number of cells after filtering: {len(polygons)}")
         with open(out / get_geojson_output_filename("tissue_contours", base), "w") as f:
             json.dump({"type": "FeatureCollection", "features": feats}, f)
@@ -306,11 +310,29 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
             for i, poly in enumerate(art):
                 feats.extend(roi.polygon_to_geojson(poly, id=f"artefact_{i}", object_type="annotation",
                                                     additional_properties={"classification": {"name": "artefact", "color": [255, 0, 0]}}))
-            logger.info(f"Total artefact area: {sum(a.area for a in art)}")
+            total_artefact_area = sum(a.area for a in art)
+            logger.info(f"Total artefact area: {total_artefact_area}")
             with open(out / get_geojson_output_filename("artefact_contours", base), "w") as f:
                 json.dump({"type": "FeatureCollection", "features": feats}, f)
     if bx != 0 or by != 0:
         polygons = [geojson.apply_bounds_offset_to_feature(p, bx, by) for p in polygons]
+    if args.output_type and "csv" in args.output_type:
+        # predict_wsi.py:1786-1857: per-class counts and densities over the (tissue - artefact) area
+        from .. import outputs
+        if plan.roi_class_dict is not None:
+            if args.artefact_detection_model_path:
+                raise NotImplementedError("csv densities per ROI class with artefact detection need polygon "
+                                          "intersection areas (GEOS), which are not restated")
+            prio = [c.strip() for c in args.roi_class_priority] if args.roi_class_priority else None
+            by_class = outputs.map_cells_to_roi_classes(polygons, plan.roi_class_dict, prio)
+            df = outputs.calculate_cellular_densities(
+                by_class, {k: sum(p.area for p in v) for k, v in plan.roi_class_dict.items()},
+                {k: 0 for k in plan.roi_class_dict}, plan.mpp[0], plan.mpp[1], labels)
+        else:
+            df = outputs.calculate_cellular_densities(polygons, total_tissue_area, total_artefact_area,
+                                                      plan.mpp[0], plan.mpp[1], labels)
+        df.to_csv(out / f"{base}_cell_densities.csv", index=False)
+        logger.info(f"Saving cellular densities to {out}/{base}_cell_densities.csv")
     contours = out / get_geojson_output_filename("cell_contours", base)
     centroids = out / get_geojson_output_filename("cell_centroids", base)
     with open(contours, "w") as f:
@@ -322,8 +344,11 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
 
 
 def _check_unsupported(args):
-    if args.output_type:
-        raise NotImplementedError("--output_type csv / spatialdata is not built yet")
+    if args.output_type and "spatialdata" in args.output_type:
+        raise NotImplementedError("--output_type spatialdata needs the spatialdata / geopandas stack, which is not "
+                                  "available to this engine; csv is supported")
+    if args.output_type and args.tissue_detection_model_path is None:
+        raise ValueError(f"Tissue detection model path must be provided when using --output_type {args.output_type}")
     if args.tile_size < MIN_TILE_SIZE:
         raise ValueError(f"Tile size must be at least {MIN_TILE_SIZE}, got {args.tile_size}")
 

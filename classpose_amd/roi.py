@@ -383,6 +383,11 @@ def filter_cells_by_artefacts(cells: list[dict], artefact_polys: list[RoiPolygon
     return [cell for cell, h in zip(cells, hit) if not h], int(hit.sum())
 
 
+def get_artefact_class_id(class_name: str) -> int:
+    """predict_wsi.py:1203-1221"""
+    return {"Fold": 2, "Darkspot & Foreign Object": 3, "PenMarking": 4, "Edge & Air Bubble": 5, "OOF": 6}.get(class_name, 0)
+
+
 def get_cell_centroid(cell: dict) -> list[float]:
     m = cell["properties"]["measurements"]
     return [[x for x in m if x["name"] == "centroidX"][0]["value"],

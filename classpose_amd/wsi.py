@@ -82,6 +82,7 @@ class SlidePlan:
     coords: list
     rois: list | None = None
     tissue_cnts: list | None = None
+    roi_class_dict: dict | None = None
 
 
 def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePlan:

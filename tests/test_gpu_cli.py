@@ -198,16 +198,25 @@ def test_predict_wsi_cli_tissue_and_artefacts(cuda, tmp_path, monkeypatch):
         "--model_config", "conic", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.5&seed=31",
         "--output_folder", str(out), "--tile_size", "256", "--overlap", "32", "--device", "cuda:0",
         "--tissue_detection_model_path", str(tmp_path / "td.pth"),
-        "--artefact_detection_model_path", str(tmp_path / "art.pth"), "--filter_artefacts"])
+        "--artefact_detection_model_path", str(tmp_path / "art.pth"), "--filter_artefacts",
+        "--output_type", "csv"])
     predict_wsi.main(args)
+    import pandas as pd
+    df = pd.read_csv(next(out.glob("*_cell_densities.csv")))
+    assert list(df.columns) == ["region", "cell_class", "count", "density"] and len(df) == 6
+    assert set(df["region"]) == {"tissue"}
     cont = json.load(open(next(out.glob("*cell_contours.geojson"))))
     tissue = json.load(open(next(out.glob("*tissue_contours.geojson"))))
     art = json.load(open(next(out.glob("*artefact_contours.geojson"))))
+    assert df["count"].sum() == len(cont["features"])
     assert len(tissue["features"]) == 1 and len(tissue["features"][0]["geometry"]["coordinates"]) == 2   # ellipse + hole
     assert tissue["features"][0]["id"] == "tissue_0"
     assert [m["name"] for m in tissue["features"][0]["properties"]["measurements"]] == ["area", "perimeter", "centroidX", "centroidY"]
     assert len(art["features"]) == 1 and art["features"][0]["properties"]["classification"]["name"] == "artefact"
     t_area = tissue["features"][0]["properties"]["measurements"][0]["value"]
+    a_area = art["features"][0]["properties"]["measurements"][0]["value"]
+    eff_mm2 = (t_area - a_area) * 0.25 / 1e6
+    assert np.allclose(df["density"], df["count"] / eff_mm2)
     ell_area = np.pi * 0.40 * W * 0.36 * Hs - np.pi * (0.06 * W) ** 2
     assert abs(t_area - ell_area) / ell_area < 0.05
     found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]

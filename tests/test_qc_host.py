@@ -173,3 +173,34 @@ def test_resize_nearest_and_jpeg():
     j = grandqc.simulate_jpeg_compression(img)
     assert j.shape == img.shape and j.dtype == np.uint8 and not np.array_equal(j, img)
     assert np.abs(j.astype(int) - img.astype(int)).mean() < 12
+
+
+def test_densities_match_reference_golden(golden):
+    """calculate_cellular_densities / get_artefact_class_id vs vectors minted from the reference itself
+    (tests/golden/make_golden_outputs.py)"""
+    import json, os
+    from classpose_amd import outputs
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_outputs.json")))
+    for case in g["global_cases"]:
+        df = outputs.calculate_cellular_densities(case["cells"], case["tissue"], case["artefact"], case["mpp_x"],
+                                                  case["mpp_y"], g["labels"])
+        assert df.to_dict("records") == case["rows"]
+    rc = g["roi_case"]
+    df = outputs.calculate_cellular_densities(rc["cells"], rc["tissue"], rc["artefact"], rc["mpp_x"], rc["mpp_y"], g["labels"])
+    assert df.to_dict("records") == rc["rows"] and list(df.columns) == ["region", "cell_class", "count", "density"]
+    assert {n: roi.get_artefact_class_id(n) for n in g["artefact_class_ids"]} == g["artefact_class_ids"]
+
+
+def test_map_cells_to_roi_classes_priority():
+    from classpose_amd import outputs
+
+    def cell(x, y, name="a"):
+        ring = [[x - 1, y - 1], [x + 1, y - 1], [x + 1, y + 1], [x - 1, y + 1], [x - 1, y - 1]]
+        return {"geometry": {"coordinates": [ring]}, "properties": {"classification": {"name": name}}}
+    sq = lambda x0, y0, s: roi.RoiPolygon([[x0, y0], [x0 + s, y0], [x0 + s, y0 + s], [x0, y0 + s]])
+    classes = {"Tumour": [sq(0, 0, 100)], "Stroma": [sq(50, 50, 100)], "Necrosis": []}
+    cells = [cell(10, 10), cell(75, 75), cell(140, 140), cell(300, 300)]
+    m = outputs.map_cells_to_roi_classes(cells, classes)
+    assert [len(m[k]) for k in ("Tumour", "Stroma", "Necrosis")] == [2, 1, 0]
+    m = outputs.map_cells_to_roi_classes(cells, classes, ["Stroma", "Missing"])
+    assert [len(m[k]) for k in ("Tumour", "Stroma", "Necrosis")] == [1, 2, 0]
