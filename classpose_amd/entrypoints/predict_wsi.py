@@ -84,7 +84,10 @@ class TileStream:
         self.dev = device
         self.q: queue.Queue = queue.Queue(maxsize=depth)
         self.pinned = [torch.empty((nT, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(depth + 2)]
+        self.copied: dict = {}
         self.copy_stream = torch.cuda.Stream(device)
+        # region decoding (OpenSlide / the procedural slide) releases the GIL: read a batch's tiles in parallel
+        self.readers = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)))
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
@@ -93,12 +96,18 @@ class TileStream:
             for b, s in enumerate(range(0, len(self.idxs), self.nT)):
                 chunk = self.idxs[s:s + self.nT]
                 host = self.pinned[b % len(self.pinned)]
-                for k, ti in enumerate(chunk):
+                if b >= len(self.pinned):                   # its previous H2D copy must have left the buffer
+                    self.copied[b % len(self.pinned)].synchronize()
+
+                def read(k_ti):
+                    k, ti = k_ti
                     host[k].copy_(torch.from_numpy(wsi.read_tile(self.slide, self.plan, self.plan.coords[ti])))
+                list(self.readers.map(read, enumerate(chunk)))
                 with torch.cuda.stream(self.copy_stream):
                     dev = host[: len(chunk)].to(self.dev, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
+                self.copied[b % len(self.pinned)] = ev
                 self.q.put((chunk, dev, ev))
             self.q.put(None)
         except BaseException as e:      # surface reader errors in the consumer

@@ -102,6 +102,51 @@ def render_region(seed: int, x0: int, y0: int, w: int, h: int) -> np.ndarray:
     return np.clip(np.rint(base + noise), 0, 255).astype(np.uint8)
 
 
+def render_points(seed: int, xs: np.ndarray, ys: np.ndarray) -> np.ndarray:
+    """Pixels of the procedural slide at the grid xs x ys of absolute coordinates: uint8
+    (len(ys), len(xs), 3), identical to ``render_region`` at those pixels."""
+    xs, ys = np.asarray(xs, dtype=np.int64), np.asarray(ys, dtype=np.int64)
+    out = np.empty((len(ys), len(xs), 3), np.uint8)
+    gxs = np.floor_divide(xs, PITCH)
+    gys = np.floor_divide(ys, PITCH)
+    cs = np.arange(3, dtype=np.int64)[None, None, :]
+    # nuclei of every grid cell the samples can touch, hashed once: [gy - gy0][gx - gx0]
+    gx0, gx1, gy0, gy1 = int(gxs.min()) - 1, int(gxs.max()) + 1, int(gys.min()) - 1, int(gys.max()) + 1
+    tgx, tgy = np.meshgrid(np.arange(gx0, gx1 + 1), np.arange(gy0, gy1 + 1), indexing="xy")
+    kx, ky = tgx + (1 << 20), tgy + (1 << 20)
+    tcx = (tgx + 0.5) * PITCH + (_u01(_hash(seed, kx, ky, 1)) * 2 - 1) * JITTER
+    tcy = (tgy + 0.5) * PITCH + (_u01(_hash(seed, kx, ky, 2)) * 2 - 1) * JITTER
+    tr2 = (R_MIN + _u01(_hash(seed, kx, ky, 3)) * (R_MAX - R_MIN)) ** 2
+    rows = max(1, 500_000 // max(len(xs), 1))
+
+    def band(r0):
+        yb = ys[r0:r0 + rows]
+        gyb = gys[r0:r0 + rows]
+        inside = np.zeros((len(yb), len(xs)), bool)
+        for dy in (-1, 0, 1):
+            iy = (gyb + dy - gy0)[:, None]
+            for dx in (-1, 0, 1):
+                ix = (gxs + dx - gx0)[None, :]
+                inside |= (yb[:, None] - tcy[iy, ix]) ** 2 + (xs[None, :] - tcx[iy, ix]) ** 2 <= tr2[iy, ix]
+        base = np.where(inside[..., None], FG, BG)
+        yk = yb[:, None, None] + (1 << 20)
+        xk = xs[None, :, None] + (1 << 20)
+        u1 = _u01(_hash(seed, xk, yk, cs, 11))
+        u2 = _u01(_hash(seed, xk, yk, cs, 12))
+        noise = np.sqrt(-2.0 * np.log(u1)) * np.cos(2 * np.pi * u2) * NOISE_SIGMA
+        out[r0:r0 + rows] = np.clip(np.rint(base + noise), 0, 255).astype(np.uint8)
+
+    starts = list(range(0, len(ys), rows))
+    if len(starts) > 1:                       # numpy releases the GIL: bands run on the host cores
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as ex:
+            list(ex.map(band, starts))
+    else:
+        band(0)
+    return out
+
+
 def analytic_fields(seed: int, x0: int, y0: int, w: int, h: int, n_classes: int,
                     out_w: int | None = None, out_h: int | None = None):
     """Flow-injection tensors for the region, as the network would emit them.
@@ -172,13 +217,12 @@ class SyntheticSlide:
         return np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], axis=-1)
 
     def get_thumbnail(self, size) -> np.ndarray:
+        """nearest-pixel subsample of level 0 (the pixel function is evaluated at the sampled
+        coordinates only, so 10^4-px thumbnails of 10^4..10^5-px slides stay cheap)"""
         w, h = int(size[0]), int(size[1])
-        sx, sy = self.width / w, self.height / h
-        out = np.empty((h, w, 3), np.uint8)
-        for j in range(h):       # nearest-pixel subsample; thumbnails are tiny
-            row = render_region(self.seed, 0, int(j * sy), self.width, 1)[0]
-            out[j] = row[(np.arange(w) * sx).astype(np.int64)]
-        return out
+        xs = (np.arange(w) * (self.width / w)).astype(np.int64)
+        ys = (np.arange(h) * (self.height / h)).astype(np.int64)
+        return render_points(self.seed, xs, ys)
 
     def close(self) -> None:
         pass
