@@ -76,39 +76,54 @@ CELL_ROW = np.dtype([("area", "<f8"), ("perimeter", "<f8"), ("cx", "<f8"), ("cy"
 
 
 class TileStream:
-    """Reader thread: slide regions -> pinned host batches -> device (hipMemcpyAsync on a side
-    stream), double buffered so reads / copies overlap the engine."""
+    """Reader side of the tile loop: slide regions are decoded by a pool of threads (OpenSlide and the
+    procedural slide release the GIL) several batches ahead, land in pinned host batches and go to the
+    device with hipMemcpyAsync on a side stream, so reads / copies overlap the engine.  ``extra``
+    (optional) computes per-tile side inputs in the same pool (flow-injection tests)."""
 
-    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3):
+    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3, extra=None):
         self.slide, self.plan, self.idxs, self.nT = slide, plan, list(idxs), nT
-        self.dev = device
+        self.dev, self.extra = device, extra
+        n_workers = max(2, min(32, (os.cpu_count() or 4) // 2))
+        self.ahead = max(depth, -(-n_workers // max(nT, 1)))        # batches being decoded at once
         self.q: queue.Queue = queue.Queue(maxsize=depth)
-        self.pinned = [torch.empty((nT, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(depth + 2)]
+        self.pinned = [torch.empty((nT, H, W, 3), dtype=torch.uint8).pin_memory()
+                       for _ in range(self.ahead + depth + 2)]
         self.copied: dict = {}
         self.copy_stream = torch.cuda.Stream(device)
-        # region decoding (OpenSlide / the procedural slide) releases the GIL: read a batch's tiles in parallel
-        self.readers = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)))
+        self.readers = ThreadPoolExecutor(max_workers=n_workers)
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
+    def _submit(self, b):
+        chunk = self.idxs[b * self.nT:(b + 1) * self.nT]
+        slot = b % len(self.pinned)
+        if slot in self.copied:                                  # its previous H2D copy must have left the buffer
+            self.copied.pop(slot).synchronize()
+        host = self.pinned[slot]
+
+        def read(k, ti):
+            host[k].copy_(torch.from_numpy(wsi.read_tile(self.slide, self.plan, self.plan.coords[ti])))
+            return self.extra(ti) if self.extra is not None else None
+        return chunk, slot, [self.readers.submit(read, k, ti) for k, ti in enumerate(chunk)]
+
     def _run(self):
         try:
-            for b, s in enumerate(range(0, len(self.idxs), self.nT)):
-                chunk = self.idxs[s:s + self.nT]
-                host = self.pinned[b % len(self.pinned)]
-                if b >= len(self.pinned):                   # its previous H2D copy must have left the buffer
-                    self.copied[b % len(self.pinned)].synchronize()
-
-                def read(k_ti):
-                    k, ti = k_ti
-                    host[k].copy_(torch.from_numpy(wsi.read_tile(self.slide, self.plan, self.plan.coords[ti])))
-                list(self.readers.map(read, enumerate(chunk)))
+            n_batches = -(-len(self.idxs) // self.nT)
+            pending = []
+            nxt = 0
+            while nxt < n_batches or pending:
+                while nxt < n_batches and len(pending) < self.ahead:
+                    pending.append(self._submit(nxt))
+                    nxt += 1
+                chunk, slot, futs = pending.pop(0)
+                extras = [f.result() for f in futs]
                 with torch.cuda.stream(self.copy_stream):
-                    dev = host[: len(chunk)].to(self.dev, non_blocking=True)
+                    dev = self.pinned[slot][: len(chunk)].to(self.dev, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
-                self.copied[b % len(self.pinned)] = ev
-                self.q.put((chunk, dev, ev))
+                self.copied[slot] = ev
+                self.q.put((chunk, dev, ev, extras))
             self.q.put(None)
         except BaseException as e:      # surface reader errors in the consumer
             self.q.put(e)
@@ -194,20 +209,20 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
         nT = max(1, max(args.batch_size, 32) // n_sub)
         eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
-        stream = TileStream(slide, plan, idxs, nT, R, R, device)
-        for chunk, tiles_dev, ev in stream:
-            torch.cuda.current_stream(device).wait_event(ev)
+        extra = None
+        if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
+            # test / bench mode for synthetic slides with random weights: the dynamics consume
+            # analytic fields of the procedural nuclei, the network still runs on the pixels
+            from .. import synth
+
+            def extra(ti, R=R, W=W, H=H):
+                return synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R,
+                                             n_classes, W, H)
+        stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra)
+        def collect(sid, chunk, keep_alive):
+            nonlocal n_done
             n = len(chunk)
-            tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
-            inject = None
-            if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
-                # test / bench mode for synthetic slides with random weights: the dynamics consume
-                # analytic fields of the procedural nuclei, the network still runs on the pixels
-                from .. import synth
-                f = [synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R,
-                                           n_classes, W, H) for ti in chunk]
-                inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
-            out = eng.run(tiles_dev, inject=inject, records=True)
+            out = eng.result(sid)
             masks = out.masks.cpu().numpy().view(np.uint16)          # D2H: 2 B / pixel
             recs = eng.fetch_records(n, out)
             if int(out.nlabels.max()) >= 65535:
@@ -220,6 +235,20 @@ def run_rank(args, rank: int, world: int, device: torch.device):
             if rank == 0 and (n_done // nT) % 20 == 0:
                 logger.info(f"Predicted tiles: {n_done}/{len(mine)} "
                             f"({n_done / max(time.time() - t0, 1e-9):.1f} tiles/s/GPU)")
+
+        in_flight = None                     # one batch runs on the device while the previous one is collected
+        for chunk, tiles_dev, ev, f in stream:
+            torch.cuda.current_stream(device).wait_event(ev)
+            tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
+            inject = None
+            if extra is not None:
+                inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
+            sid = eng.submit(tiles_dev, inject=inject, records=True)
+            if in_flight is not None:
+                collect(*in_flight)
+            in_flight = (sid, chunk, (tiles_dev, inject))
+        if in_flight is not None:
+            collect(*in_flight)
         del eng, stream
     cells_all, xy_all, n_invalid = [], [], 0
     for f in futures:
