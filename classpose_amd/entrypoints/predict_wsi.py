@@ -140,7 +140,10 @@ class TileStream:
 
 def run_rank(args, rank: int, world: int, device: torch.device):
     """Everything one GPU does; returns (cell table, vertex pool) of this rank's shard."""
-    if args.model_config in DEFAULT_MODEL_CONFIGS:
+    if getattr(args, "model_path", None) is not None:
+        # predict_wsi_cpsam: a plain Cellpose-SAM checkpoint, no semantic head, every cell is "cell"
+        model_config = ModelConfig(path=args.model_path, url=None, mpp=args.train_mpp, cell_types=[])
+    elif args.model_config in DEFAULT_MODEL_CONFIGS:
         model_config = ModelConfig(**DEFAULT_MODEL_CONFIGS[args.model_config])
     else:
         model_config = ModelConfig.load_from_yaml(args.model_config)
@@ -148,7 +151,12 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     torch.cuda.set_device(device)
     sd = model_config.load_state_dict()
     fts, n_classes, _ = engine.NetWeights.infer_structure(sd)
-    if model_config.cell_types:
+    if getattr(args, "model_path", None) is not None:
+        if n_classes > 1:
+            raise ValueError("--model_path expects a Cellpose-SAM checkpoint without a class head; "
+                             "use classpose-predict-wsi --model_config for Classpose models")
+        labels = None
+    elif model_config.cell_types:
         if len(model_config.cell_types) != n_classes - 1:
             raise ValueError(f"Number of labels ({len(model_config.cell_types)}) does not match "
                              f"number of classes ({n_classes - 1})")
@@ -365,10 +373,10 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
             by_class = outputs.map_cells_to_roi_classes(polygons, plan.roi_class_dict, prio)
             df = outputs.calculate_cellular_densities(
                 by_class, {k: sum(p.area for p in v) for k, v in plan.roi_class_dict.items()},
-                {k: 0 for k in plan.roi_class_dict}, plan.mpp[0], plan.mpp[1], labels)
+                {k: 0 for k in plan.roi_class_dict}, plan.mpp[0], plan.mpp[1], labels or ["cell"])
         else:
             df = outputs.calculate_cellular_densities(polygons, total_tissue_area, total_artefact_area,
-                                                      plan.mpp[0], plan.mpp[1], labels)
+                                                      plan.mpp[0], plan.mpp[1], labels or ["cell"])
         df.to_csv(out / f"{base}_cell_densities.csv", index=False)
         logger.info(f"Saving cellular densities to {out}/{base}_cell_densities.csv")
     contours = out / get_geojson_output_filename("cell_contours", base)
@@ -391,13 +399,16 @@ def _check_unsupported(args):
         raise ValueError(f"Tile size must be at least {MIN_TILE_SIZE}, got {args.tile_size}")
 
 
-def _spawn_entry(local_rank: int, world: int, port: int, argv: list[str], dev_ids: list[int]):
+def _spawn_entry(local_rank: int, world: int, port: int, argv: list[str], dev_ids: list[int], parser_factory=None):
     os.environ.update(RANK=str(local_rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev_ids[local_rank]),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    main(build_parser().parse_args(argv), spawned=True)
+    args = (parser_factory or build_parser)().parse_args(argv)
+    if not hasattr(args, "model_config"):
+        args.model_config = None
+    main(args, spawned=True)
 
 
-def main(args, spawned: bool = False):
+def main(args, spawned: bool = False, parser_factory=None):
     _check_unsupported(args)
     devices = get_device(args.device)
     env_world = int(os.environ.get("WORLD_SIZE", 1))
@@ -406,7 +417,7 @@ def main(args, spawned: bool = False):
         import torch.multiprocessing as mp
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         ids = [d.index or 0 for d in devices]
-        mp.start_processes(_spawn_entry, args=(len(devices), port, sys.argv[1:], ids),
+        mp.start_processes(_spawn_entry, args=(len(devices), port, sys.argv[1:], ids, parser_factory),
                            nprocs=len(devices), start_method="spawn")
         return
     rank, world, local = parallel.init_distributed()

@@ -279,6 +279,8 @@ def make_state_dict(n_classes: int = 7, fts: list[int] | None = None, depth: int
     sd["W2"] = torch.eye(192).reshape(192, 3, 8, 8)
     sd["diam_labels"] = torch.tensor([30.0])
     sd["diam_mean"] = torch.tensor([30.0])
+    if n_classes <= 1:                       # plain Cellpose-SAM checkpoint (cpsam): no semantic head
+        return sd
     oc = n_classes * 64
     if fts is None:
         sd["out_class.weight"] = rn(oc, 256, 1, 1, std=1.0 / np.sqrt(256))

@@ -240,3 +240,29 @@ def test_predict_wsi_cli_tissue_and_artefacts(cuda, tmp_path, monkeypatch):
     d, idx = cKDTree(found).query(np.stack([cx[safe], cy[safe]], 1))
     # (a nucleus in a 4-tile corner overlap can lose every copy to the reference's greedy de-duplication)
     assert (d < 1.5).mean() > 0.995 and len(np.unique(idx[d < 1.5])) == (d < 1.5).sum()
+
+
+def test_predict_wsi_cpsam_cli(cuda, tmp_path, monkeypatch):
+    """class-less Cellpose-SAM entry point: --model_path / --train_mpp, every polygon is a "cell" """
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    from classpose_amd.entrypoints import predict_wsi_cpsam
+    W, Hs = 800, 600
+    args = predict_wsi_cpsam.build_parser().parse_args([
+        "--model_path", str(tmp_path / "cpsam"), "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.5&seed=3",
+        "--output_folder", str(tmp_path), "--tile_size", "256", "--overlap", "32", "--device", "cuda:0"])
+    predict_wsi_cpsam.main(args)
+    cont = json.load(open(next(tmp_path.glob("*contours.geojson"))))
+    assert len(cont["features"]) > 100
+    assert {f["properties"]["classification"]["name"] for f in cont["features"]} == {"cell"}
+    assert cont["features"][0]["properties"]["classification"]["color"] == [0, 168, 132]
+    nx, ny = (W - 256) // 224 + 1, (Hs - 256) // 224 + 1
+    cov_w, cov_h = (nx - 1) * 224 + 256, (ny - 1) * 224 + 256
+    cx, cy, r, _ = synth.nuclei_in_region(3, 0, 0, cov_w, cov_h)
+    inner = (cx - r > 12) & (cx + r < cov_w - 12) & (cy - r > 12) & (cy + r < cov_h - 12)
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[inner], cy[inner]], 1))
+    assert (d < 1.5).mean() > 0.99
