@@ -14,8 +14,8 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, qc_arch as A
-from ._lib import CpxQcOp, check, ptr
+from .. import _lib, qc_arch as A
+from .._lib import CpxQcOp, check, ptr
 
 NONE = C.c_size_t(-1).value
 
@@ -267,7 +267,7 @@ import os
 import pickle
 import uuid
 
-from .log import get_logger
+from ..log import get_logger
 
 grandqc_logger = get_logger("classpose.grandqc")
 
@@ -340,7 +340,7 @@ def load_qc_state_dict(path: str, n_classes: int, seed: int) -> dict:
     synthetic weights are used when CLASSPOSE_SYNTHETIC_WEIGHTS=1, else FileNotFoundError."""
     if not os.path.exists(path):
         if os.getenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "0") == "1":
-            from . import synth
+            from .. import synth
             grandqc_logger.warning(f"No weights at {path}: using seeded synthetic GrandQC weights")
             return synth.make_grandqc_state_dict(n_classes, seed)
         raise FileNotFoundError(f"{path} not found (downloads are not available: fetch the GrandQC checkpoint "
@@ -368,7 +368,7 @@ def simulate_jpeg_compression(image: np.ndarray) -> np.ndarray:
 
 
 def extract_slide_info(slide, mpp_model: float):
-    from .wsi import get_slide_resolution
+    from ..wsi import get_slide_resolution
     w_l0, h_l0 = slide.level_dimensions[0]
     mpp = get_slide_resolution(slide)[0]
     reduction_factor = mpp_model / mpp
@@ -380,6 +380,27 @@ def _thumbnail_rgb(slide, dims) -> np.ndarray:
     if not isinstance(img, np.ndarray):
         img = np.asarray(img.convert("RGB"))
     return np.ascontiguousarray(img[..., :3])
+
+
+def make_class_map(mask: np.ndarray, class_colors: list[list[int]]) -> np.ndarray:
+    """wsi_qc_helpers.make_class_map: class index -> RGB"""
+    lut = np.zeros((256, 3), np.uint8)
+    lut[: len(class_colors)] = np.asarray(class_colors, dtype=np.uint8)
+    return lut[np.asarray(mask).astype(np.uint8)]
+
+
+def draw_contour_outlines(shape, contours, thickness: int = 10) -> np.ndarray:
+    """``cv2.drawContours(img, [cnt], 0, 255, thickness=10)`` for the diagnostic ``filled_class_map``
+    image (wsi_tissue_detection.py:239): closed polylines of the given thickness, drawn with PIL
+    (OpenCV's exact line rasteriser is not restated; nothing downstream reads this image)."""
+    from PIL import Image, ImageDraw
+    img = Image.new("L", (shape[1], shape[0]), 0)
+    d = ImageDraw.Draw(img)
+    for c in contours:
+        pts = [tuple(map(float, p)) for p in np.asarray(c)]
+        if len(pts) >= 2:
+            d.line(pts + [pts[0]], fill=255, width=thickness, joint="curve")
+    return np.asarray(img)
 
 
 def resize_nearest(mask: np.ndarray, width: int, height: int) -> np.ndarray:
@@ -536,8 +557,8 @@ def detect_tissue_wsi(slide, model_td_path="./models/tissue_detection/Tissue_Det
                       mpp_model_td: int = 10, m_p_s_model_td: int = 512, device="cuda:0", min_area: int = 0,
                       apply_bounds_offset: bool = False, class_map_override=None):
     """Same return tuple as the reference: (image, filtered_mask, filled_class_map, output_cnts,
-    geojson, mpp_model_td).  ``filled_class_map`` (a cv2.drawContours rendering nothing downstream
-    reads) is returned as zeros.  ``class_map_override(image) -> int8 map`` replaces the network's
+    geojson, mpp_model_td).  ``filled_class_map`` is the contour-outline rendering (thickness 10) of
+    ``draw_contour_outlines``.  ``class_map_override(image) -> int8 map`` replaces the network's
     decision in flow-injection style tests (the network still runs)."""
     net = _as_net(model_td_path, 2, device, seed=101)
     bx = float(slide.properties.get("openslide.bounds-x", 0.0))
@@ -550,7 +571,8 @@ def detect_tissue_wsi(slide, model_td_path="./models/tissue_detection/Tissue_Det
     if class_map_override is not None:
         class_map = np.asarray(class_map_override(image), dtype=np.int8)
     filtered, output_cnts = tissue_contours(class_map, mpp_model_td, min_area, (w_l0 / width, h_l0 / height))
-    filled = np.zeros_like(filtered)
+    filled = draw_contour_outlines(filtered.shape, [c["contour"] / np.array([w_l0 / width, h_l0 / height])
+                                                    for c in output_cnts.values()], 10)
     if not output_cnts:
         grandqc_logger.warning("No tissue contours detected in slide.")
         return image, filtered, filled, {}, {"type": "FeatureCollection", "features": []}, mpp_model_td
@@ -625,8 +647,8 @@ def detect_artefacts_wsi(slide, model_art_path="./models/artefact_detection/Gran
                          model_td_path="./models/tissue_detection/Tissue_Detection_MPP10.pth", mpp_model_td: int = 10,
                          m_p_s_model_td: int = 512, min_area: int = 0, apply_bounds_offset: bool = False,
                          tissue_override=None, artefact_override=None):
-    """(artefact_mask, artefact_map, artefact_cnts, geojson) like the reference; ``artefact_map`` (a
-    LANCZOS-resized colour rendering nothing downstream reads) is None."""
+    """(artefact_mask, artefact_map, artefact_cnts, geojson) like the reference; ``artefact_map`` is
+    the colour rendering resized to 50 px per patch with PIL LANCZOS (:232-239)."""
     grandqc_logger.info("Performing tissue detection...")
     _, tissue_mask, _, _, _, _ = detect_tissue_wsi(slide, model_td_path, mpp_model_td, m_p_s_model_td, device,
                                                    min_area, False, class_map_override=tissue_override)
@@ -642,4 +664,7 @@ def detect_artefacts_wsi(slide, model_art_path="./models/artefact_detection/Gran
     artefact_cnts, geojson = artefact_contours(artefact_mask, (w_l0 / width, h_l0 / height))
     if apply_bounds_offset and (bx != 0 or by != 0):
         _shift_outputs(artefact_cnts, geojson, bx, by)
-    return artefact_mask, None, artefact_cnts, geojson
+    from PIL import Image
+    amap = Image.fromarray(make_class_map(artefact_mask, ARTIFACT_COLORS)).resize(
+        (max(1, int(width * 50 / m_p_s_model_art)), max(1, int(height * 50 / m_p_s_model_art))), Image.Resampling.LANCZOS)
+    return artefact_mask, np.array(amap), artefact_cnts, geojson
