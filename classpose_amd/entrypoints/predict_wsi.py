@@ -263,8 +263,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         cells, xy = f.result()
         keep = cells["valid"] == 1
         n_invalid += int((~keep).sum())
-        for c in cells[keep]:
-            xy_all.append(xy[c["offset"]: c["offset"] + c["n_pts"]])
+        xy_all.append(geojson.gather_vertices(xy, cells["offset"][keep], cells["n_pts"][keep]))
         rows = np.zeros(int(keep.sum()), CELL_ROW)
         for name in ("area", "perimeter", "cx", "cy", "n_pts", "cls"):
             rows[name] = cells[keep][name]
@@ -296,23 +295,27 @@ def _qc_override(kind: str):
 
 
 def write_outputs(args, cells, xy, labels, plan, device=None):
-    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])]).astype(np.int64)
-    curr = []
-    for i, c in enumerate(cells):
-        coords = xy[offs[i]: offs[i + 1]].tolist()
-        centroid = np.round([c["cx"], c["cy"]], 2).tolist()
-        curr.append(geojson.cell_dict(coords, int(c["cls"]), labels, c["area"], c["perimeter"], centroid))
-    polygons = [geojson.to_geojson_polygon(x) for x in curr]
-    logger.info(f"Number of detected cells: {len(polygons)}")
-    if len(polygons) == 0:
+    """De-duplication, ROI / tissue / artefact filters and the output files, on the cell table
+    (struct of arrays): same results as the reference's list-of-dict pipeline
+    (predict_wsi.py:1600-1857; ``tests/test_host_polygons_geojson.py`` checks the equivalence)."""
+    logger.info(f"Number of detected cells: {len(cells)}")
+    if len(cells) == 0:
         logger.warning("No cells detected")
         return None
-    polygons = geojson.deduplicate(polygons)
-    logger.info(f"Number of cells after de-duplication: {len(polygons)}")
+    cen = geojson.rounded_centroids(cells)
+    keep = np.asarray(geojson.dedup_indices(cen, cells["area"]), dtype=np.int64)
+    logger.info(f"Number of cells after de-duplication: {len(keep)}")
+
+    def filter_within(keep, polys):          # STRtree.query(points, "within"): one hit per containing polygon
+        counts = np.zeros(len(keep), np.int64)
+        for c in polys:
+            counts += c.contains_points_strict(cen[keep, 0], cen[keep, 1])
+        return np.repeat(keep, counts)
+
     if getattr(plan, "rois", None):
         logger.info("Filtering cells based on ROI contours")
-        polygons = roi.filter_cells_by_contours(polygons, plan.rois)
-        logger.info(f"Number of cells after filtering: {len(polygons)}")
+        keep = filter_within(keep, plan.rois)
+        logger.info(f"Number of cells after filtering: {len(keep)}")
     bx, by = plan.bounds
     total_tissue_area = total_artefact_area = 0
     out = Path(args.output_folder)
@@ -322,7 +325,7 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
     if plan.tissue_cnts is not None:
         # predict_wsi.py:1637-1676: tissue filter + <stem>_tissue_contours.geojson (display coordinates)
         logger.info("Filtering cells based on tissue contours")
-        polygons = roi.filter_cells_by_contours(polygons, plan.tissue_cnts)
+        keep = filter_within(keep, plan.tissue_cnts)
         shown = [c.translate(-bx, -by) for c in plan.tissue_cnts] if (bx != 0 or by != 0) else plan.tissue_cnts
         feats = []
         for i, cnt in enumerate(shown):
@@ -330,7 +333,7 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
                                                 additional_properties={"classification": {"name": "tissue", "color": [0, 0, 0]}}))
         total_tissue_area = sum(c.area for c in shown)
         logger.info(f"Total tissue area: {total_tissue_area}")
-        logger.info(f"Number of cells after filtering: {len(polygons)}")
+        logger.info(f"Number of cells after filtering: {len(keep)}")
         with open(out / get_geojson_output_filename("tissue_contours", base), "w") as f:
             json.dump({"type": "FeatureCollection", "features": feats}, f)
     if args.artefact_detection_model_path is not None:
@@ -346,10 +349,13 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
                 tissue_override=_qc_override("tissue"), artefact_override=_qc_override("artefact"))
             logger.info(f"Found {len(artefact_cnts)} artefact contours")
             art = roi.polygons_from_cnts(artefact_cnts)
-            if args.filter_artefacts:
-                polygons, removed = roi.filter_cells_by_artefacts(polygons, art)
-                logger.info(f"Removed {removed} cells in artefact regions")
-                logger.info(f"Cells remaining after artefact filtering: {len(polygons)}")
+            if args.filter_artefacts and art:
+                hit = np.zeros(len(keep), bool)
+                for a in art:
+                    hit |= a.contains_points_strict(cen[keep, 0], cen[keep, 1])
+                keep = keep[~hit]
+                logger.info(f"Removed {int(hit.sum())} cells in artefact regions")
+                logger.info(f"Cells remaining after artefact filtering: {len(keep)}")
             if bx != 0 or by != 0:
                 art = [a.translate(-bx, -by) for a in art]
             feats = []
@@ -360,31 +366,33 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
             logger.info(f"Total artefact area: {total_artefact_area}")
             with open(out / get_geojson_output_filename("artefact_contours", base), "w") as f:
                 json.dump({"type": "FeatureCollection", "features": feats}, f)
-    if bx != 0 or by != 0:
-        polygons = [geojson.apply_bounds_offset_to_feature(p, bx, by) for p in polygons]
     if args.output_type and "csv" in args.output_type:
         # predict_wsi.py:1786-1857: per-class counts and densities over the (tissue - artefact) area
         from .. import outputs
+        dens_labels = labels or ["cell"]
+        names = np.array([(labels[int(c) - 1] if labels is not None else "cell") for c in cells["cls"][keep]], dtype=object)
         if plan.roi_class_dict is not None:
             if args.artefact_detection_model_path:
                 raise NotImplementedError("csv densities per ROI class with artefact detection need polygon "
                                           "intersection areas (GEOS), which are not restated")
             prio = [c.strip() for c in args.roi_class_priority] if args.roi_class_priority else None
-            by_class = outputs.map_cells_to_roi_classes(polygons, plan.roi_class_dict, prio)
+            # polygon centroids (unrounded; the bounds offset is applied like the reference does before this step)
+            region = outputs.map_points_to_roi_classes(cells["cx"][keep] - bx, cells["cy"][keep] - by,
+                                                       plan.roi_class_dict, prio)
+            by_class = {k: [{"properties": {"classification": {"name": nm}}} for nm in names[region == k]]
+                        for k in plan.roi_class_dict}
             df = outputs.calculate_cellular_densities(
                 by_class, {k: sum(p.area for p in v) for k, v in plan.roi_class_dict.items()},
-                {k: 0 for k in plan.roi_class_dict}, plan.mpp[0], plan.mpp[1], labels or ["cell"])
+                {k: 0 for k in plan.roi_class_dict}, plan.mpp[0], plan.mpp[1], dens_labels)
         else:
-            df = outputs.calculate_cellular_densities(polygons, total_tissue_area, total_artefact_area,
-                                                      plan.mpp[0], plan.mpp[1], labels or ["cell"])
+            df = outputs.densities_from_counts("tissue", {l: int((names == l).sum()) for l in dens_labels},
+                                               total_tissue_area, total_artefact_area, plan.mpp[0], plan.mpp[1],
+                                               dens_labels)
         df.to_csv(out / f"{base}_cell_densities.csv", index=False)
         logger.info(f"Saving cellular densities to {out}/{base}_cell_densities.csv")
     contours = out / get_geojson_output_filename("cell_contours", base)
     centroids = out / get_geojson_output_filename("cell_centroids", base)
-    with open(contours, "w") as f:
-        json.dump({"type": "FeatureCollection", "features": polygons}, f)
-    with open(centroids, "w") as f:
-        json.dump({"type": "FeatureCollection", "features": geojson.polygons_to_centroids(polygons)}, f)
+    geojson.write_feature_collections(contours, centroids, cells, xy, keep, labels, (bx, by))
     logger.info(f"Wrote {contours} and {centroids}")
     return contours, centroids
 

@@ -116,3 +116,74 @@ def polygons_to_centroids(cells: list[dict]) -> list[dict]:
                            "measurements": cell["properties"]["measurements"]},
         })
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# struct-of-arrays path of the CLI: the same features as the dict functions above, serialised
+# straight from the cell table (no per-cell Python dicts are held: a 40k^2 slide has ~10^6 cells)
+# ---------------------------------------------------------------------------------------------
+def gather_vertices(xy: np.ndarray, offsets: np.ndarray, n_pts: np.ndarray) -> np.ndarray:
+    """rows xy[offsets[i] : offsets[i] + n_pts[i]] of every i, concatenated (vectorised)"""
+    n_pts = np.asarray(n_pts, dtype=np.int64)
+    total = int(n_pts.sum())
+    if total == 0:
+        return np.zeros((0, 2), xy.dtype)
+    starts = np.repeat(np.asarray(offsets, dtype=np.int64) - np.concatenate([[0], np.cumsum(n_pts)[:-1]]), n_pts)
+    return xy[starts + np.arange(total)]
+
+
+def rounded_centroids(cells: np.ndarray) -> np.ndarray:
+    """``np.round(polygon.centroid.coords[0], 2)`` (predict_wsi.py:629) for the whole table"""
+    return np.stack([np.round(cells["cx"], 2), np.round(cells["cy"], 2)], 1)
+
+
+def _fmt(v) -> str:
+    return repr(float(v))
+
+
+def write_feature_collections(contours_path, centroids_path, cells: np.ndarray, xy: np.ndarray, keep,
+                              labels: list[str] | None, bounds=(0.0, 0.0)) -> int:
+    """Writes ``{"type": "FeatureCollection", "features": [...]}`` for the cells ``keep`` (indices into
+    the table, repeats allowed) exactly as ``json.dump`` of ``to_geojson_polygon`` /
+    ``polygons_to_centroids`` features (after ``apply_bounds_offset_to_feature``) would, streaming."""
+    import json
+    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])]).astype(np.int64)
+    cen = rounded_centroids(cells)
+    bx, by = float(bounds[0]), float(bounds[1])
+    shift = bx != 0 or by != 0
+    dumps = json.dumps
+    n = 0
+    with open(contours_path, "w") as fc, open(centroids_path, "w") as fp:
+        fc.write('{"type": "FeatureCollection", "features": [')
+        fp.write('{"type": "FeatureCollection", "features": [')
+        for i in keep:
+            i = int(i)
+            c = cells[i]
+            ring = xy[offs[i]: offs[i + 1]]
+            if shift:
+                ring = ring - np.array([bx, by])
+            pts = ring.tolist()
+            pts.append(list(pts[0]))
+            cl = int(c["cls"])
+            if labels is not None:
+                name, color = labels[cl - 1], COLORMAP[cl - 1]
+            else:
+                name, color = "cell", [0, 168, 132]
+            cx, cy = float(cen[i, 0]), float(cen[i, 1])
+            if shift:
+                cx, cy = cx - bx, cy - by
+            meas = ('[{"name": "area", "value": %s}, {"name": "perimeter", "value": %s}, '
+                    '{"name": "centroidX", "value": %s}, {"name": "centroidY", "value": %s}]'
+                    % (_fmt(c["area"]), _fmt(c["perimeter"]), _fmt(cx), _fmt(cy)))
+            cls_json = '{"name": %s, "color": %s}' % (dumps(name), dumps(color))
+            sep = ", " if n else ""
+            fc.write('%s{"type": "Feature", "id": "%s", "geometry": {"type": "Polygon", "coordinates": [%s]}, '
+                     '"properties": {"objectType": "annotation", "isLocked": false, "classification": %s, '
+                     '"measurements": %s}}' % (sep, uuid.uuid4(), dumps(pts), cls_json, meas))
+            fp.write('%s{"type": "Feature", "id": "%s", "geometry": {"type": "Point", "coordinates": [%s, %s]}, '
+                     '"properties": {"objectType": "annotation", "isLocked": false, "classification": %s, '
+                     '"measurements": %s}}' % (sep, uuid.uuid4(), _fmt(cx), _fmt(cy), cls_json, meas))
+            n += 1
+        fc.write("]}")
+        fp.write("]}")
+    return n

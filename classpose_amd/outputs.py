@@ -42,6 +42,30 @@ def map_cells_to_roi_classes(cells: list[dict], roi_class_dict: dict[str, list],
     return result
 
 
+def map_points_to_roi_classes(xs, ys, roi_class_dict: dict[str, list], priority_list=None):
+    """array form of ``map_cells_to_roi_classes``: region name per point (None when no class contains it)"""
+    import numpy as np
+    if priority_list:
+        ordered = [c for c in priority_list if c in roi_class_dict] + \
+                  [c for c in roi_class_dict if c not in priority_list]
+    else:
+        ordered = list(roi_class_dict.keys())
+    region = np.full(len(xs), None, dtype=object)
+    for name in ordered:
+        hit = np.zeros(len(xs), bool)
+        for p in roi_class_dict.get(name, []):
+            hit |= p.contains_points_strict(xs, ys)
+        region[hit & (region == None)] = name            # noqa: E711  (object array comparison)
+    return region
+
+
+def densities_from_counts(region: str, counts: dict, tissue_area_pixels, artefact_area_pixels, mpp_x: float,
+                          mpp_y: float, labels: list[str]) -> pd.DataFrame:
+    eff_mm2 = (tissue_area_pixels - artefact_area_pixels) * (mpp_x * mpp_y) / 1e6
+    return pd.DataFrame([{"region": region, "cell_class": l, "count": counts.get(l, 0),
+                          "density": counts.get(l, 0) / eff_mm2 if eff_mm2 > 0 else 0} for l in labels])
+
+
 def calculate_cellular_densities(cells, tissue_area_pixels, artefact_area_pixels, mpp_x: float, mpp_y: float,
                                  labels: list[str]) -> pd.DataFrame:
     """rows (region, cell_class, count, density [cells/mm^2]); density = count / ((tissue - artefact)

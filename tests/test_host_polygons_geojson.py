@@ -92,3 +92,59 @@ def test_cell_dict_class_zero_indexes_last_label():
     assert d["coords"][0] == d["coords"][-1] and len(d["coords"]) == 5
     d = geojson.cell_dict([[0, 0], [1, 0], [1, 1], [0, 1]], 2, ["A", "B", "C"], 1.0, 4.0, [0.5, 0.5])
     assert d["label"] == "B" and d["color"] == [255, 255, 179]
+
+
+def test_streaming_writer_equals_dict_pipeline(tmp_path):
+    """the CLI's struct-of-arrays path (dedup on rounded centroids, bounds offset, streamed JSON) produces
+    the same FeatureCollections as the reference-shaped list-of-dict functions + json.dump"""
+    import json
+    from classpose_amd.entrypoints.predict_wsi import CELL_ROW
+    rng = np.random.default_rng(4)
+    n = 400
+    labels = ["a", "b", "c"]
+    cells = np.zeros(n, CELL_ROW)
+    cells["n_pts"] = rng.integers(4, 9, n)
+    cells["cls"] = rng.integers(0, 4, n)                    # includes class 0 -> labels[-1]
+    cells["area"] = rng.uniform(20, 300, n)
+    cells["perimeter"] = rng.uniform(10, 80, n)
+    cells["cx"] = rng.uniform(0, 300, n)
+    cells["cy"] = rng.uniform(0, 300, n)
+    cells["cx"][50:80] = cells["cx"][20:50] + rng.uniform(-3, 3, 30)      # near-duplicates
+    cells["cy"][50:80] = cells["cy"][20:50] + rng.uniform(-3, 3, 30)
+    xy = rng.uniform(0, 300, (int(cells["n_pts"].sum()), 2)) * 0.37
+    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])])
+    bounds = (12.5, 7.25)
+    # dict pipeline (what the reference does)
+    feats = []
+    for i, c in enumerate(cells):
+        centroid = np.round([c["cx"], c["cy"]], 2).tolist()
+        feats.append(geojson.to_geojson_polygon(geojson.cell_dict(xy[offs[i]:offs[i + 1]].tolist(), int(c["cls"]), labels,
+                                                                  c["area"], c["perimeter"], centroid)))
+    feats = geojson.deduplicate(feats)
+    feats = [geojson.apply_bounds_offset_to_feature(f, *bounds) for f in feats]
+    ref_cont = json.loads(json.dumps({"type": "FeatureCollection", "features": feats}))
+    ref_cent = json.loads(json.dumps({"type": "FeatureCollection", "features": geojson.polygons_to_centroids(feats)}))
+    # array pipeline
+    keep = geojson.dedup_indices(geojson.rounded_centroids(cells), cells["area"])
+    assert 0 < len(keep) < n
+    n_written = geojson.write_feature_collections(tmp_path / "c.json", tmp_path / "p.json", cells, xy, keep, labels, bounds)
+    got_cont, got_cent = json.load(open(tmp_path / "c.json")), json.load(open(tmp_path / "p.json"))
+    assert n_written == len(ref_cont["features"]) == len(got_cont["features"]) == len(got_cent["features"])
+
+    def strip(fc):
+        return [{k: v for k, v in f.items() if k != "id"} for f in fc["features"]]
+    assert strip(got_cont) == strip(ref_cont) and strip(got_cent) == strip(ref_cent)
+    assert len({f["id"] for f in got_cont["features"]}) == n_written
+    # text level: same separators as json.dump
+    txt = open(tmp_path / "c.json").read()
+    assert txt.startswith('{"type": "FeatureCollection", "features": [{"type": "Feature", "id": "')
+    # class-less labels and an empty selection
+    geojson.write_feature_collections(tmp_path / "e.json", tmp_path / "e2.json", cells, xy, [], None)
+    assert json.load(open(tmp_path / "e.json")) == {"type": "FeatureCollection", "features": []}
+    geojson.write_feature_collections(tmp_path / "n.json", tmp_path / "n2.json", cells, xy, [3, 3], None)
+    f = json.load(open(tmp_path / "n.json"))["features"]
+    assert len(f) == 2 and f[0]["properties"]["classification"] == {"name": "cell", "color": [0, 168, 132]}
+    # vertex gather
+    sel = np.array([5, 2, 9])
+    g = geojson.gather_vertices(xy, offs[sel], cells["n_pts"][sel])
+    assert np.array_equal(g, np.concatenate([xy[offs[i]:offs[i + 1]] for i in sel]))
