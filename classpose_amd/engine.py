@@ -296,7 +296,7 @@ class _Slot:
         nS = nT * eng.n_sub
         self.stats = torch.empty(nT * 3 * 4, dtype=torch.float32, device=d)
         self.hist = torch.empty(nT * 768, dtype=torch.int32, device=d)
-        self.patches = torch.empty(nS * 1024 * 192, dtype=torch.int16, device=d)
+        self.patches = torch.zeros(nS * 1024 * 192, dtype=torch.int16, device=d)   # zeros: a partial first batch still runs all rows
         self.head = torch.empty(nS * 1024 * eng.w.c.ld_head, dtype=torch.float32, device=d)
         self.dP = torch.empty((nT, 2, H, W), dtype=torch.float32, device=d)
         self.cellprob = torch.empty((nT, H, W), dtype=torch.float32, device=d)
@@ -381,7 +381,10 @@ class Engine:
                                             ptr(sl.stats), ptr(sl.hist), sn), "normalize_stats")
         check(self.L.cpx_make_subtiles(ptr(tiles_u8), ptr(sl.stats), n, C.byref(self.tiling),
                                        ptr(sl.patches), sn), "make_subtiles")
-        check(self.L.cpx_net_forward(C.byref(self.w.c), ptr(sl.patches), n * self.n_sub, ptr(sl.head),
+        # the network always runs the full batch (rows of absent tiles hold old patches): kernel selection
+        # and tile shapes depend on M, so a partial last batch would otherwise round differently --
+        # this keeps a tile's outputs bitwise independent of batch composition, rank and world size
+        check(self.L.cpx_net_forward(C.byref(self.w.c), ptr(sl.patches), self.nT * self.n_sub, ptr(sl.head),
                                      ptr(self.net_ws), self.net_ws_bytes, sn), "net_forward")
         sl.ev_net.record(self.s_net)
         tiles_u8.record_stream(self.s_net)
