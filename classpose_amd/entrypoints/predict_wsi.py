@@ -127,6 +127,8 @@ class TileStream:
             self.q.put(None)
         except BaseException as e:      # surface reader errors in the consumer
             self.q.put(e)
+        finally:
+            self.readers.shutdown(wait=False)
 
     def __iter__(self):
         while True:
