@@ -217,7 +217,9 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     for R, idxs in by_size.items():                              # R: pixels read per tile side
         H, W = ops.resized_shape(R, R, plan.resize_factor)       # what the network sees
         n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
-        nT = max(1, max(args.batch_size, 32) // n_sub)
+        # sub-tiles per launch: 96 keeps the 256-row GEMM grid a near-multiple of the 256 CUs for the 9- and
+        # 25-sub-tile geometries too (+7..9 % over 32, tools/bench_variants.py); --batch_size can raise it
+        nT = max(1, max(args.batch_size, 96) // n_sub)
         eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
         extra = None
         if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
