@@ -101,6 +101,8 @@ SIGNATURES = {
     "cpx_compute_masks": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _d, _i, _i, _d, _p, _p, _p, _p, _p]),
     "cpx_instance_records": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "cpx_find_contours_ccomp_host": (_i, [_p, _i, _i, _p, _i, _p, _p, _p, _i]),
+    "cpx_polygonize_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "cpx_polygonize_device": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_polygonize_host": (_i, [_p, _i, _i, _p, _i, _d, _d, _d, _p, _i, _p]),
 }
 # not part of the public header (debug / A-B switches)

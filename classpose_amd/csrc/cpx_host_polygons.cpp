@@ -176,7 +176,7 @@ extern "C" int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, con
             const double x1 = xy[2 * ((i + 1) % np)] - bx, y1 = xy[2 * ((i + 1) % np) + 1] - by;
             const double cr = x0 * y1 - x1 * y0;
             a2 += cr; cx += (x0 + x1) * cr; cy += (y0 + y1) * cr;
-            per += std::hypot(x1 - x0, y1 - y0);
+            per += std::sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));   // same expression as cpx_polygons.hip
         }
         o.area = std::fabs(a2) / 2;
         o.perimeter = per;

@@ -286,6 +286,9 @@ class TileOutputs:
     logits: torch.Tensor | None  # f32 [nT, ncls, H, W]
     records: torch.Tensor | None = None      # uint8 view of cpx_record[nT][max_rec]
     rec_counts: torch.Tensor | None = None   # int32 [nT]
+    cells: torch.Tensor | None = None        # uint8 view of cpx_cell[nT][max_rec]   (polygons=...)
+    xy_pool: torch.Tensor | None = None      # f64 [max_pts, 2] level-0 vertices
+    n_pts_total: torch.Tensor | None = None  # int32 [1]
 
 
 class _Slot:
@@ -307,6 +310,8 @@ class _Slot:
         self.nlabels = torch.empty(nT, dtype=torch.int32, device=d)
         self.records = torch.empty(nT * eng.max_rec * C.sizeof(CpxRecord), dtype=torch.uint8, device=d)
         self.rec_counts = torch.empty(nT, dtype=torch.int32, device=d)
+        self.cells = self.xy_pool = self.n_pts_total = self.poly_ws = self.origins = None   # allocated on first use
+        self.has_polygons = False
         self.ev_net = torch.cuda.Event()
         self.ev_post = torch.cuda.Event()
         self.n = 0
@@ -351,6 +356,7 @@ class Engine:
         self.taper = torch.from_numpy(taper_1d(BSIZE)).to(d)
         self.pp_ws_bytes = self.L.cpx_postproc_workspace_bytes(nT, H, W)
         self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 8192)
+        self.max_pts = nT * max(4096, H * W // 8)             # device vertex pool (f1), 16 B per vertex
         self.slots = [_Slot(self) for _ in range(self.N_SLOTS)]
         self.s_net = torch.cuda.Stream(d)
         self.s_post = torch.cuda.Stream(d)
@@ -358,10 +364,12 @@ class Engine:
         self._last: _Slot | None = None
 
     # -- pipeline -------------------------------------------------------
-    def submit(self, tiles_u8: torch.Tensor, inject=None, records: bool = True) -> int:
+    def submit(self, tiles_u8: torch.Tensor, inject=None, records: bool = True, polygons=None) -> int:
         """Enqueue one batch (uint8 [n, H, W, 3] resident on the device, n <= batch_tiles) and
         return its slot id.  ``inject`` = (dP, cellprob, logits) device tensors: flow-injection
-        mode (the network still runs; the dynamics consume the injected fields instead)."""
+        mode (the network still runs; the dynamics consume the injected fields instead).
+        ``polygons`` = (scale, origins [n][2] level-0 tile origins): also polygonise the instances
+        on the device (``cpx_polygonize_device``), results via ``fetch_polygons``."""
         n = tiles_u8.shape[0]
         assert n <= self.nT and tiles_u8.dtype == torch.uint8 and tiles_u8.is_contiguous()
         assert tiles_u8.shape[1:] == (self.H, self.W, 3) and tiles_u8.device == self.dev
@@ -405,6 +413,25 @@ class Engine:
             check(self.L.cpx_instance_records(ptr(sl.masks), ptr(sl.class_masks), n, self.H, self.W,
                                               self.max_rec, ptr(sl.records), ptr(sl.rec_counts),
                                               ptr(sl.pp_ws), sp), "instance_records")
+        sl.has_polygons = polygons is not None
+        if polygons is not None:
+            assert records, "polygons need the per-cell records"
+            scale, origins = polygons
+            if sl.cells is None:
+                sl.cells = torch.empty(self.nT * self.max_rec * C.sizeof(_lib.CpxCell), dtype=torch.uint8, device=self.dev)
+                sl.xy_pool = torch.empty((self.max_pts, 2), dtype=torch.float64, device=self.dev)
+                sl.n_pts_total = torch.zeros(1, dtype=torch.int32, device=self.dev)
+                sl.poly_ws = torch.empty(self.L.cpx_polygonize_workspace_bytes(self.nT, self.H, self.W, self.max_rec),
+                                         dtype=torch.uint8, device=self.dev)
+                sl.origins_host = torch.zeros((self.nT, 2), dtype=torch.float64).pin_memory()
+                sl.origins = torch.zeros((self.nT, 2), dtype=torch.float64, device=self.dev)
+            sl.origins_host[:n] = torch.as_tensor(np.asarray(origins, dtype=np.float64).reshape(n, 2))
+            with torch.cuda.stream(self.s_post):
+                sl.origins.copy_(sl.origins_host, non_blocking=True)
+            check(self.L.cpx_polygonize_device(ptr(sl.masks), ptr(sl.records), ptr(sl.rec_counts), n, self.H, self.W,
+                                               self.max_rec, float(scale), ptr(sl.origins), ptr(sl.xy_pool),
+                                               self.max_pts, ptr(sl.cells), ptr(sl.n_pts_total), ptr(sl.poly_ws), sp),
+                  "polygonize_device")
         sl.ev_post.record(self.s_post)
         return sid
 
@@ -417,10 +444,25 @@ class Engine:
         self._last = sl
         n = sl.n
         return TileOutputs(sl.masks[:n], sl.class_masks[:n], sl.nlabels[:n], sl.dP[:n], sl.cellprob[:n],
-                           sl.logits[:n] if self.w.ncls > 1 else None, sl.records, sl.rec_counts)
+                           sl.logits[:n] if self.w.ncls > 1 else None, sl.records, sl.rec_counts,
+                           *((sl.cells, sl.xy_pool, sl.n_pts_total) if sl.has_polygons else (None, None, None)))
 
-    def run(self, tiles_u8: torch.Tensor, inject=None, records: bool = True) -> "TileOutputs":
-        return self.result(self.submit(tiles_u8, inject, records))
+    def run(self, tiles_u8: torch.Tensor, inject=None, records: bool = True, polygons=None) -> "TileOutputs":
+        return self.result(self.submit(tiles_u8, inject, records, polygons))
+
+    def fetch_polygons(self, n: int, out: "TileOutputs"):
+        """Device polygons of a collected batch -> (cells CELL_DTYPE[m] with a ``tile`` column appended as a
+        separate int array, xy float64 [total, 2]); None when the vertex pool overflowed (callers fall back to
+        the host polygoniser for that batch)."""
+        total = int(out.n_pts_total.item())
+        if total > self.max_pts:
+            return None
+        counts = out.rec_counts[:n].cpu().numpy()
+        raw = out.cells.cpu().numpy().view(CELL_DTYPE).reshape(self.nT, self.max_rec)
+        rows = [raw[t, :min(int(counts[t]), self.max_rec)] for t in range(n)]
+        tile = np.concatenate([np.full(len(r), t, np.int32) for t, r in enumerate(rows)]) if n else np.zeros(0, np.int32)
+        cells = np.concatenate(rows) if n else raw[:0, 0]
+        return cells, tile, out.xy_pool[:total].cpu().numpy()
 
     # kept for the bench / CLI: records of the most recently collected batch
     @property
@@ -441,6 +483,9 @@ class Engine:
             if n else raw[:0, 0]
 
 
+CELL_DTYPE = np.dtype([("area", "<f8"), ("perimeter", "<f8"), ("cx", "<f8"), ("cy", "<f8"),
+                       ("n_pts", "<i4"), ("offset", "<i4"), ("valid", "<i4"), ("cls", "<i4")])
+assert CELL_DTYPE.itemsize == C.sizeof(_lib.CpxCell)
 RECORD_DTYPE = np.dtype([("tile", "<i4"), ("label", "<i4"), ("cls", "<i4"), ("area", "<i4"),
                          ("y0", "<i4"), ("x0", "<i4"), ("y1", "<i4"), ("x1", "<i4"),
                          ("sum_y", "<i8"), ("sum_x", "<i8")])

@@ -211,6 +211,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         by_size.setdefault(plan.coords[ti][1], []).append(ti)
     pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
     futures = []
+    cells_all, xy_all, n_invalid = [], [], 0
     scale = plan.prediction_to_slide_scale
     t0 = time.time()
     n_done = 0
@@ -232,17 +233,28 @@ def run_rank(args, rank: int, world: int, device: torch.device):
                                              n_classes, W, H)
         stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra)
         def collect(sid, chunk, keep_alive):
-            nonlocal n_done
+            nonlocal n_done, n_invalid
             n = len(chunk)
             out = eng.result(sid)
-            masks = out.masks.cpu().numpy().view(np.uint16)          # D2H: 2 B / pixel
-            recs = eng.fetch_records(n, out)
             if int(out.nlabels.max()) >= 65535:
                 raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
-            for k, ti in enumerate(chunk):
-                origin = plan.coords[ti][0]
-                futures.append(pool.submit(postprocess.polygonize_tile, masks[k].copy(),
-                                           recs[recs["tile"] == k], scale, origin))
+            polys = eng.fetch_polygons(n, out)
+            if polys is not None:                                    # contours traced on the device (f1)
+                cells, _, xy = polys
+                keep = cells["valid"] == 1
+                n_invalid += int((~keep).sum())
+                xy_all.append(geojson.gather_vertices(xy, cells["offset"][keep], cells["n_pts"][keep]))
+                rows = np.zeros(int(keep.sum()), CELL_ROW)
+                for name in ("area", "perimeter", "cx", "cy", "n_pts", "cls"):
+                    rows[name] = cells[keep][name]
+                cells_all.append(rows)
+            else:                                                    # vertex pool overflow: host polygoniser
+                masks = out.masks.cpu().numpy().view(np.uint16)      # D2H: 2 B / pixel
+                recs = eng.fetch_records(n, out)
+                for k, ti in enumerate(chunk):
+                    origin = plan.coords[ti][0]
+                    futures.append(pool.submit(postprocess.polygonize_tile, masks[k].copy(),
+                                               recs[recs["tile"] == k], scale, origin))
             n_done += n
             if rank == 0 and (n_done // nT) % 20 == 0:
                 logger.info(f"Predicted tiles: {n_done}/{len(mine)} "
@@ -255,14 +267,14 @@ def run_rank(args, rank: int, world: int, device: torch.device):
             inject = None
             if extra is not None:
                 inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
-            sid = eng.submit(tiles_dev, inject=inject, records=True)
+            sid = eng.submit(tiles_dev, inject=inject, records=True,
+                             polygons=(scale, [plan.coords[ti][0] for ti in chunk]))
             if in_flight is not None:
                 collect(*in_flight)
             in_flight = (sid, chunk, (tiles_dev, inject))
         if in_flight is not None:
             collect(*in_flight)
         del eng, stream
-    cells_all, xy_all, n_invalid = [], [], 0
     for f in futures:
         cells, xy = f.result()
         keep = cells["valid"] == 1

@@ -8,11 +8,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CpxCell, CpxRecord
-from .engine import RECORD_DTYPE
-
-CELL_DTYPE = np.dtype([("area", "<f8"), ("perimeter", "<f8"), ("cx", "<f8"), ("cy", "<f8"),
-                       ("n_pts", "<i4"), ("offset", "<i4"), ("valid", "<i4"), ("cls", "<i4")])
-assert CELL_DTYPE.itemsize == C.sizeof(CpxCell)
+from .engine import CELL_DTYPE, RECORD_DTYPE
 
 
 def polygonize_tile(masks_u16: np.ndarray, records: np.ndarray, scale: float, origin) -> tuple:

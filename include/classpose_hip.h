@@ -310,6 +310,21 @@ int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, const cpx_reco
                         double scale, double off_x, double off_y, double *xy_pool, int max_pts,
                         cpx_cell *cells);
 
+/* f1: the same polygonisation on the DEVICE (one thread per instance, post-processing stream), so
+ * that only vertex lists and cpx_cell rows leave the GPU instead of the 2 B/pixel id maps.
+ * masks_u16 [nT][H][W]; records [nT][max_rec] + rec_counts [nT] as cpx_instance_records wrote them;
+ * origins [nT][2] double (level-0 x, y of each tile); cells [nT][max_rec] (rows >= rec_counts[t]
+ * untouched); vertex i of a cell = (x_px * scale + origin_x, y_px * scale + origin_y) at
+ * xy_pool[2 * (offset + i)], offsets are an exclusive scan in (tile, record) order; n_pts_total [1]
+ * receives the pool use (cells whose vertices would pass max_pts come back with n_pts = 0).
+ * Precondition: hole-free instances (what cpx_fill_holes_and_remove_small_masks produces); then the
+ * outputs are bit-identical to cpx_polygonize_host.                                            */
+size_t cpx_polygonize_workspace_bytes(int nT, int H, int W, int max_rec);
+int cpx_polygonize_device(const uint16_t *masks_u16, const cpx_record *records, const int32_t *rec_counts,
+                          int nT, int H, int W, int max_rec, double scale, const double *origins,
+                          double *xy_pool, int max_pts, cpx_cell *cells, int32_t *n_pts_total,
+                          void *workspace, void *stream);
+
 /* cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_SIMPLE) of the GrandQC class maps
  * (/root/reference/src/classpose/grandqc/wsi_tissue_detection.py:209-213,
  * wsi_artefact_detection.py:262-265), host code.  mask [H][W] uint8, non-zero = foreground.
