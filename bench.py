@@ -56,7 +56,7 @@ def cpu_baseline(sd, coords, budget_s=12.0, max_tiles=4):
     the same injected fields -> class vote -> records.  Bounded sample."""
     from oracle import classmask, dynamics, net, tiling
     # torch-CPU scales to ~16-32 threads on this ViT-L and collapses beyond (measured on the
-    # 256-core GPU-box host: 5.1 s/tile at 32 threads, 151 s/tile at 256: tools/cpu_threads.py)
+    # 256-core GPU-box host: 5.1 s/tile at 32 threads, 151 s/tile at 256)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     fw = net.make_forward(sd, torch.float32)
