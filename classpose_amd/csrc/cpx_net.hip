@@ -188,7 +188,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
                                                            const unsigned short *__restrict__ relh,
                                                            const unsigned short *__restrict__ relw,
                                                            unsigned short *__restrict__ out,
-                                                           unsigned *__restrict__ dbg = nullptr) {
+                                                           unsigned *__restrict__ dbg = nullptr,
+                                                           int g_att_xcd_order = 1) {
     unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0, tstart = 0;
     if constexpr (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory"); tprev = tstart; }
@@ -197,8 +198,16 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     __shared__ float sG[4][32 * GS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
-    const int head = blockIdx.y, s = blockIdx.z;
-    const int qh = blockIdx.x * 4 + wave;                 // image row of this wave's queries
+    // XCD-aware block order: workgroups go round-robin to the 8 XCDs by linear id, and the 8 row groups of
+    // one (sub-tile, head) stream the same 256 KB of K / V^T -- keep them on ONE XCD's L2 (per-XCD order:
+    // 8 consecutive workgroups = one pair) instead of fetching that pair once per XCD (fabric reads / 8)
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    int rg = blockIdx.x, head = blockIdx.y, s = blockIdx.z;
+    if (g_att_xcd_order) {
+        const int j = lin >> 3, pair = (j >> 3) * 8 + (lin & 7);
+        rg = j & 7; head = pair & 15; s = pair >> 4;
+    }
+    const int qh = rg * 4 + wave;                         // image row of this wave's queries
     const size_t tok0 = (size_t)s * 1024;
     const unsigned short *qrow = qkv + (tok0 + qh * 32 + r) * 3072 + head * 64;
 
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
         unsigned long long tend;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
         if (lane == 0) {
-            unsigned *d = dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 * 9 + wave * 9;
+            unsigned *d = dbg + (size_t)lin * 4 * 9 + wave * 9;
             for (int i = 0; i < 8; ++i) d[i] = seg[i];
             d[8] = (unsigned)(tend - tstart);
         }
@@ -383,6 +392,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
 
 static int attention_launch(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                             void *vT_ws, void *out, void *stream, bool transpose_v);
+static int g_att_xcd = 1;          // XCD-aware workgroup order (debug / A-B switch)
+extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 // diagnostic: per-wave cycle counts of the loop segments -> dbg [n_subtiles*16*8 blocks][4 waves][9]
 extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
@@ -391,7 +402,7 @@ extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const voi
                        (const unsigned short *)qkv, (unsigned short *)vT_ws);
     hipLaunchKernelGGL((k_attention<false, true>), dim3(8, 16, n_subtiles), dim3(ATT_THREADS), 0, s,
                        (const unsigned short *)qkv, (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                       (const unsigned short *)rel_w, (unsigned short *)out, dbg);
+                       (const unsigned short *)rel_w, (unsigned short *)out, dbg, g_att_xcd);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -411,11 +422,11 @@ static int attention_launch(const void *qkv, const void *rel_h, const void *rel_
     if (cpx_get_half_dtype())
         hipLaunchKernelGGL((k_attention<true, false>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
                            (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr);
+                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr, g_att_xcd);
     else
         hipLaunchKernelGGL((k_attention<false, false>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
                            (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr);
+                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr, g_att_xcd);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
