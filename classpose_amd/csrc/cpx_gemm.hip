@@ -40,6 +40,7 @@ struct GemmArgs {
     int ld_out;
     int tiles_n, n_blocks;
     int l2_block;           // 1: 8 x 4 super-tile order per XCD (debug switch, default on)
+    int rev_m;              // 1: walk the M tiles from the last row block to the first (see gemm_launch)
     int dbg;                // timing-only ablations of the 256^2 epilogue (0 in production)
     // LayerNorm folded into the GEMM (consumer side): out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
     // with W pre-multiplied by gamma, bias = b + W.beta, colsum[n] = sum_k W'[n][k]
@@ -340,6 +341,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
             tile_n = bid - tile_m * g.tiles_n;
         }
     }
+    if (g.rev_m) tile_m = g.n_blocks / g.tiles_n - 1 - tile_m;
     const int m0 = tile_m * 256, n0 = tile_n * 256;
     const int K = g.K, nk = K / 64;
 
@@ -545,6 +547,11 @@ static int g_gemm_dbg = 0;
 extern "C" void cpx_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 static int g_gemm_l2 = 1;
 extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
+// experiment switch (default off): mlp.lin2 walks M backwards so that the most recently written rows of the
+// 268 MB hidden tensor (> the 256 MB Infinity Cache) are read first.  Bitwise identical; measured 26.50 vs
+// 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
+static int g_gemm_rev = 0;
+extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 static int g_gemm_big = 1;         // 1 = use the 256^2 kernel when the shape allows
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 
@@ -630,6 +637,7 @@ extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, i
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
     a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg;
+    a.rev_m = (g_gemm_rev && K >= 4096) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s); break;

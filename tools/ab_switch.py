@@ -1,0 +1,35 @@
+"""In-process interleaved A/B of a private debug switch on the whole engine step.
+usage: python tools/ab_switch.py cpx_gemm_set_reverse [cpx_other_switch ...]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from classpose_amd import _lib, engine, synth
+dev = torch.device("cuda:0"); L = _lib.lib()
+sd = synth.make_state_dict(7, None, depth=24, seed=0)
+w = engine.NetWeights.from_state_dict(sd, "bf16", dev)
+eng = engine.Engine(w, 256, batch_tiles=8)
+tiles = torch.from_numpy(np.stack([synth.render_region(1234, 224 * i, 0, 256, 256) for i in range(8)])).to(dev)
+f = [synth.analytic_fields(1234, 224 * i, 0, 256, 256, 7) for i in range(8)]
+inj = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(dev) for k in range(3))
+def steps(n):
+    prev = None
+    for _ in range(n):
+        sid = eng.submit(tiles, inject=inj, records=True)
+        if prev is not None: eng.result(prev)
+        prev = sid
+    out = eng.result(prev)
+    return out
+steps(3)
+for name in sys.argv[1:]:
+    fn = getattr(L, name)
+    res = {0: [], 1: []}; outs = {}
+    for rnd in range(5):
+        for v in (0, 1):
+            fn(v)
+            o = steps(2); torch.cuda.synchronize(); t = time.perf_counter(); o = steps(20); torch.cuda.synchronize()
+            res[v].append((time.perf_counter() - t) / 20 * 1e3)
+            outs[v] = (o.dP.clone(), o.masks.clone())
+    fn(int(os.environ.get('AB_RESTORE', '1')))
+    print(name, "bitwise equal outputs:", torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]))
+    for v in (0, 1):
+        print(f"  {name}({v}) engine ms/step: min {min(res[v]):.3f} median {sorted(res[v])[2]:.3f}  {[round(x, 2) for x in res[v]]}")
