@@ -433,12 +433,16 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;     // V third of the qkv projection
     const int c16 = tid & 31;                   // 16-byte chunk within a 512-byte row (store phase)
     float ln_mean[2][4], ln_rstd[2][4];         // this lane's 8 token rows (hm, mb)
-    if (g.ln_stats) {
+    if (EPI != CPX_EPI_RESID_BF16 && g.ln_stats) {
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
                 ln_row_params(g.ln_stats, m0 + hm * 128 + wm * 64 + mb * 16 + fr, 1.0f / K, ln_mean[hm][mb], ln_rstd[hm][mb]);
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) ln_mean[hm][mb] = -ln_mean[hm][mb] * ln_rstd[hm][mb];
     }
     uint4 rres[16];
     if constexpr (EPI == CPX_EPI_RESID_BF16) {  // residual rows: issue the loads now, consume after the LDS pass
@@ -447,6 +451,19 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
             rres[it] = *reinterpret_cast<const uint4 *>((const unsigned short *)g.aux +
                                                         (size_t)(m0 + it * 16 + (tid >> 5)) * g.ld_out + n0 + c16 * 8);
     }
+    // this lane's 4 column groups (hn, nb): bias and LayerNorm column sums once, not once per accumulator
+    // (the LDS stores below alias every pointer for the compiler, so it would reload them 32 times)
+    constexpr bool LN_IN = EPI != CPX_EPI_RESID_BF16;      // the residual GEMMs never consume a folded LayerNorm
+    float4 colb[2][2], colc[2][2];
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
+            colb[hn][nb] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (LN_IN)
+                colc[hn][nb] = g.ln_stats ? *reinterpret_cast<const float4 *>(g.ln_colsum + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -458,14 +475,14 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                     const int ml = hm * 128 + wm * 64 + mb * 16 + fr;
                     const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
                     f32x4 v = acc[hm][hn][mb][nb];
-                    if (g.ln_stats) {
-                        const float4 cs = *reinterpret_cast<const float4 *>(g.ln_colsum + n0 + nl);
-                        const float mu = ln_mean[hm][mb], rs = ln_rstd[hm][mb];
-                        v[0] = (v[0] - mu * cs.x) * rs; v[1] = (v[1] - mu * cs.y) * rs;
-                        v[2] = (v[2] - mu * cs.z) * rs; v[3] = (v[3] - mu * cs.w) * rs;
-                    }
-                    if (g.bias) {
-                        const float4 b = *reinterpret_cast<const float4 *>(g.bias + n0 + nl);
+                    const float4 b = colb[hn][nb];
+                    if (LN_IN && g.ln_stats) {
+                        // rstd * (acc - mean * colsum) + bias = fma(acc, rstd, fma(-mean * rstd, colsum, bias))
+                        const float4 cs = colc[hn][nb];
+                        const float nm = ln_mean[hm][mb], rs = ln_rstd[hm][mb];      // ln_mean holds -mean * rstd
+                        v[0] = fmaf(v[0], rs, fmaf(nm, cs.x, b.x)); v[1] = fmaf(v[1], rs, fmaf(nm, cs.y, b.y));
+                        v[2] = fmaf(v[2], rs, fmaf(nm, cs.z, b.z)); v[3] = fmaf(v[3], rs, fmaf(nm, cs.w, b.w));
+                    } else {
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                     if constexpr (EPI == CPX_EPI_GELU_BF16) {
@@ -630,7 +647,7 @@ extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, i
     CPX_REQUIRE(ld_out >= N && ld_out % 4 == 0);
     CPX_REQUIRE((epilogue != CPX_EPI_RESID_BF16 && epilogue != CPX_EPI_POS_BF16 && epilogue != CPX_EPI_QKV_BF16) || aux);
     CPX_REQUIRE(epilogue != CPX_EPI_QKV_BF16 || (N == 3072 && M % 1024 == 0));
-    CPX_REQUIRE(!ln_stats || ln_colsum);
+    CPX_REQUIRE(!ln_stats || (ln_colsum && epilogue != CPX_EPI_RESID_BF16));
     CPX_REQUIRE(!stats_out || (epilogue == CPX_EPI_RESID_BF16 && N == 1024 && cpx_gemm_uses_big_tile(M, N, K, epilogue)));
     GemmArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;

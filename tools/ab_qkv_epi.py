@@ -1,0 +1,25 @@
+"""qkv projection: QKV epilogue (V third written transposed) vs plain bf16 epilogue, one process."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from classpose_amd import _lib, ops
+dev = torch.device("cuda:0")
+M, N, K = 32768, 3072, 1024
+g = torch.Generator().manual_seed(0)
+A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+b = torch.randn(N, generator=g).to(dev)
+vt = torch.empty((M, 1024), dtype=torch.bfloat16, device=dev)
+res = {"qkv": [], "bf16": []}
+for rnd in range(4):
+    for epi in ("qkv", "bf16"):
+        aux = vt if epi == 'qkv' else None
+        for _ in range(3): ops.gemm(A, W, epi, b, aux)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): ops.gemm(A, W, epi, b, aux)
+        e1.record(); torch.cuda.synchronize()
+        res[epi].append(e0.elapsed_time(e1) / 20 * 1e3)
+for k, v in res.items():
+    print(k, "us: min %.1f median %.1f" % (min(v), sorted(v)[len(v) // 2]))
