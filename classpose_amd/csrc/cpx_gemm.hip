@@ -273,7 +273,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define G2_HALF 16384
 #define G2_BUF 65536
 #define G2_EPI_LD 528
-#define G2_LDS_BYTES (256 * G2_EPI_LD)      // 135168 >= 2 * G2_BUF
+#define G2_LN_OFF (256 * G2_EPI_LD)         // 256 x (rstd, -mean * rstd) of the tile's token rows (folded LayerNorm)
+#define G2_LDS_BYTES (G2_LN_OFF + 256 * 8)  // 135168 (>= 2 * G2_BUF) + 2048
 
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
@@ -383,9 +384,27 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     u32x4 fx[4][2], fw[2][2];
 
+    // folded LayerNorm: the tile's 256 token rows get their (rstd, -mean * rstd) once, computed by one lane
+    // each under the prologue's DMA latency and parked in the LDS tail for the epilogue.  The statistics are
+    // requested BEFORE the DMA so that waiting for them (in-order vmcnt) does not drain the staging.
+    const bool ln_in = EPI != CPX_EPI_RESID_BF16 && g.ln_stats != nullptr && tid < 256;
+    float4 st_a = make_float4(0.f, 0.f, 0.f, 0.f), st_b = st_a;
+    if (ln_in) {
+        st_a = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8);
+        st_b = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8 + 4);
+    }
     // prologue: all of tile 0, then X0 / W1 of tile 1 (the two a steady-state tile -1 would have staged)
     stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-    if (nk > 1) { stage(0, 1); stage(3, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (nk > 1) { stage(0, 1); stage(3, 1); }
+    if (ln_in) {
+        const float inv_k = 1.0f / K;
+        const float sum = (st_a.x + st_a.z) + (st_b.x + st_b.z), sq = (st_a.y + st_a.w) + (st_b.y + st_b.w);
+        const float mean = sum * inv_k;
+        const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-6f);
+        *reinterpret_cast<float2 *>(smem + G2_LN_OFF + tid * 8) = make_float2(rstd, -mean * rstd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_BAR();
     if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
@@ -437,12 +456,10 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                ln_row_params(g.ln_stats, m0 + hm * 128 + wm * 64 + mb * 16 + fr, 1.0f / K, ln_mean[hm][mb], ln_rstd[hm][mb]);
-#pragma unroll
-        for (int hm = 0; hm < 2; ++hm)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) ln_mean[hm][mb] = -ln_mean[hm][mb] * ln_rstd[hm][mb];
+            for (int mb = 0; mb < 4; ++mb) {
+                const float2 p = *reinterpret_cast<const float2 *>(smem + G2_LN_OFF + (hm * 128 + wm * 64 + mb * 16 + fr) * 8);
+                ln_rstd[hm][mb] = p.x; ln_mean[hm][mb] = p.y;      // ln_mean holds -mean * rstd
+            }
     }
     uint4 rres[16];
     if constexpr (EPI == CPX_EPI_RESID_BF16) {  // residual rows: issue the loads now, consume after the LDS pass
