@@ -58,6 +58,21 @@ __device__ __forceinline__ void ln_row_params(const float *st, int m, float inv_
     rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-6f);
 }
 
+// v + (v permuted by a DPP control): one VALU instruction, no LDS traffic (ds_bpermute-based __shfl_xor
+// cost 160 LDS-pipe operations per lane in the residual epilogue)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over each 32-lane half of the wave; the total is valid in lanes 16..31 and 48..63
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);           // row_half_mirror
+    v = dpp_add<0x140>(v);           // row_mirror: every lane of a 16-lane row holds the row total
+    return dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3: + the total of the row before
+}
+
 template <bool F16>
 __device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c) {
     if constexpr (F16)
@@ -562,9 +577,8 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                     const float lo = from_half<F16>(a[i] & 0xFFFF), hi = from_half<F16>(a[i] >> 16);
                     sm += lo + hi; sq += lo * lo + hi * hi;
                 }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-                if (c16 == 0)
+                sm = half_wave_sum(sm); sq = half_wave_sum(sq);
+                if (c16 == 16)
                     *reinterpret_cast<float2 *>(g.stats_out + ((size_t)(m0 + ml) * LN_SLOTS + tile_n) * 2) = make_float2(sm, sq);
             }
         }
