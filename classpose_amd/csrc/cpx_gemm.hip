@@ -463,6 +463,17 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
     __builtin_amdgcn_sched_barrier(0);
 
+    if (g.dbg & 4) {            // timing-only ablation: main loop + prologue, accumulators kept live
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) asm volatile("" ::"v"(acc[a][b][c][d]));
+        return;
+    }
     // ---- epilogue: bias/activation in f32 -> half tile in LDS -> whole rows to HBM
     const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;     // V third of the qkv projection
     const int c16 = tid & 31;                   // 16-byte chunk within a 512-byte row (store phase)
