@@ -104,7 +104,7 @@ __device__ __forceinline__ float tap(const float *im, int H, int W, int y, int x
 
 __global__ void k_follow(const float *__restrict__ cp, float thr, int niter, float shx, float shy,
                          float hw, float hh, int32_t *__restrict__ p_final,
-                         float *__restrict__ p_float, PPLayout lay, void *ws) {
+                         float *__restrict__ p_float, PPLayout lay, void *ws, int early_exit) {
     int idx = blockIdx.x * NTHR + threadIdx.x;
     if (idx >= lay.HW) return;
     size_t t = blockIdx.y;
@@ -121,6 +121,7 @@ __global__ void k_follow(const float *__restrict__ cp, float thr, int niter, flo
     float py = __fdiv_rn((float)y, shy);
     px = px * 2.0f; px = px - 1.0f;
     py = py * 2.0f; py = py - 1.0f;
+    float qx = __int_as_float(0x7fc00000), qy = qx;      // position two steps back (NaN: never equal)
     for (int it = 0; it < niter; ++it) {
         float fx = __fmaf_rn(px + 1.0f, hw, -0.5f);
         float fy = __fmaf_rn(py + 1.0f, hh, -0.5f);
@@ -134,8 +135,17 @@ __global__ void k_follow(const float *__restrict__ cp, float thr, int niter, flo
         float dy = __fmaf_rn(tap(imy, H, W, y0 + 1, x0 + 1), se,
                    __fmaf_rn(tap(imy, H, W, y0 + 1, x0), sw,
                    __fmaf_rn(tap(imy, H, W, y0, x0 + 1), ne, tap(imy, H, W, y0, x0) * nw)));
-        px = px + dx; px = px < -1.0f ? -1.0f : (px > 1.0f ? 1.0f : px);
-        py = py + dy; py = py < -1.0f ? -1.0f : (py > 1.0f ? 1.0f : py);
+        float nx = px + dx; nx = nx < -1.0f ? -1.0f : (nx > 1.0f ? 1.0f : nx);
+        float ny = py + dy; ny = ny < -1.0f ? -1.0f : (ny > 1.0f ? 1.0f : ny);
+        // The step is a pure function of the position, so the remaining iterations can be skipped EXACTLY
+        // once the orbit closes: a fixed point repeats forever, a 2-cycle alternates (+0 / -0 compare equal
+        // and behave identically: the next step starts with p + 1).  Anything else runs all niter steps.
+        if (early_exit && nx == px && ny == py) break;
+        if (early_exit && nx == qx && ny == qy) {                       // s[it+1] == s[it-1]
+            if (((niter - (it + 1)) & 1) == 0) { px = nx; py = ny; }
+            break;
+        }
+        qx = px; qy = py; px = nx; py = ny;
     }
     px = px + 1.0f; px = px * 0.5f; px = px * shx;
     py = py + 1.0f; py = py * 0.5f; py = py * shy;
@@ -876,6 +886,9 @@ static int pp_check(int nT, int H, int W) {
     return CPX_OK;
 }
 
+static int g_follow_early = 1;      // exact orbit-closure early exit of the Euler loop (debug / A-B switch)
+extern "C" void cpx_follow_set_early_exit(int on) { g_follow_early = on; }
+
 extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, int H, int W,
                                 float thr, int niter, int32_t *p_final, float *p_float, void *ws,
                                 void *stream) {
@@ -888,7 +901,7 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
     hipLaunchKernelGGL(k_prep_flow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, dP, cellprob, thr, kx, ky, lay, ws);
     hipLaunchKernelGGL(k_follow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, cellprob, thr, niter,
                        (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
-                       p_float, lay, ws);
+                       p_float, lay, ws, g_follow_early);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
