@@ -292,12 +292,48 @@ __global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout la
     atomicMin(&WS(int, off_first)[lab], idx);
 }
 
+// Label statistics visit RUNS, not pixels: a thread owns 8 consecutive pixels and calls f(label, first
+// linear index, run length, y, x of the first pixel) once per maximal run of one positive label on one image
+// row (instances are ~15 px wide, so this issues ~8x fewer atomics than one call per pixel; all updates are
+// integer min / max / add, so the results are identical).  Returns true if the thread saw a background pixel.
+#define RUN_PX 8
+#define GRID_RUN(lay, nT) dim3(cpx_cdiv(cpx_cdiv((lay).HW, RUN_PX), NTHR), (nT))
+template <typename T, typename F>
+__device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, int W, int limit, F &&f) {
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
+    if (base >= HW) return false;
+    int lab[RUN_PX];
+    if (base + RUN_PX <= HW && sizeof(T) == 4 && (reinterpret_cast<size_t>(m + base) & 15) == 0) {
+        const int4 a = *reinterpret_cast<const int4 *>(m + base), b = *reinterpret_cast<const int4 *>(m + base + 4);
+        lab[0] = a.x; lab[1] = a.y; lab[2] = a.z; lab[3] = a.w; lab[4] = b.x; lab[5] = b.y; lab[6] = b.z; lab[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) lab[i] = base + i < HW ? (int)m[base + i] : 0;
+    }
+    bool bg = false;
+    int y = base / W, x = base - y * W;
+    int cur = 0, start = 0, sx = 0, sy = 0, n = 0;
+#pragma unroll
+    for (int i = 0; i < RUN_PX; ++i) {
+        int l = lab[i];
+        if (base + i < HW && l <= 0) bg = true;
+        if (l <= 0 || l >= limit) l = 0;
+        if (l != cur || x == 0) {                       // label change or a new image row: close the run
+            if (cur > 0) f(cur, start, n, sy, sx);
+            cur = l; start = base + i; sx = x; sy = y; n = 0;
+        }
+        ++n;
+        if (++x == W) { x = 0; ++y; }
+    }
+    if (cur > 0) f(cur, start, n, sy, sx);
+    return bg;
+}
+
 // generic: first raster index per label (labels < L)
 __global__ void k_first(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
-    if (lab > 0) atomicMin(&WS(int, off_first)[lab], idx);
+    int *first = WS(int, off_first);
+    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
+                   [&](int lab, int idx, int, int, int) { atomicMin(&first[lab], idx); });
 }
 
 __global__ void k_fill_i32(size_t off, int n, int value, PPLayout lay, void *ws) {
@@ -342,16 +378,16 @@ __global__ void k_copy_scalar(int dst, int src, PPLayout lay, void *ws) {
 // ---------------------------------------------------------------------------
 // per-label bbox / count / coordinate sums
 __global__ void k_lab_stats(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
-    if (lab <= 0) return;
-    int y = idx / lay.W, x = idx - y * lay.W;
-    int *bb = WS(int, off_bbox) + 4 * lab;
-    atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x);
-    atomicAdd(&WS(int, off_cnt)[lab], 1);
-    atomicAdd(&WS(unsigned long long, off_sumy)[lab], (unsigned long long)y);
-    atomicAdd(&WS(unsigned long long, off_sumx)[lab], (unsigned long long)x);
+    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
+    unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
+    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
+                   [&](int lab, int, int n, int y, int x) {
+                       int *bb = bbox + 4 * lab;
+                       atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
+                       atomicAdd(&cnt[lab], n);
+                       atomicAdd(&sumy[lab], (unsigned long long)n * y);
+                       atomicAdd(&sumx[lab], (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2));
+                   });
 }
 
 __global__ void k_init_stats(PPLayout lay, void *ws) {
@@ -572,15 +608,13 @@ __global__ void k_zero_f64(size_t off, int n, PPLayout lay, void *ws) {
 // a14  fill_holes_and_remove_small_masks
 // ---------------------------------------------------------------------------
 __global__ void k_count_labels(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
-    if (lab > 0) {
-        atomicAdd(&WS(int, off_cnt)[lab], 1);
-        atomicMax(&WS(int, off_scal)[SC_VMAX], lab);
-    } else {
-        WS(int, off_scal)[SC_HASBG] = 1;
-    }
+    int *cnt = WS(int, off_cnt), *scal = WS(int, off_scal);
+    const bool bg = for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
+                                   [&](int lab, int, int n, int, int) {
+                                       atomicAdd(&cnt[lab], n);
+                                       atomicMax(&scal[SC_VMAX], lab);
+                                   });
+    if (bg) scal[SC_HASBG] = 1;
 }
 
 // counts = unique(masks, return_counts=True)[1][1:]; remove label VALUE (i+1) where
@@ -839,18 +873,18 @@ __global__ void k_to_u16(const int32_t *__restrict__ masks, uint16_t *__restrict
 }
 
 __global__ void k_rec_stats(const uint16_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
-    if (lab <= 0 || lab >= lay.L) return;
-    int y = idx / lay.W, x = idx - y * lay.W;
-    int *bb = WS(int, off_bbox) + 4 * lab;
-    atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x);
-    atomicAdd(&WS(int, off_cnt)[lab], 1);
-    atomicAdd(&WS(unsigned long long, off_sumy)[lab], (unsigned long long)y);
-    atomicAdd(&WS(unsigned long long, off_sumx)[lab], (unsigned long long)x);
-    atomicMin(&WS(int, off_first)[lab], idx);
-    atomicMax(&WS(int, off_scal)[SC_VMAX], lab);
+    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt), *first = WS(int, off_first), *scal = WS(int, off_scal);
+    unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
+    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, lay.L,
+                   [&](int lab, int idx, int n, int y, int x) {
+                       int *bb = bbox + 4 * lab;
+                       atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
+                       atomicAdd(&cnt[lab], n);
+                       atomicAdd(&sumy[lab], (unsigned long long)n * y);
+                       atomicAdd(&sumx[lab], (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2));
+                       atomicMin(&first[lab], idx);
+                       atomicMax(&scal[SC_VMAX], lab);
+                   });
 }
 
 __global__ void k_rec_write(const uint8_t *__restrict__ cm, int max_rec, cpx_record *__restrict__ rec,
@@ -911,7 +945,7 @@ static int pp_renumber(int32_t *masks, int nT, const PPLayout &lay, void *ws, hi
                        bool first_already) {
     if (!first_already) {
         hipLaunchKernelGGL(k_fill_i32, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay.off_first, lay.L, 0x7FFFFFFF, lay, ws);
-        hipLaunchKernelGGL(k_first, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+        hipLaunchKernelGGL(k_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     }
     hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal + sizeof(int) * SC_NLAB, 1, 0, lay, ws);
     hipLaunchKernelGGL(k_renumber_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, SC_VMAX, lay, ws);
@@ -956,7 +990,7 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
     hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_zero_f64, dim3(cpx_cdiv(2 * lay.THW, NTHR), nT), dim3(NTHR), 0, s, lay.off_T, 2 * lay.THW, lay, ws);
-    hipLaunchKernelGGL(k_lab_stats, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_d2, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_niter, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
@@ -972,7 +1006,7 @@ static void pp_size_filter(int32_t *masks, int nT, int min_size, const PPLayout 
                            hipStream_t s) {
     hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
     hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_count_labels, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
     hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     pp_renumber(masks, nT, lay, ws, s, false);
@@ -990,14 +1024,14 @@ extern "C" int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int
     else {   // labels may be non-contiguous: bbox loop below handles absent labels (slc None)
         hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
         hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-        hipLaunchKernelGGL(k_count_labels, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+        hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
         hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, lay, ws);
     }
     // find_objects(masks): bbox per label, then fill
     int nlab_saved_slot = SC_NLAB;
     (void)nlab_saved_slot;
     hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_lab_stats, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_copy_to_tmp, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_fill_serial, dim3(1, nT), dim3(NTHR), 0, s, masks, lay, ws);
@@ -1082,7 +1116,7 @@ extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *cl
     CPX_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * nT, s));
     hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
     hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_rec_stats, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks_u16, lay, ws);
+    hipLaunchKernelGGL(k_rec_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks_u16, lay, ws);
     hipLaunchKernelGGL(k_rec_write, GRID_LAB(lay, nT), dim3(NTHR), 0, s, class_masks, max_rec, records, counts, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
