@@ -457,10 +457,14 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
                                                   void *ws) {
     __shared__ double sT[2 * DIFF_LDS_CELLS];
     __shared__ unsigned char sL[DIFF_LDS_CELLS];
-    int lab = blockIdx.x + 1;
-    if (lab >= lay.L) return;
+    // persistent over labels: a fixed grid of workgroups strides through 1..vmax (k_niter left the largest
+    // occupied label in SC_VMAX) instead of one 60 KB-LDS workgroup per POSSIBLE label (L-1 = H*W/11 of them,
+    // ~99 % of which exited at once but still had to be dispatched and kept the GEMM workgroups off their CUs)
+    const int vmax = min(WS(int, off_scal)[SC_VMAX], lay.L - 1);
+  for (int lab = blockIdx.x + 1; lab <= vmax; lab += gridDim.x) {
+    __syncthreads();                                     // the previous label of this workgroup is done with sT / sL
     int n = WS(int, off_cnt)[lab];
-    if (n <= 0) return;
+    if (n <= 0) continue;
     const int *bb = WS(int, off_bbox) + 4 * lab;
     const int y0 = bb[0], x0 = bb[1];
     const int bh = bb[2] - y0 + 1, bw = bb[3] - x0 + 1;
@@ -541,6 +545,7 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
             }
         }
     }
+  }
 }
 
 // per-pixel squared error between mask-derived unit flows and network flows / 5
@@ -994,7 +999,7 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     hipLaunchKernelGGL(k_center_d2, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_niter, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_flow_err_pix, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, dP, lay, ws);
     hipLaunchKernelGGL(k_flow_err_label, GRID_LAB(lay, nT), dim3(NTHR), 0, s, masks, threshold, flow_errors, lay, ws);
     hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
