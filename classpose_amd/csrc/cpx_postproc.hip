@@ -44,7 +44,7 @@ static PPLayout pp_layout(int H, int W) {
     p.off_h1 = take(sizeof(int) * p.HWp);
     p.off_M1 = take(sizeof(int) * p.HWp);
     p.off_tmp = take(sizeof(int) * p.HW);
-    p.off_im = take(sizeof(float) * 2 * p.HW);
+    p.off_im = take(sizeof(float) * 2 * p.THW);      // zero-bordered interleaved flow field [H+2][W+2][dx, dy]
     p.off_T = take(sizeof(double) * 2 * p.THW);
     p.off_e = take(sizeof(double) * 2 * p.HW);
     p.off_seed_pos = take(sizeof(int) * p.L);
@@ -85,22 +85,28 @@ extern "C" int cpx_postproc_max_labels(int H, int W) { return H * W / 11 + 2; }
 // a11  follow_flows
 // ---------------------------------------------------------------------------
 // im = (dP * (cellprob > thr) / 5) * (2 / (size-1))   [numpy fp32 ops, then torch fp32 scalar mul]
+// flow field of the Euler loop: (dX, dY) * mask / 5 * 2/(size-1), interleaved and zero-bordered by one pixel,
+// so that a bilinear sample is two 16-byte loads (one per row) with no bounds tests -- the loop is bound by
+// the texture-addresser rate of its gathers (8 scalar taps per step before)
 __global__ void k_prep_flow(const float *__restrict__ dP, const float *__restrict__ cp, float thr,
                             float kx, float ky, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
+    int c = blockIdx.x * NTHR + threadIdx.x;
+    if (c >= lay.THW) return;
     size_t t = blockIdx.y;
-    float m = cp[t * lay.HW + idx] > thr ? 1.0f : 0.0f;
-    float dy = dP[(t * 2 + 0) * lay.HW + idx];
-    float dx = dP[(t * 2 + 1) * lay.HW + idx];
-    float *im = WS(float, off_im);
-    im[idx] = __fdiv_rn(dx * m, 5.0f) * kx;               // im[0] = dX
-    im[lay.HW + idx] = __fdiv_rn(dy * m, 5.0f) * ky;      // im[1] = dY
+    const int py = c / lay.TW, px = c - py * lay.TW;
+    float2 v = make_float2(0.f, 0.f);
+    if (py >= 1 && py <= lay.H && px >= 1 && px <= lay.W) {
+        const int idx = (py - 1) * lay.W + (px - 1);
+        float m = cp[t * lay.HW + idx] > thr ? 1.0f : 0.0f;
+        float dy = dP[(t * 2 + 0) * lay.HW + idx];
+        float dx = dP[(t * 2 + 1) * lay.HW + idx];
+        v.x = __fdiv_rn(dx * m, 5.0f) * kx;               // im[0] = dX
+        v.y = __fdiv_rn(dy * m, 5.0f) * ky;               // im[1] = dY
+    }
+    reinterpret_cast<float2 *>(WS(float, off_im))[c] = v;
 }
 
-__device__ __forceinline__ float tap(const float *im, int H, int W, int y, int x) {
-    return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? im[y * W + x] : 0.0f;
-}
+typedef float flow4 __attribute__((ext_vector_type(4), aligned(8)));
 
 __global__ void k_follow(const float *__restrict__ cp, float thr, int niter, float shx, float shy,
                          float hw, float hh, int32_t *__restrict__ p_final,
@@ -114,8 +120,8 @@ __global__ void k_follow(const float *__restrict__ cp, float thr, int niter, flo
         if (p_float) { p_float[(t * 2) * lay.HW + idx] = -1.f; p_float[(t * 2 + 1) * lay.HW + idx] = -1.f; }
         return;
     }
-    const float *imx = WS(float, off_im);
-    const float *imy = imx + lay.HW;
+    const float *im = WS(float, off_im);
+    const int TW = lay.TW;
     int y = idx / W, x = idx - y * W;
     float px = __fdiv_rn((float)x, shx);
     float py = __fdiv_rn((float)y, shy);
@@ -128,13 +134,14 @@ __global__ void k_follow(const float *__restrict__ cp, float thr, int niter, flo
         float x_w = floorf(fx), y_n = floorf(fy);
         float w = fx - x_w, e = 1.0f - w, n = fy - y_n, s = 1.0f - n;
         float nw = s * e, ne = s * w, sw = n * e, se = n * w;
-        int x0 = (int)x_w, y0 = (int)y_n;
-        float dx = __fmaf_rn(tap(imx, H, W, y0 + 1, x0 + 1), se,
-                   __fmaf_rn(tap(imx, H, W, y0 + 1, x0), sw,
-                   __fmaf_rn(tap(imx, H, W, y0, x0 + 1), ne, tap(imx, H, W, y0, x0) * nw)));
-        float dy = __fmaf_rn(tap(imy, H, W, y0 + 1, x0 + 1), se,
-                   __fmaf_rn(tap(imy, H, W, y0 + 1, x0), sw,
-                   __fmaf_rn(tap(imy, H, W, y0, x0 + 1), ne, tap(imy, H, W, y0, x0) * nw)));
+        // positions are clamped to [-1, 1], so x0 is in [-1, W-1] and the 2x2 taps lie inside the bordered
+        // field (the min/max only keeps a NaN position from addressing outside the buffer)
+        int x0 = min(max((int)x_w, -1), W - 1), y0 = min(max((int)y_n, -1), H - 1);
+        const float *r0 = im + ((size_t)(y0 + 1) * TW + (x0 + 1)) * 2;
+        const flow4 a = *reinterpret_cast<const flow4 *>(r0);                 // (dx, dy) at x0, (dx, dy) at x0+1
+        const flow4 b = *reinterpret_cast<const flow4 *>(r0 + (size_t)TW * 2);
+        float dx = __fmaf_rn(b[2], se, __fmaf_rn(b[0], sw, __fmaf_rn(a[2], ne, a[0] * nw)));
+        float dy = __fmaf_rn(b[3], se, __fmaf_rn(b[1], sw, __fmaf_rn(a[3], ne, a[1] * nw)));
         float nx = px + dx; nx = nx < -1.0f ? -1.0f : (nx > 1.0f ? 1.0f : nx);
         float ny = py + dy; ny = ny < -1.0f ? -1.0f : (ny > 1.0f ? 1.0f : ny);
         // The step is a pure function of the position, so the remaining iterations can be skipped EXACTLY
@@ -937,7 +944,7 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
-    hipLaunchKernelGGL(k_prep_flow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, dP, cellprob, thr, kx, ky, lay, ws);
+    hipLaunchKernelGGL(k_prep_flow, dim3(cpx_cdiv(lay.THW, NTHR), nT), dim3(NTHR), 0, s, dP, cellprob, thr, kx, ky, lay, ws);
     hipLaunchKernelGGL(k_follow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, cellprob, thr, niter,
                        (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
                        p_float, lay, ws, g_follow_early);
