@@ -271,52 +271,14 @@ __global__ void k_seed_grow(PPLayout lay, void *ws) {
     }
 }
 
-// label gather + per-label pixel count (label 0 not counted)
-__global__ void k_gather(const int32_t *__restrict__ p_final, int32_t *__restrict__ masks,
-                         PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    size_t t = blockIdx.y;
-    int p = p_final[t * lay.HW + idx];
-    int lab = 0;
-    if (p != -1) {
-        int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
-        py = min(max(py, 0), lay.H + RPAD - 1); px = min(max(px, 0), lay.W + RPAD - 1);
-        lab = WS(int, off_M1)[py * lay.Wp + px];
-    }
-    masks[t * lay.HW + idx] = lab;
-    if (lab > 0) atomicAdd(&WS(int, off_cnt)[lab], 1);
-}
-
-// big-mask removal (count > H*W*fraction) + first raster index per surviving label
-__global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    size_t t = blockIdx.y;
-    int lab = masks[t * lay.HW + idx];
-    if (lab <= 0) return;
-    if ((double)WS(int, off_cnt)[lab] > big) { masks[t * lay.HW + idx] = 0; return; }
-    atomicMin(&WS(int, off_first)[lab], idx);
-}
-
 // Label statistics visit RUNS, not pixels: a thread owns 8 consecutive pixels and calls f(label, first
 // linear index, run length, y, x of the first pixel) once per maximal run of one positive label on one image
 // row (instances are ~15 px wide, so this issues ~8x fewer atomics than one call per pixel; all updates are
 // integer min / max / add, so the results are identical).  Returns true if the thread saw a background pixel.
 #define RUN_PX 8
 #define GRID_RUN(lay, nT) dim3(cpx_cdiv(cpx_cdiv((lay).HW, RUN_PX), NTHR), (nT))
-template <typename T, typename F>
-__device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, int W, int limit, F &&f) {
-    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
-    if (base >= HW) return false;
-    int lab[RUN_PX];
-    if (base + RUN_PX <= HW && sizeof(T) == 4 && (reinterpret_cast<size_t>(m + base) & 15) == 0) {
-        const int4 a = *reinterpret_cast<const int4 *>(m + base), b = *reinterpret_cast<const int4 *>(m + base + 4);
-        lab[0] = a.x; lab[1] = a.y; lab[2] = a.z; lab[3] = a.w; lab[4] = b.x; lab[5] = b.y; lab[6] = b.z; lab[7] = b.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < RUN_PX; ++i) lab[i] = base + i < HW ? (int)m[base + i] : 0;
-    }
+template <typename F>
+__device__ __forceinline__ bool label_runs(const int (&lab)[RUN_PX], int base, int HW, int W, int limit, F &&f) {
     bool bg = false;
     int y = base / W, x = base - y * W;
     int cur = 0, start = 0, sx = 0, sy = 0, n = 0;
@@ -334,6 +296,56 @@ __device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, 
     }
     if (cur > 0) f(cur, start, n, sy, sx);
     return bg;
+}
+template <typename T, typename F>
+__device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, int W, int limit, F &&f) {
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
+    if (base >= HW) return false;
+    int lab[RUN_PX];
+    if (base + RUN_PX <= HW && sizeof(T) == 4 && (reinterpret_cast<size_t>(m + base) & 15) == 0) {
+        const int4 a = *reinterpret_cast<const int4 *>(m + base), b = *reinterpret_cast<const int4 *>(m + base + 4);
+        lab[0] = a.x; lab[1] = a.y; lab[2] = a.z; lab[3] = a.w; lab[4] = b.x; lab[5] = b.y; lab[6] = b.z; lab[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) lab[i] = base + i < HW ? (int)m[base + i] : 0;
+    }
+    return label_runs(lab, base, HW, W, limit, f);
+}
+
+// label gather + per-label pixel count (label 0 not counted)
+__global__ void k_gather(const int32_t *__restrict__ p_final, int32_t *__restrict__ masks,
+                         PPLayout lay, void *ws) {
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
+    if (base >= lay.HW) return;
+    const size_t t = blockIdx.y;
+    const int *M1 = WS(int, off_M1);
+    int lab[RUN_PX];
+#pragma unroll
+    for (int i = 0; i < RUN_PX; ++i) {
+        lab[i] = 0;
+        if (base + i < lay.HW) {
+            const int p = p_final[t * lay.HW + base + i];
+            if (p != -1) {
+                int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
+                py = min(max(py, 0), lay.H + RPAD - 1); px = min(max(px, 0), lay.W + RPAD - 1);
+                lab[i] = M1[py * lay.Wp + px];
+            }
+            masks[t * lay.HW + base + i] = lab[i];
+        }
+    }
+    int *cnt = WS(int, off_cnt);
+    label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int, int n, int, int) { atomicAdd(&cnt[l], n); });
+}
+
+// big-mask removal (count > H*W*fraction) + first raster index per surviving label
+__global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout lay, void *ws) {
+    const int *cnt = WS(int, off_cnt);
+    int *first = WS(int, off_first);
+    int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    for_label_runs(m, lay.HW, lay.W, 0x7FFFFFFF, [&](int lab, int idx, int n, int, int) {
+        if ((double)cnt[lab] > big) { for (int i = 0; i < n; ++i) m[idx + i] = 0; }
+        else atomicMin(&first[lab], idx);
+    });
 }
 
 // generic: first raster index per label (labels < L)
@@ -424,14 +436,18 @@ __device__ __forceinline__ double center_d2(int y, int x, const int *bb, int n,
 }
 
 __global__ void k_center_d2(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    int lab = masks[(size_t)blockIdx.y * lay.HW + idx];
-    if (lab <= 0) return;
-    int y = idx / lay.W, x = idx - y * lay.W;
-    double d2 = center_d2(y, x, WS(int, off_bbox) + 4 * lab, WS(int, off_cnt)[lab],
-                          WS(unsigned long long, off_sumy)[lab], WS(unsigned long long, off_sumx)[lab]);
-    atomicMin(&WS(unsigned long long, off_d2)[lab], (unsigned long long)__double_as_longlong(d2));
+    const int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
+    const unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
+    unsigned long long *d2min = WS(unsigned long long, off_d2);
+    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
+                   [&](int lab, int, int n, int y, int x) {
+                       unsigned long long best = 0xFFFFFFFFFFFFFFFFull;      // d2 >= 0: the bit pattern orders like the value
+                       for (int i = 0; i < n; ++i) {
+                           const double d2 = center_d2(y, x + i, bbox + 4 * lab, cnt[lab], sumy[lab], sumx[lab]);
+                           best = min(best, (unsigned long long)__double_as_longlong(d2));
+                       }
+                       atomicMin(&d2min[lab], best);
+                   });
 }
 
 __global__ void k_center_pick(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
@@ -980,9 +996,9 @@ extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, doubl
     hipLaunchKernelGGL(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_seed_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_seed_grow, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_gather, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
+    hipLaunchKernelGGL(k_gather, GRID_RUN(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
     double big = (double)((long long)H * W) * max_size_fraction;
-    hipLaunchKernelGGL(k_big_first, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
+    hipLaunchKernelGGL(k_big_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
     // labels here are seed ranks 1..nseeds
     hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_VMAX, SC_NSEEDS, lay, ws);
     pp_renumber(masks, nT, lay, ws, s, true);
@@ -1003,7 +1019,7 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_zero_f64, dim3(cpx_cdiv(2 * lay.THW, NTHR), nT), dim3(NTHR), 0, s, lay.off_T, 2 * lay.THW, lay, ws);
     hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_center_d2, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_niter, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
