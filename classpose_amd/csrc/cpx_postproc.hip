@@ -597,19 +597,45 @@ __global__ void k_flow_err_pix(const int32_t *__restrict__ masks, const float *_
 }
 
 // scipy.ndimage.mean: per-label sums accumulated in raster order (np.bincount), / count
-__global__ void k_flow_err_label(const int32_t *__restrict__ masks, double thr,
-                                 double *__restrict__ errs_out, PPLayout lay, void *ws) {
-    int v = blockIdx.x * NTHR + threadIdx.x + 1;
+// One WAVE per label: the lanes fetch 64 bbox pixels at a time (coalesced), then the wave adds the label's
+// values one by one in raster order -- np.bincount's sequential float64 summation -- by broadcasting lane
+// after lane (v_readlane); the old one-thread-per-label loop chased ~3 dependent loads per pixel (148 us).
+__device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), src_lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restrict__ masks, double thr,
+                                                         double *__restrict__ errs_out, PPLayout lay, void *ws) {
+    const int lane = threadIdx.x & 63;
+    const int v = (blockIdx.x * NTHR + threadIdx.x) / 64 + 1;          // wave-uniform label
     if (v >= lay.L) return;
-    int n = WS(int, off_cnt)[v];
-    if (n <= 0) { if (errs_out) errs_out[(size_t)blockIdx.y * lay.L + v - 1] = 0.0; return; }
+    const int n = WS(int, off_cnt)[v];
+    if (n <= 0) { if (errs_out && lane == 0) errs_out[(size_t)blockIdx.y * lay.L + v - 1] = 0.0; return; }
     const int *bb = WS(int, off_bbox) + 4 * v;
+    const int y0 = bb[0], x0 = bb[1], bw = bb[3] - x0 + 1, npx = (bb[2] - y0 + 1) * bw;
     const int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
     const double *e = WS(double, off_e);
     double sy = 0.0, sx = 0.0;
-    for (int y = bb[0]; y <= bb[2]; ++y)
-        for (int x = bb[1]; x <= bb[3]; ++x)
-            if (m[y * lay.W + x] == v) { sy = sy + e[y * lay.W + x]; sx = sx + e[lay.HW + y * lay.W + x]; }
+    for (int q0 = 0; q0 < npx; q0 += 64) {
+        const int q = q0 + lane;
+        bool in = false;
+        double ey = 0.0, ex = 0.0;
+        if (q < npx) {
+            const int ly = q / bw, p = (y0 + ly) * lay.W + x0 + (q - ly * bw);
+            in = m[p] == v;
+            if (in) { ey = e[p]; ex = e[lay.HW + p]; }
+        }
+        unsigned long long todo = __ballot(in);
+        while (todo) {                                                 // ascending lanes = raster order
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            sy = sy + wave_bcast_f64(ey, i);
+            sx = sx + wave_bcast_f64(ex, i);
+        }
+    }
+    if (lane != 0) return;
     double err = 0.0;
     err = err + sy / (double)n;
     err = err + sx / (double)n;
@@ -1024,7 +1050,7 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     hipLaunchKernelGGL(k_niter, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_flow_err_pix, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, dP, lay, ws);
-    hipLaunchKernelGGL(k_flow_err_label, GRID_LAB(lay, nT), dim3(NTHR), 0, s, masks, threshold, flow_errors, lay, ws);
+    hipLaunchKernelGGL(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, threshold, flow_errors, lay, ws);
     hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
