@@ -196,3 +196,21 @@ def test_compute_masks_maximum_tile_1024(cuda):
     assert np.array_equal(ops.masks_to_numpy(m)[0], ref)
     cref_, _ = classmask.compute_class_masks(ref, lg)
     assert np.array_equal(cm.cpu().numpy()[0], cref_.astype(np.uint8))
+
+
+@pytest.mark.parametrize("H,W", [(61, 53), (97, 131), (40, 203)])
+def test_compute_masks_odd_sizes_batched(cuda, H, W):
+    """odd H, W and H*W not a multiple of 8: 8-pixel runs straddle image rows, tile bases are not 16-byte
+    aligned, the bordered flow field has an odd row pitch -- ids, classes and records still equal the oracle"""
+    tiles = [_fields(k, H, W, s) for k, s in (("discs", 3), ("noisy_discs", 4), ("random", 5))]
+    dP = torch.from_numpy(np.stack([t[0] for t in tiles])).to(cuda)
+    cp = torch.from_numpy(np.stack([t[1] for t in tiles])).to(cuda)
+    lg = torch.from_numpy(np.stack([t[2] for t in tiles])).to(cuda)
+    m, cm, nlab = ops.compute_masks(dP, cp, lg)
+    mh = ops.masks_to_numpy(m)
+    for i, (a, b, c) in enumerate(tiles):
+        ref = dynamics.compute_masks(a, b)
+        assert np.array_equal(mh[i], ref), i
+        cref_, _ = classmask.compute_class_masks(ref, c)
+        assert np.array_equal(cm.cpu().numpy()[i], cref_.astype(np.uint8)), i
+        assert int(nlab[i]) == ref.max()
