@@ -62,21 +62,28 @@ def cpu_baseline(sd, coords, budget_s=12.0, max_tiles=4):
     fw = net.make_forward(sd, torch.float32)
     fw(np.zeros((1, 3, 256, 256), np.float32))                       # warm-up (thread pool, caches)
     n, cells, dt = 0, 0, 0.0
+    stage = {"normalise": 0.0, "network": 0.0, "dynamics": 0.0, "class_vote_records": 0.0}
     while n < max_tiles and (n == 0 or dt < budget_s):
         (x0, y0), _ = coords[n]
         tile = synth.render_region(1234, x0, y0, TILE, TILE)           # rendering is not timed
         dP, cp, lg, _ = synth.analytic_fields(1234, x0, y0, TILE, TILE, NCLS)
         t1 = time.perf_counter()
         x = tiling.normalize_img(tile[None])
+        t2 = time.perf_counter()
         tiling.run_net(fw, x, batch_size=8, bsize=256)
+        t3 = time.perf_counter()
         m = dynamics.compute_masks(dP, cp)
+        t4 = time.perf_counter()
         cm, _ = classmask.compute_class_masks(m, lg)
         classmask.instance_records(m, cm)
-        dt += time.perf_counter() - t1
+        t5 = time.perf_counter()
+        dt += t5 - t1
+        for k, v in zip(stage, (t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            stage[k] += v
         cells += int(m.max())
         n += 1
     return dict(value=n / dt, unit="tiles/s", cores=cores, kind="port",
-                cells_per_s=cells / dt,
+                cells_per_s=cells / dt, stage_ms_per_tile={k: round(v / n * 1e3, 2) for k, v in stage.items()},
                 sample=f"{n} tiles of the same workload, one tile per eval (4 sub-tiles, fp32 torch-CPU "
                        f"ViT-L + oracle dynamics on the injected fields), {dt:.1f} s")
 
