@@ -18,6 +18,7 @@
 // blocks that share an XCD (id % 8) walk a contiguous band of M rows and re-use
 // the activation panel from that XCD's L2.
 #include "cpx_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -330,8 +331,17 @@ __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][
 #define G2_BAR() __builtin_amdgcn_s_barrier()
 #define G2_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int EPI, bool F16>
+// FLAGS (compile time, so that none of these tests sits inside the unrolled epilogue loops -- the runtime
+// versions cost ~250 scalar branches per lane and tile): 1 = consume a folded LayerNorm (g.ln_stats),
+// 2 = emit row statistics (g.stats_out, residual epilogue only), 4 = honour the g.dbg timing ablations
+#define G2F_LN 1
+#define G2F_STATS 2
+#define G2F_DBG 4
+template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
+    constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16;
+    constexpr bool STATS = (FLAGS & G2F_STATS) != 0 && EPI == CPX_EPI_RESID_BF16;
+    constexpr bool DBG = (FLAGS & G2F_DBG) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,7 +412,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     // folded LayerNorm: the tile's 256 token rows get their (rstd, -mean * rstd) once, computed by one lane
     // each under the prologue's DMA latency and parked in the LDS tail for the epilogue.  The statistics are
     // requested BEFORE the DMA so that waiting for them (in-order vmcnt) does not drain the staging.
-    const bool ln_in = EPI != CPX_EPI_RESID_BF16 && g.ln_stats != nullptr && tid < 256;
+    const bool ln_in = LN_IN && tid < 256;
     float4 st_a = make_float4(0.f, 0.f, 0.f, 0.f), st_b = st_a;
     if (ln_in) {
         st_a = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8);
@@ -463,7 +473,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
     __builtin_amdgcn_sched_barrier(0);
 
-    if (g.dbg & 4) {            // timing-only ablation: main loop + prologue, accumulators kept live
+    if (DBG && (g.dbg & 4)) {   // timing-only ablation: main loop + prologue, accumulators kept live
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -478,7 +488,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;     // V third of the qkv projection
     const int c16 = tid & 31;                   // 16-byte chunk within a 512-byte row (store phase)
     float ln_mean[2][4], ln_rstd[2][4];         // this lane's 8 token rows (hm, mb)
-    if (EPI != CPX_EPI_RESID_BF16 && g.ln_stats) {
+    if constexpr (LN_IN) {
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -487,6 +497,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                 ln_rstd[hm][mb] = p.x; ln_mean[hm][mb] = p.y;      // ln_mean holds -mean * rstd
             }
     }
+    uint2 direct_prev = make_uint2(0u, 0u);
     uint4 rres[16];
     if constexpr (EPI == CPX_EPI_RESID_BF16) {  // residual rows: issue the loads now, consume after the LDS pass
 #pragma unroll
@@ -496,7 +507,6 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     }
     // this lane's 4 column groups (hn, nb): bias and LayerNorm column sums once, not once per accumulator
     // (the LDS stores below alias every pointer for the compiler, so it would reload them 32 times)
-    constexpr bool LN_IN = EPI != CPX_EPI_RESID_BF16;      // the residual GEMMs never consume a folded LayerNorm
     float4 colb[2][2], colc[2][2];
 #pragma unroll
     for (int hn = 0; hn < 2; ++hn)
@@ -504,9 +514,11 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
         for (int nb = 0; nb < 2; ++nb) {
             const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
             colb[hn][nb] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (LN_IN)
-                colc[hn][nb] = g.ln_stats ? *reinterpret_cast<const float4 *>(g.ln_colsum + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (LN_IN) colc[hn][nb] = *reinterpret_cast<const float4 *>(g.ln_colsum + n0 + nl);
         }
+    // the V third of the qkv projection stages a transposed image; resolved per tile OUTSIDE the unrolled loops
+    auto convert_and_stage = [&](auto vt_tag) {
+        constexpr bool VT = decltype(vt_tag)::value;
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -519,7 +531,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                     const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
                     f32x4 v = acc[hm][hn][mb][nb];
                     const float4 b = colb[hn][nb];
-                    if (LN_IN && g.ln_stats) {
+                    if constexpr (LN_IN) {
                         // rstd * (acc - mean * colsum) + bias = fma(acc, rstd, fma(-mean * rstd, colsum, bias))
                         const float4 cs = colc[hn][nb];
                         const float nm = ln_mean[hm][mb], rs = ln_rstd[hm][mb];      // ln_mean holds -mean * rstd
@@ -529,7 +541,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                     if constexpr (EPI == CPX_EPI_GELU_BF16) {
-                        if (!(g.dbg & 2)) {
+                        if (!DBG || !(g.dbg & 2)) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
                         }
@@ -537,7 +549,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    if (vt_tile) {              // transposed image [channel][token] for the V^T layout
+                    if constexpr (VT) {          // transposed image [channel][token] for the V^T layout
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             *reinterpret_cast<unsigned short *>(smem + (nl + r) * G2_EPI_LD + ml * 2) = to_half<F16>(v[r]);
@@ -545,9 +557,29 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                         uint2 o;
                         o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
                         o.y = (unsigned)to_half<F16>(v[2]) | ((unsigned)to_half<F16>(v[3]) << 16);
+                        if (DBG && EPI != CPX_EPI_RESID_BF16 && (g.dbg & 8)) {
+                            // EXPERIMENT (timing + correctness switch): no LDS staging.  Lanes fq and fq^1 (16 lanes
+                            // apart) trade one 8-byte piece so that each holds 8 consecutive channels -- the even
+                            // one of the nb = 0 block, the odd one of the nb = 1 block -- and stores 16 bytes itself
+                            // (64 contiguous bytes per token row and wave instead of whole 512-byte rows).
+                            if (nb == 0) { direct_prev = o; }
+                            else {
+                                const uint2 send = (fq & 1) ? direct_prev : o;
+                                uint2 recv;
+                                recv.x = __shfl_xor((int)send.x, 16); recv.y = __shfl_xor((int)send.y, 16);
+                                const uint4 w = (fq & 1) ? make_uint4(recv.x, recv.y, o.x, o.y)
+                                                         : make_uint4(direct_prev.x, direct_prev.y, recv.x, recv.y);
+                                const int ch = hn * 128 + wn * 32 + ((fq & 1) ? 16 : 0) + (fq >> 1) * 8;
+                                *reinterpret_cast<uint4 *>((unsigned short *)g.out + (size_t)(m0 + ml) * g.ld_out + n0 + ch) = w;
+                            }
+                        } else
                         *reinterpret_cast<uint2 *>(smem + ml * G2_EPI_LD + nl * 2) = o;
                     }
                 }
+    };
+    if (EPI == CPX_EPI_QKV_BF16 && vt_tile) convert_and_stage(std::true_type{});
+    else convert_and_stage(std::false_type{});
+    if (DBG && EPI != CPX_EPI_RESID_BF16 && (g.dbg & 8) && !vt_tile) return;
     __syncthreads();
     if (vt_tile) {
         // LDS row = channel c (head = c/64, d = c%64), 256 tokens contiguous -> vT[s][head][d][t0..t0+255]
@@ -577,8 +609,8 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                 }
                 v = make_uint4(a[0], a[1], a[2], a[3]);
             }
-            if (!(g.dbg & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = v;
-            if (g.stats_out) {
+            if (!DBG || !(g.dbg & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = v;
+            if constexpr (STATS) {
                 // partial LayerNorm statistics of the (rounded) output row over this block's 256 columns:
                 // 32 lanes share a row; slot = column tile, written whole -> deterministic, no atomics
                 unsigned a[4] = {v.x, v.y, v.z, v.w};
@@ -614,20 +646,36 @@ extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 static int g_gemm_big = 1;         // 1 = use the 256^2 kernel when the shape allows
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 
+template <int EPI, bool F16, int FLAGS>
+static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gemm256<EPI, F16, FLAGS>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
+}
+
 template <int EPI, bool F16>
 static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
     if constexpr (EPI == CPX_EPI_F32 || EPI == CPX_EPI_POS_BF16) return false;
     else {
         if (!g_gemm_big || a0.M % 256 || a0.N % 256 || (a0.K / 64) % 2 || a0.K < 128) return false;
         if ((a0.M / 256) * (a0.N / 256) < 256) return false;          // not enough tiles for 256 CUs
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
-            attr_done = true;
-        }
         GemmArgs a = a0;
         a.tiles_n = a.N / 256; a.n_blocks = (a.M / 256) * (a.N / 256);
-        hipLaunchKernelGGL((k_gemm256<EPI, F16>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
+        // one instantiation per (LayerNorm consumer | statistics producer) x (timing ablations, bf16 only)
+        constexpr int F1 = EPI == CPX_EPI_RESID_BF16 ? G2F_STATS : G2F_LN;
+        const bool f1 = EPI == CPX_EPI_RESID_BF16 ? a.stats_out != nullptr : a.ln_stats != nullptr;
+        if constexpr (!F16) {
+            if (a.dbg) {
+                if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DBG>(a, s);
+                else launch_gemm256_flags<EPI, F16, G2F_DBG>(a, s);
+                return true;
+            }
+        }
+        if (f1) launch_gemm256_flags<EPI, F16, F1>(a, s);
+        else launch_gemm256_flags<EPI, F16, 0>(a, s);
         return true;
     }
 }

@@ -12,7 +12,7 @@ for name, N, K, epi in (("fc1", 4096, 1024, "gelu"), ("qkv-like", 3072, 1024, "b
     b = torch.randn(N, generator=g).to(dev)
     res = {}
     for rnd in range(3):
-        for dbg, label in ((0, "full"), (2, "no GELU math"), (1, "no global stores"), (3, "neither"), (4, "no epilogue")):
+        for dbg, label in ((0, "full"), (2, "no GELU math"), (1, "no global stores"), (3, "neither"), (4, "no epilogue"), (8, "direct 16-B stores, no LDS staging")):
             L.cpx_gemm_set_dbg(dbg)
             for _ in range(3): ops.gemm(A, W, epi, b)
             torch.cuda.synchronize()
