@@ -109,6 +109,7 @@ SIGNATURES = {
 _PRIVATE = {
     "cpx_gemm_set_variant": (None, [_i]),
     "cpx_prof_set_stride": (None, [_i]),
+    "cpx_attention_set_trv": (None, [_i]),
     "cpx_follow_set_early_exit": (None, [_i]),
     "cpx_gemm_set_reverse": (None, [_i]),
     "cpx_attention_set_xcd_order": (None, [_i]),

@@ -182,7 +182,9 @@ __device__ __forceinline__ int pi_perm(int r) { return (r & ~12) | ((r & 4) << 1
     do {                                                                                       \
         if constexpr (DBG) { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(x)); asm volatile("" ::"v"(d_)); } \
     } while (0)
-template <bool F16, bool DBG = false>
+// TRV: V is read in its natural [token][d] layout straight from the qkv rows and transposed by the LDS read
+// (ds_read_b64_tr_b16) instead of coming pre-transposed from a V^T buffer written by the qkv GEMM
+template <bool F16, bool DBG = false, bool TRV = false>
 __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short *__restrict__ qkv,
                                                            const unsigned short *__restrict__ vT,
                                                            const unsigned short *__restrict__ relh,
@@ -198,6 +200,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     __shared__ float sG[4][32 * GS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
+    const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short *)&sV[0][0];
     // XCD-aware block order: workgroups go round-robin to the 8 XCDs by linear id, and the 8 row groups of
     // one (sub-tile, head) stream the same 256 KB of K / V^T -- keep them on ONE XCD's L2 (per-XCD order:
     // 8 consecutive workgroups = one pair) instead of fetching that pair once per XCD (fabric reads / 8)
@@ -249,9 +252,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     const int k_key = tid >> 3, k_c = tid & 7;            // K tile: 32 keys x 8 chunks
     const int v_d = tid >> 2, v_c = tid & 3;              // V^T tile: 64 d x 4 chunks
     const unsigned short *kbase = qkv + (tok0 + k_key) * 3072 + 1024 + head * 64 + k_c * 8;
-    const unsigned short *vbase = vT + (((size_t)s * 16 + head) * 64 + v_d) * 1024 + v_c * 8;
+    const unsigned short *vbase = TRV ? qkv + (tok0 + k_key) * 3072 + 2048 + head * 64 + k_c * 8
+                                      : vT + (((size_t)s * 16 + head) * 64 + v_d) * 1024 + v_c * 8;
+    const size_t v_tile_step = TRV ? (size_t)32 * 3072 : 32;            // elements from one key tile to the next
     const int k_dst = k_key * 64 + ((k_c ^ (k_key & 7)) * 8);
-    const int v_dst = v_d * 32 + ((v_c ^ ((v_d >> 2) & 3)) * 8);
+    // TRV image: [32 keys][64 d], 16-byte chunk c of key row k at position c ^ 4*((k>>1)&1): the four rows a
+    // transposed read touches per half-wave then fall on disjoint banks
+    const int v_dst = TRV ? k_key * 64 + ((k_c ^ (((k_key >> 1) & 1) * 4)) * 8)
+                          : v_d * 32 + ((v_c ^ ((v_d >> 2) & 3)) * 8);
     // K / V^T tiles reach LDS through a 4-deep REGISTER ring: the global loads for key tile t+3 are
     // issued in iteration t and written to LDS at the end of iteration t+2, so each load has two
     // full iterations to land (one iteration did not cover the L2/HBM latency: a lone workgroup
@@ -260,9 +268,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     kr0 = *reinterpret_cast<const uint4 *>(kbase);
     vr0 = *reinterpret_cast<const uint4 *>(vbase);
     kr1 = *reinterpret_cast<const uint4 *>(kbase + (size_t)1 * 32 * 3072);
-    vr1 = *reinterpret_cast<const uint4 *>(vbase + 1 * 32);
+    vr1 = *reinterpret_cast<const uint4 *>(vbase + 1 * v_tile_step);
     kr2 = *reinterpret_cast<const uint4 *>(kbase + (size_t)2 * 32 * 3072);
-    vr2 = *reinterpret_cast<const uint4 *>(vbase + 2 * 32);
+    vr2 = *reinterpret_cast<const uint4 *>(vbase + 2 * v_tile_step);
     kr3 = kr0; vr3 = vr0;
     *reinterpret_cast<uint4 *>(&sK[0][k_dst]) = kr0;
     *reinterpret_cast<uint4 *>(&sV[0][v_dst]) = vr0;
@@ -284,7 +292,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     auto tile = [&](const int kh, const int buf, uint4 &k_ld, uint4 &v_ld, const uint4 &k_st, const uint4 &v_st) {
         if (kh + 3 < 32) {
             k_ld = *reinterpret_cast<const uint4 *>(kbase + (size_t)(kh + 3) * 32 * 3072);
-            v_ld = *reinterpret_cast<const uint4 *>(vbase + (kh + 3) * 32);
+            v_ld = *reinterpret_cast<const uint4 *>(vbase + (kh + 3) * v_tile_step);
         }
         // S' = K . Q^T + Gw   (Gw rides in as the MFMA C operand; Gh is one scalar per lane and
         // is folded into the exponent offset, so the bias costs no per-element VALU work)
@@ -344,7 +352,29 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
             const int d = db * 32 + r;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                uint4 vf = *reinterpret_cast<const uint4 *>(&sV[buf][d * 32 + (((2 * st + h2) ^ ((d >> 2) & 3)) * 8)]);
+                uint4 vf;
+                if constexpr (TRV) {
+                    // lane 16g + 4q + p supplies the address of key row k0 + q, d columns 4p..4p+3 of its group's
+                    // 16-column block and receives d column (lane & 15) of the 4 rows: two reads = 8 keys
+                    const int p_ = lane & 3, q_ = (lane >> 2) & 3, g1 = (lane >> 4) & 1;
+                    const int c = db * 4 + g1 * 2 + (p_ >> 1);
+                    unsigned long long lo, hi;
+                    {
+                        const int row = st * 16 + h2 * 8 + q_;
+                        const unsigned a = lds_v + (unsigned)(buf * 64 * 32 + row * 64 + ((c ^ (((row >> 1) & 1) * 4)) * 8) + (p_ & 1) * 4) * 2;
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+                    }
+                    {
+                        const int row = st * 16 + h2 * 8 + 4 + q_;
+                        const unsigned a = lds_v + (unsigned)(buf * 64 * 32 + row * 64 + ((c ^ (((row >> 1) & 1) * 4)) * 8) + (p_ & 1) * 4) * 2;
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    vf = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+                } else {
+                    vf = *reinterpret_cast<const uint4 *>(&sV[buf][d * 32 + (((2 * st + h2) ^ ((d >> 2) & 3)) * 8)]);
+                }
                 O[db] = mfma32<F16>(vf, pf[st], O[db]);
             }
         }
@@ -394,6 +424,11 @@ static int attention_launch(const void *qkv, const void *rel_h, const void *rel_
                             void *vT_ws, void *out, void *stream, bool transpose_v);
 static int g_att_xcd = 1;          // XCD-aware workgroup order (debug / A-B switch)
 extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
+// experiment switch (default off): V read from the qkv rows through ds_read_b64_tr_b16, no V^T buffer and a plain
+// qkv epilogue.  Bitwise identical outputs; the whole engine step measured 24.57 vs 24.44 ms (one-process A/B,
+// tools/ab_switch.py cpx_attention_set_trv): the 8 transposed reads per tile cost more than the epilogue saves.
+static int g_att_trv = 0;
+extern "C" void cpx_attention_set_trv(int v) { g_att_trv = v; }
 // diagnostic: per-wave cycle counts of the loop segments -> dbg [n_subtiles*16*8 blocks][4 waves][9]
 extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
@@ -415,18 +450,17 @@ static int attention_launch(const void *qkv, const void *rel_h, const void *rel_
                             void *vT_ws, void *out, void *stream, bool transpose_v) {
     CPX_REQUIRE(qkv && rel_h && rel_w && vT_ws && out && n_subtiles > 0);
     hipStream_t s = (hipStream_t)stream;
-    if (transpose_v)
+    if (transpose_v && !g_att_trv)
         hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
                            (const unsigned short *)qkv, (unsigned short *)vT_ws);
     dim3 grid(8, 16, n_subtiles);
-    if (cpx_get_half_dtype())
-        hipLaunchKernelGGL((k_attention<true, false>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
-                           (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr, g_att_xcd);
-    else
-        hipLaunchKernelGGL((k_attention<false, false>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv,
-                           (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
-                           (const unsigned short *)rel_w, (unsigned short *)out, (unsigned *)nullptr, g_att_xcd);
+#define ATT_LAUNCH(F16_, TRV_)                                                                              \
+    hipLaunchKernelGGL((k_attention<F16_, false, TRV_>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv, \
+                       (const unsigned short *)vT_ws, (const unsigned short *)rel_h, (const unsigned short *)rel_w, \
+                       (unsigned short *)out, (unsigned *)nullptr, g_att_xcd)
+    if (cpx_get_half_dtype()) { if (g_att_trv) ATT_LAUNCH(true, true); else ATT_LAUNCH(true, false); }
+    else { if (g_att_trv) ATT_LAUNCH(false, true); else ATT_LAUNCH(false, false); }
+#undef ATT_LAUNCH
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -545,7 +579,7 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
         const cpx_block_weights &b = w->blocks[i];
         const bool prof = g_prof_ev && g_prof_n < g_prof_cap && (i % g_prof_stride) == 0;
         if (fuse) {
-            RUN(cpx_gemm_ln(x, b.qkv_w, M, 3072, 1024, CPX_EPI_QKV_BF16, b.qkv_b, vt, qkv, 3072, st, b.qkv_colsum, nullptr, stream));
+            RUN(cpx_gemm_ln(x, b.qkv_w, M, 3072, 1024, g_att_trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16, b.qkv_b, g_att_trv ? nullptr : vt, qkv, 3072, st, b.qkv_colsum, nullptr, stream));
             RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
             RUN(cpx_gemm_ln(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
             if (!big_stats) RUN(cpx_row_stats(x, M, st, stream));
@@ -557,7 +591,7 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
             continue;
         }
         RUN(cpx_layernorm_bf16(x, b.ln1_w, b.ln1_b, M, 1024, 1e-6f, xn, stream));
-        RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, CPX_EPI_QKV_BF16, b.qkv_b, vt, qkv, 3072, stream));
+        RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, g_att_trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16, b.qkv_b, g_att_trv ? nullptr : vt, qkv, 3072, stream));
         RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
         RUN(cpx_gemm_bf16(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, stream));
         RUN(cpx_layernorm_bf16(x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
