@@ -151,8 +151,10 @@ def main():
     # every launch of the dominant GEMM is timed (BENCH_PROF_STRIDE=8 samples every 8th layer: +0.9 % tiles/s,
     # but the sampled launches then read ~10 % longer than rocprofv3's serialised average -- the event pairs'
     # idle gaps let the chip hold a higher clock; measured A/B on one box)
-    L.cpx_prof_set_stride(int(os.environ.get("BENCH_PROF_STRIDE", "1")))
-    _lib.check(L.cpx_prof_enable(args.steps * args.depth + 8), "prof_enable")
+    prof = C.c_void_p()
+    _lib.check(L.cpx_prof_create(args.steps * args.depth + 8, int(os.environ.get("BENCH_PROF_STRIDE", "1")), 1,
+                                 C.byref(prof)), "prof_create")
+    w.c.prof = prof
     parallel.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -165,9 +167,11 @@ def main():
     dt = time.perf_counter() - t0
     dt = parallel.allreduce_max(dt, dev)
     cells = parallel.allreduce_sum(float(cells_acc.item()), dev)
-    ms_sum, cnt = C.c_double(0), C.c_int(0)
-    _lib.check(L.cpx_prof_collect(C.byref(ms_sum), C.byref(cnt)), "prof_collect")
-    L.cpx_prof_enable(0)
+    ms_k, cnt_k = (C.c_double * 5)(), (C.c_int * 5)()
+    _lib.check(L.cpx_prof_collect(prof, ms_k, cnt_k), "prof_collect")
+    w.c.prof = None
+    L.cpx_prof_destroy(prof)
+    ms_sum, cnt = C.c_double(ms_k[0]), C.c_int(cnt_k[0])
 
     n_tiles = args.steps * bt * world
     M = bt * eng.n_sub * 1024

@@ -13,7 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclasspose_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+DT_BF16, DT_F16, DT_F32 = 0, 1, 2
+DTYPE_CODE = {"bf16": DT_BF16, "fp16": DT_F16, "fp32": DT_F32}
+PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2")
 
 
 class CpxTiling(C.Structure):
@@ -53,7 +56,7 @@ class CpxNetWeights(C.Structure):
                 ("neck0_w", C.c_void_p), ("neck_ln1_w", C.c_void_p), ("neck_ln1_b", C.c_void_p),
                 ("neck2_w", C.c_void_p), ("neck_ln2_w", C.c_void_p), ("neck_ln2_b", C.c_void_p),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p),
-                ("n_unet_ops", C.c_int), ("unet_ops", C.POINTER(CpxConvOp))]
+                ("n_unet_ops", C.c_int), ("unet_ops", C.POINTER(CpxConvOp)), ("prof", C.c_void_p)]
 
 
 class CpxRecord(C.Structure):
@@ -77,14 +80,22 @@ SIGNATURES = {
     "cpx_normalize_apply_u8": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "cpx_resize_linear_u8": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "cpx_make_subtiles": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
+    "cpx_make_patches": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _i, _p, _p]),
     "cpx_make_subtiles_f32": (_i, [_p, _p, _i, C.POINTER(CpxTiling), _p, _p]),
     "cpx_blend_subtiles": (_i, [_p, _i, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
     "cpx_blend_subtiles_nchw": (_i, [_p, _p, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
     "cpx_qc_forward": (_i, [C.POINTER(CpxQcOp), _i, _p, _i, _i, _i, _sz, _sz, _i, _i, _p, _p, _p, _sz, _p]),
-    "cpx_net_workspace_bytes": (_sz, [_i]),
+    "cpx_net_workspace_bytes": (_sz, [_i, _i]),
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
-    "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i]),
-    "cpx_unet_head_forward": (_i, [C.POINTER(CpxConvOp), _i, _p, _i, _p, _i, _i, _p, _sz, _p]),
+    "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i, _i]),
+    "cpx_unet_head_forward": (_i, [C.POINTER(CpxConvOp), _i, _p, _i, _p, _i, _i, _i, _p, _sz, _p]),
+    "cpx_prof_create": (_i, [_i, _i, C.c_uint, C.POINTER(C.c_void_p)]),
+    "cpx_prof_collect": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "cpx_prof_destroy": (None, [_p]),
+    "cpx_gemm": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "cpx_gemm_uses_big_tile": (_i, [_i, _i, _i, _i]),
+    "cpx_layernorm": (_i, [_i, _p, _p, _p, _i, _i, _f, _p, _p]),
+    "cpx_attention": (_i, [_i, _p, _p, _p, _i, _p, _p, _p]),
     "cpx_gemm_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
     "cpx_gemm_ln": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_row_stats": (_i, [_p, _i, _p, _p]),
@@ -105,10 +116,9 @@ SIGNATURES = {
     "cpx_polygonize_device": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_polygonize_host": (_i, [_p, _i, _i, _p, _i, _d, _d, _d, _p, _i, _p]),
 }
-# not part of the public header (debug / A-B switches)
+# include/classpose_hip_debug.h: process-global A/B and ablation switches (tools/, a few tests)
 _PRIVATE = {
     "cpx_gemm_set_variant": (None, [_i]),
-    "cpx_prof_set_stride": (None, [_i]),
     "cpx_attention_set_trv": (None, [_i]),
     "cpx_follow_set_early_exit": (None, [_i]),
     "cpx_gemm_set_reverse": (None, [_i]),
@@ -117,9 +127,6 @@ _PRIVATE = {
     "cpx_attention_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),
-    "cpx_set_half_dtype": (None, [_i]),
-    "cpx_prof_enable": (_i, [_i]),
-    "cpx_prof_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None

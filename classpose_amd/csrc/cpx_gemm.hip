@@ -17,7 +17,7 @@
 // free fragment reads.  Workgroup ids are remapped so that the
 // blocks that share an XCD (id % 8) walk a contiguous band of M rows and re-use
 // the activation panel from that XCD's L2.
-#include "cpx_common.h"
+#include "cpx_internal.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -629,10 +629,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
 }
 
 static int g_gemm_variant = 1;     // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
-static int g_gemm_f16 = 0;
 extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
-extern "C" void cpx_set_half_dtype(int f16) { g_gemm_f16 = f16; }
-extern "C" int cpx_get_half_dtype(void) { return g_gemm_f16; }
 
 static int g_gemm_dbg = 0;
 extern "C" void cpx_gemm_set_dbg(int v) { g_gemm_dbg = v; }
@@ -648,11 +645,8 @@ extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 
 template <int EPI, bool F16, int FLAGS>
 static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
-        attr_done = true;
-    }
+    static CpxOncePerDevice once;
+    once([] { (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES); });
     hipLaunchKernelGGL((k_gemm256<EPI, F16, FLAGS>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
 }
 
@@ -681,11 +675,11 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
 }
 
 template <int EPI>
-static void launch_gemm(const GemmArgs &a, hipStream_t s) {
-    if (g_gemm_f16 ? launch_gemm256<EPI, true>(a, s) : launch_gemm256<EPI, false>(a, s)) return;
+static void launch_gemm(const GemmArgs &a, hipStream_t s, bool f16) {
+    if (f16 ? launch_gemm256<EPI, true>(a, s) : launch_gemm256<EPI, false>(a, s)) return;
     dim3 grid(a.n_blocks), block(GEMM_THREADS);
     size_t lds = 2 * STAGE_BYTES;
-    if (g_gemm_f16) {
+    if (f16) {
         if (g_gemm_variant) hipLaunchKernelGGL((k_gemm<EPI, true, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_gemm<EPI, true, false>), grid, block, lds, s, a);
     } else {
@@ -714,31 +708,36 @@ __global__ void __launch_bounds__(256) k_row_stats(const unsigned short *__restr
     for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
     if (lane < 4) *reinterpret_cast<float2 *>(st + ((size_t)row * LN_SLOTS + lane) * 2) = lane == 0 ? make_float2(sm, sq) : make_float2(0.f, 0.f);
 }
-extern "C" int cpx_row_stats(const void *x, int rows, float *stats, void *stream) {
-    CPX_REQUIRE(x && stats && rows > 0);
-    if (g_gemm_f16) hipLaunchKernelGGL(k_row_stats<true>, dim3(cpx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, rows, stats);
+int cpx_row_stats_half(int dtype, const void *x, int rows, float *stats, void *stream) {
+    CPX_REQUIRE(x && stats && rows > 0 && (dtype == CPX_DT_BF16 || dtype == CPX_DT_F16));
+    if (dtype == CPX_DT_F16) hipLaunchKernelGGL(k_row_stats<true>, dim3(cpx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, rows, stats);
     else hipLaunchKernelGGL(k_row_stats<false>, dim3(cpx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, rows, stats);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
 
+extern "C" int cpx_row_stats(const void *x, int rows, float *stats, void *stream) {
+    return cpx_row_stats_half(CPX_DT_BF16, x, rows, stats, stream);
+}
+
 // does this shape take the 256^2 kernel (whose RESID epilogue can emit LN statistics)?
-extern "C" int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue) {
+int cpx_gemm_half_uses_big_tile(int M, int N, int K, int epilogue) {
     if (epilogue == CPX_EPI_F32 || epilogue == CPX_EPI_POS_BF16) return 0;
     if (!g_gemm_big || M % 256 || N % 256 || (K / 64) % 2 || K < 128) return 0;
     return (M / 256) * (N / 256) >= 256;
 }
 
-extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
-                           const float *bias, const void *aux, void *out, int ld_out,
-                           const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream) {
-    CPX_REQUIRE(A && Wt && out);
+int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                  const float *bias, const void *aux, void *out, int ld_out,
+                  const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream) {
+    CPX_REQUIRE(A && Wt && out && (dtype == CPX_DT_BF16 || dtype == CPX_DT_F16));
+    const bool f16 = dtype == CPX_DT_F16;
     CPX_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0);
     CPX_REQUIRE(ld_out >= N && ld_out % 4 == 0);
     CPX_REQUIRE((epilogue != CPX_EPI_RESID_BF16 && epilogue != CPX_EPI_POS_BF16 && epilogue != CPX_EPI_QKV_BF16) || aux);
     CPX_REQUIRE(epilogue != CPX_EPI_QKV_BF16 || (N == 3072 && M % 1024 == 0));
     CPX_REQUIRE(!ln_stats || (ln_colsum && epilogue != CPX_EPI_RESID_BF16));
-    CPX_REQUIRE(!stats_out || (epilogue == CPX_EPI_RESID_BF16 && N == 1024 && cpx_gemm_uses_big_tile(M, N, K, epilogue)));
+    CPX_REQUIRE(!stats_out || (epilogue == CPX_EPI_RESID_BF16 && N == 1024 && cpx_gemm_half_uses_big_tile(M, N, K, epilogue)));
     GemmArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;
@@ -747,20 +746,32 @@ extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, i
     a.rev_m = (g_gemm_rev && K >= 4096) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s); break;
-        case CPX_EPI_GELU_BF16: launch_gemm<CPX_EPI_GELU_BF16>(a, s); break;
-        case CPX_EPI_RESID_BF16: launch_gemm<CPX_EPI_RESID_BF16>(a, s); break;
-        case CPX_EPI_F32: launch_gemm<CPX_EPI_F32>(a, s); break;
-        case CPX_EPI_POS_BF16: launch_gemm<CPX_EPI_POS_BF16>(a, s); break;
-        case CPX_EPI_RELU_BF16: launch_gemm<CPX_EPI_RELU_BF16>(a, s); break;
-        case CPX_EPI_QKV_BF16: launch_gemm<CPX_EPI_QKV_BF16>(a, s); break;
+        case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s, f16); break;
+        case CPX_EPI_GELU_BF16: launch_gemm<CPX_EPI_GELU_BF16>(a, s, f16); break;
+        case CPX_EPI_RESID_BF16: launch_gemm<CPX_EPI_RESID_BF16>(a, s, f16); break;
+        case CPX_EPI_F32: launch_gemm<CPX_EPI_F32>(a, s, f16); break;
+        case CPX_EPI_POS_BF16: launch_gemm<CPX_EPI_POS_BF16>(a, s, f16); break;
+        case CPX_EPI_RELU_BF16: launch_gemm<CPX_EPI_RELU_BF16>(a, s, f16); break;
+        case CPX_EPI_QKV_BF16: launch_gemm<CPX_EPI_QKV_BF16>(a, s, f16); break;
         default: CPX_REQUIRE(!"unknown epilogue");
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
 
+extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                           const float *bias, const void *aux, void *out, int ld_out,
+                           const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream) {
+    return cpx_gemm_half(CPX_DT_BF16, A, Wt, M, N, K, epilogue, bias, aux, out, ld_out, ln_stats, ln_colsum, stats_out, stream);
+}
 extern "C" int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
                              const float *bias, const void *aux, void *out, int ld_out, void *stream) {
-    return cpx_gemm_ln(A, Wt, M, N, K, epilogue, bias, aux, out, ld_out, nullptr, nullptr, nullptr, stream);
+    return cpx_gemm_half(CPX_DT_BF16, A, Wt, M, N, K, epilogue, bias, aux, out, ld_out, nullptr, nullptr, nullptr, stream);
 }
+extern "C" int cpx_gemm(int dtype, const void *A, const void *Wt, int M, int N, int K, int epilogue,
+                        const float *bias, const void *aux, void *out, int ld_out, void *stream) {
+    if (dtype == CPX_DT_F32)
+        return cpx_gemm_f32((const float *)A, (const float *)Wt, M, N, K, epilogue, bias, (const float *)aux, (float *)out, ld_out, stream);
+    return cpx_gemm_half(dtype, A, Wt, M, N, K, epilogue, bias, aux, out, ld_out, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue) { return cpx_gemm_half_uses_big_tile(M, N, K, epilogue); }

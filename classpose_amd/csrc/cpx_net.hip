@@ -17,14 +17,12 @@
 //     from the accumulator registers: the key rows of the K operand are loaded
 //     in the permuted order pi(r) = swap bits 2,3 so that the accumulator's
 //     register order is the natural key order of the V^T operand.
-#include "cpx_common.h"
+#include "cpx_internal.h"
 #include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-extern "C" int cpx_get_half_dtype(void);
 
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma32(const uint4 &a, const uint4 &b, f32x16 c) {
@@ -113,12 +111,13 @@ __global__ void __launch_bounds__(256) k_layernorm(const unsigned short *__restr
     }
 }
 
-extern "C" int cpx_layernorm_bf16(const void *x, const float *w, const float *b, int rows, int C,
-                                  float eps, void *out, void *stream) {
+int cpx_layernorm_half(int dtype, const void *x, const float *w, const float *b, int rows, int C,
+                       float eps, void *out, void *stream) {
     CPX_REQUIRE(x && w && b && out && rows > 0 && (C == 1024 || C == 256));
+    CPX_REQUIRE(dtype == CPX_DT_BF16 || dtype == CPX_DT_F16);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cpx_cdiv(rows, 4)), block(256);
-    const bool f16 = cpx_get_half_dtype();
+    const bool f16 = dtype == CPX_DT_F16;
     if (C == 1024) {
         if (f16) hipLaunchKernelGGL((k_layernorm<1024, true>), grid, block, 0, s, (const unsigned short *)x, w, b, rows, eps, (unsigned short *)out);
         else hipLaunchKernelGGL((k_layernorm<1024, false>), grid, block, 0, s, (const unsigned short *)x, w, b, rows, eps, (unsigned short *)out);
@@ -128,6 +127,15 @@ extern "C" int cpx_layernorm_bf16(const void *x, const float *w, const float *b,
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;
+}
+extern "C" int cpx_layernorm(int dtype, const void *x, const float *w, const float *b, int rows, int C,
+                             float eps, void *out, void *stream) {
+    if (dtype == CPX_DT_F32) return cpx_layernorm_f32((const float *)x, w, b, rows, C, eps, (float *)out, stream);
+    return cpx_layernorm_half(dtype, x, w, b, rows, C, eps, out, stream);
+}
+extern "C" int cpx_layernorm_bf16(const void *x, const float *w, const float *b, int rows, int C,
+                                  float eps, void *out, void *stream) {
+    return cpx_layernorm_half(CPX_DT_BF16, x, w, b, rows, C, eps, out, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -420,8 +428,6 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
         }
 }
 
-static int attention_launch(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
-                            void *vT_ws, void *out, void *stream, bool transpose_v);
 static int g_att_xcd = 1;          // XCD-aware workgroup order (debug / A-B switch)
 extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 // experiment switch (default off): V read from the qkv rows through ds_read_b64_tr_b16, no V^T buffer and a plain
@@ -429,6 +435,7 @@ extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 // tools/ab_switch.py cpx_attention_set_trv): the 8 transposed reads per tile cost more than the epilogue saves.
 static int g_att_trv = 0;
 extern "C" void cpx_attention_set_trv(int v) { g_att_trv = v; }
+int cpx_attention_trv_enabled(void) { return g_att_trv; }
 // diagnostic: per-wave cycle counts of the loop segments -> dbg [n_subtiles*16*8 blocks][4 waves][9]
 extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
@@ -443,12 +450,19 @@ extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const voi
 }
 extern "C" int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w,
                                     int n_subtiles, void *vT_ws, void *out, void *stream) {
-    return attention_launch(qkv, rel_h, rel_w, n_subtiles, vT_ws, out, stream, true);
+    return cpx_attention_half(CPX_DT_BF16, qkv, rel_h, rel_w, n_subtiles, vT_ws, out, stream, true);
+}
+extern "C" int cpx_attention(int dtype, const void *qkv, const void *rel_h, const void *rel_w,
+                             int n_subtiles, void *vT_ws, void *out, void *stream) {
+    if (dtype == CPX_DT_F32)
+        return cpx_attention_f32((const float *)qkv, (const float *)rel_h, (const float *)rel_w, n_subtiles, (float *)out, stream);
+    return cpx_attention_half(dtype, qkv, rel_h, rel_w, n_subtiles, vT_ws, out, stream, true);
 }
 // transpose_v = false: vT_ws already holds V^T (written by the qkv GEMM's CPX_EPI_QKV_BF16 epilogue)
-static int attention_launch(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
-                            void *vT_ws, void *out, void *stream, bool transpose_v) {
+int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                       void *vT_ws, void *out, void *stream, bool transpose_v) {
     CPX_REQUIRE(qkv && rel_h && rel_w && vT_ws && out && n_subtiles > 0);
+    CPX_REQUIRE(dtype == CPX_DT_BF16 || dtype == CPX_DT_F16);
     hipStream_t s = (hipStream_t)stream;
     if (transpose_v && !g_att_trv)
         hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
@@ -458,7 +472,7 @@ static int attention_launch(const void *qkv, const void *rel_h, const void *rel_
     hipLaunchKernelGGL((k_attention<F16_, false, TRV_>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv, \
                        (const unsigned short *)vT_ws, (const unsigned short *)rel_h, (const unsigned short *)rel_w, \
                        (unsigned short *)out, (unsigned *)nullptr, g_att_xcd)
-    if (cpx_get_half_dtype()) { if (g_att_trv) ATT_LAUNCH(true, true); else ATT_LAUNCH(true, false); }
+    if (dtype == CPX_DT_F16) { if (g_att_trv) ATT_LAUNCH(true, true); else ATT_LAUNCH(true, false); }
     else { if (g_att_trv) ATT_LAUNCH(false, true); else ATT_LAUNCH(false, false); }
 #undef ATT_LAUNCH
     CPX_CHECK_LAUNCH();
@@ -490,7 +504,6 @@ __global__ void __launch_bounds__(256) k_im2col3(const unsigned short *__restric
 struct NetWs {
     size_t off_x, off_xn, off_qkv, off_vt, off_ao, off_h, off_neck, off_neck2, off_col, off_st, total;
 };
-extern "C" int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue);
 static NetWs net_ws(int nS) {
     NetWs w; size_t o = 0; const size_t M = (size_t)nS * 1024;
     auto take = [&](size_t b) { size_t r = o; o = cpx_align_up(o + b, 256); return r; };
@@ -507,139 +520,153 @@ static NetWs net_ws(int nS) {
     w.total = o;
     return w;
 }
-extern "C" size_t cpx_net_workspace_bytes(int n_subtiles) {
-    return n_subtiles > 0 ? net_ws(n_subtiles).total : 0;
+extern "C" size_t cpx_net_workspace_bytes(int n_subtiles, int dtype) {
+    if (n_subtiles <= 0) return 0;
+    return dtype == CPX_DT_F32 ? cpx_net_f32_workspace_bytes(n_subtiles) : net_ws(n_subtiles).total;
 }
-extern "C" size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops, int n_ops, int nS);
-extern "C" int cpx_unet_head_forward(const cpx_conv_op *ops, int n_ops, const void *feat, int nS, float *head,
-                                     int ld_head, int col0, void *workspace, size_t ws_bytes, void *stream);
-
-extern "C" void cpx_set_half_dtype(int f16);
-extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
-                           const float *bias, const void *aux, void *out, int ld_out,
-                           const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream);
-extern "C" int cpx_row_stats(const void *x, int rows, float *stats, void *stream);
 
 // ---------------------------------------------------------------------------
-// optional per-launch timing of the dominant kernel (the fc1 GEMM, k_gemm<GELU>):
-// HIP events recorded on the launch stream around every fc1 launch of a forward.
-// Events are created by cpx_prof_enable (never inside the launch path).
+// optional per-launch timing (bench.py's roofline lines): HIP events recorded on the launch
+// stream around the selected kernels of a forward.  The handle is created by the caller (never
+// inside the launch path), carried in cpx_net_weights.prof and owned by ONE engine / host thread.
 // ---------------------------------------------------------------------------
-static hipEvent_t *g_prof_ev = nullptr;
-static int g_prof_cap = 0, g_prof_n = 0, g_prof_stride = 1;
-// sample every stride-th layer only: each event pair costs ~5 us of idle GPU around the timed kernel
-extern "C" void cpx_prof_set_stride(int stride) { g_prof_stride = stride > 0 ? stride : 1; }
-extern "C" int cpx_prof_enable(int max_launches) {
-    for (int i = 0; i < 2 * g_prof_cap; ++i) (void)hipEventDestroy(g_prof_ev[i]);
-    delete[] g_prof_ev; g_prof_ev = nullptr; g_prof_cap = 0; g_prof_n = 0;
-    if (max_launches <= 0) return CPX_OK;
-    g_prof_ev = new hipEvent_t[2 * (size_t)max_launches];
-    for (int i = 0; i < 2 * max_launches; ++i) CPX_HIP(hipEventCreate(&g_prof_ev[i]));
-    g_prof_cap = max_launches;
-    return CPX_OK;
-}
-// sum of elapsed ms and number of timed launches since enable; call after a stream sync
-extern "C" int cpx_prof_collect(double *ms_sum, int *count) {
-    double s = 0.0;
-    for (int i = 0; i < g_prof_n; ++i) {
-        float ms = 0.f;
-        CPX_HIP(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
-        s += ms;
+extern "C" int cpx_prof_create(int max_launches, int stride, unsigned kinds_mask, void **out) {
+    CPX_REQUIRE(out && max_launches > 0);
+    CpxProf *p = new CpxProf();
+    p->ev = new hipEvent_t[2 * (size_t)max_launches];
+    p->kind = new int[max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipError_t e = hipEventCreate(&p->ev[i]);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);
+            delete[] p->ev; delete[] p->kind; delete p;
+            CPX_HIP(e);
+        }
     }
-    if (ms_sum) *ms_sum = s;
-    if (count) *count = g_prof_n;
-    g_prof_n = 0;
+    p->cap = max_launches; p->n = 0; p->stride = stride > 0 ? stride : 1;
+    p->kinds_mask = kinds_mask ? kinds_mask : 1u;
+    *out = p;
     return CPX_OK;
+}
+// per kind: sum of elapsed ms and number of timed launches since the last collect; call after a stream sync.
+// ms_sum / count: arrays of CPX_PROF_KINDS (5) entries: fc1, attention, qkv, proj, fc2.
+extern "C" int cpx_prof_collect(void *prof, double *ms_sum, int *count) {
+    CpxProf *p = (CpxProf *)prof;
+    CPX_REQUIRE(p && ms_sum && count);
+    for (int k = 0; k < CPX_PROF_KINDS; ++k) { ms_sum[k] = 0.0; count[k] = 0; }
+    for (int i = 0; i < p->n; ++i) {
+        float ms = 0.f;
+        CPX_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        ms_sum[p->kind[i]] += ms;
+        ++count[p->kind[i]];
+    }
+    p->n = 0;
+    return CPX_OK;
+}
+extern "C" void cpx_prof_destroy(void *prof) {
+    CpxProf *p = (CpxProf *)prof;
+    if (!p) return;
+    for (int i = 0; i < 2 * p->cap; ++i) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev; delete[] p->kind; delete p;
 }
 
 extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, int nS, float *head,
                                void *workspace, size_t workspace_bytes, void *stream) {
     CPX_REQUIRE(w && patches && head && workspace && nS > 0);
     CPX_REQUIRE(w->depth > 0 && w->blocks && w->ld_head % 128 == 0 && w->ld_head >= w->n_head_cols);
+    CPX_REQUIRE(w->dtype == CPX_DT_BF16 || w->dtype == CPX_DT_F16 || w->dtype == CPX_DT_F32);
+    if (w->dtype == CPX_DT_F32) return cpx_net_forward_f32(w, patches, nS, head, workspace, workspace_bytes, stream);
     NetWs L = net_ws(nS);
     CPX_REQUIRE(workspace_bytes >= L.total);
-    cpx_set_half_dtype(w->dtype == 1);
+    const int dt = w->dtype;
     char *ws = (char *)workspace;
     const int M = nS * 1024;
     void *x = ws + L.off_x, *xn = ws + L.off_xn, *qkv = ws + L.off_qkv, *vt = ws + L.off_vt,
          *ao = ws + L.off_ao, *hb = ws + L.off_h, *nk = ws + L.off_neck, *nk2 = ws + L.off_neck2,
          *col = ws + L.off_col;
+    CpxProf *prof = (CpxProf *)w->prof;
+    hipStream_t hs = (hipStream_t)stream;
+    const int trv = cpx_attention_trv_enabled();
     int rc;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+#define GEMM(A_, W_, N_, K_, EPI_, B_, AUX_, OUT_, LD_) \
+    cpx_gemm_half(dt, A_, W_, M, N_, K_, EPI_, B_, AUX_, OUT_, LD_, nullptr, nullptr, nullptr, stream)
+#define TIMED(kind_, layer_, call_) do { const bool t_ = cpx_prof_begin(prof, kind_, layer_, hs); RUN(call_); if (t_) cpx_prof_end(prof, hs); } while (0)
     // patch embed (+bias +pos_embed)
-    RUN(cpx_gemm_bf16(patches, w->pe_w, M, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024, stream));
+    RUN(GEMM(patches, w->pe_w, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024));
     float *st = (float *)(ws + L.off_st);
     // LayerNorm fusion: the RESID GEMMs emit partial row statistics of the residual stream, the
     // next GEMM applies (x - mean) * rstd algebraically in its epilogue (weights pre-folded)
     const bool fuse = w->fuse_ln != 0;
-    const bool big_stats = fuse && cpx_gemm_uses_big_tile(M, 1024, 1024, CPX_EPI_RESID_BF16) &&
-                           cpx_gemm_uses_big_tile(M, 1024, 4096, CPX_EPI_RESID_BF16);
-    if (fuse) RUN(cpx_row_stats(x, M, st, stream));
+    const bool big_stats = fuse && cpx_gemm_half_uses_big_tile(M, 1024, 1024, CPX_EPI_RESID_BF16) &&
+                           cpx_gemm_half_uses_big_tile(M, 1024, 4096, CPX_EPI_RESID_BF16);
+    if (fuse) RUN(cpx_row_stats_half(dt, x, M, st, stream));
+    const int qkv_epi = trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16;
     for (int i = 0; i < w->depth; ++i) {
         const cpx_block_weights &b = w->blocks[i];
-        const bool prof = g_prof_ev && g_prof_n < g_prof_cap && (i % g_prof_stride) == 0;
         if (fuse) {
-            RUN(cpx_gemm_ln(x, b.qkv_w, M, 3072, 1024, g_att_trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16, b.qkv_b, g_att_trv ? nullptr : vt, qkv, 3072, st, b.qkv_colsum, nullptr, stream));
-            RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
-            RUN(cpx_gemm_ln(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
-            if (!big_stats) RUN(cpx_row_stats(x, M, st, stream));
-            if (prof) CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n], (hipStream_t)stream));
-            RUN(cpx_gemm_ln(x, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, st, b.fc1_colsum, nullptr, stream));
-            if (prof) { CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], (hipStream_t)stream)); ++g_prof_n; }
-            RUN(cpx_gemm_ln(hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
-            if (!big_stats) RUN(cpx_row_stats(x, M, st, stream));
+            TIMED(CPX_PROF_QKV, i, cpx_gemm_half(dt, x, b.qkv_w, M, 3072, 1024, qkv_epi, b.qkv_b, trv ? nullptr : vt, qkv, 3072, st, b.qkv_colsum, nullptr, stream));
+            TIMED(CPX_PROF_ATTN, i, cpx_attention_half(dt, qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
+            TIMED(CPX_PROF_PROJ, i, cpx_gemm_half(dt, ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
+            if (!big_stats) RUN(cpx_row_stats_half(dt, x, M, st, stream));
+            TIMED(CPX_PROF_FC1, i, cpx_gemm_half(dt, x, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, st, b.fc1_colsum, nullptr, stream));
+            TIMED(CPX_PROF_FC2, i, cpx_gemm_half(dt, hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
+            if (!big_stats) RUN(cpx_row_stats_half(dt, x, M, st, stream));
             continue;
         }
-        RUN(cpx_layernorm_bf16(x, b.ln1_w, b.ln1_b, M, 1024, 1e-6f, xn, stream));
-        RUN(cpx_gemm_bf16(xn, b.qkv_w, M, 3072, 1024, g_att_trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16, b.qkv_b, g_att_trv ? nullptr : vt, qkv, 3072, stream));
-        RUN(attention_launch(qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
-        RUN(cpx_gemm_bf16(ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, stream));
-        RUN(cpx_layernorm_bf16(x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
-        if (prof) CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n], (hipStream_t)stream));
-        RUN(cpx_gemm_bf16(xn, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, stream));
-        if (prof) { CPX_HIP(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], (hipStream_t)stream)); ++g_prof_n; }
-        RUN(cpx_gemm_bf16(hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, stream));
+        RUN(cpx_layernorm_half(dt, x, b.ln1_w, b.ln1_b, M, 1024, 1e-6f, xn, stream));
+        TIMED(CPX_PROF_QKV, i, GEMM(xn, b.qkv_w, 3072, 1024, qkv_epi, b.qkv_b, trv ? nullptr : vt, qkv, 3072));
+        TIMED(CPX_PROF_ATTN, i, cpx_attention_half(dt, qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
+        TIMED(CPX_PROF_PROJ, i, GEMM(ao, b.proj_w, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024));
+        RUN(cpx_layernorm_half(dt, x, b.ln2_w, b.ln2_b, M, 1024, 1e-6f, xn, stream));
+        TIMED(CPX_PROF_FC1, i, GEMM(xn, b.fc1_w, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096));
+        TIMED(CPX_PROF_FC2, i, GEMM(hb, b.fc2_w, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024));
     }
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d
-    RUN(cpx_gemm_bf16(x, w->neck0_w, M, 256, 1024, CPX_EPI_BF16, nullptr, nullptr, nk, 256, stream));
-    RUN(cpx_layernorm_bf16(nk, w->neck_ln1_w, w->neck_ln1_b, M, 256, 1e-6f, nk2, stream));
+    RUN(GEMM(x, w->neck0_w, 256, 1024, CPX_EPI_BF16, nullptr, nullptr, nk, 256));
+    RUN(cpx_layernorm_half(dt, nk, w->neck_ln1_w, w->neck_ln1_b, M, 256, 1e-6f, nk2, stream));
     {
         size_t n_chunks = (size_t)M * 288;
         hipLaunchKernelGGL(k_im2col3, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, (const unsigned short *)nk2, n_chunks, (unsigned short *)col);
+                           hs, (const unsigned short *)nk2, n_chunks, (unsigned short *)col);
         CPX_CHECK_LAUNCH();
     }
-    RUN(cpx_gemm_bf16(col, w->neck2_w, M, 256, 2304, CPX_EPI_BF16, nullptr, nullptr, nk, 256, stream));
-    RUN(cpx_layernorm_bf16(nk, w->neck_ln2_w, w->neck_ln2_b, M, 256, 1e-6f, nk2, stream));
+    RUN(GEMM(col, w->neck2_w, 256, 2304, CPX_EPI_BF16, nullptr, nullptr, nk, 256));
+    RUN(cpx_layernorm_half(dt, nk, w->neck_ln2_w, w->neck_ln2_b, M, 256, 1e-6f, nk2, stream));
     // heads: out (192) | out_class (ncls*64), f32 token-major
-    RUN(cpx_gemm_bf16(nk2, w->head_w, M, w->ld_head, 256, CPX_EPI_F32, w->head_b, nullptr, head, w->ld_head, stream));
+    RUN(GEMM(nk2, w->head_w, w->ld_head, 256, CPX_EPI_F32, w->head_b, nullptr, head, w->ld_head));
     if (w->n_unet_ops > 0) {        // UNet semantic head overwrites the class columns (head_w rows there are zero)
-        const size_t need = cpx_unet_workspace_bytes(w->unet_ops, w->n_unet_ops, nS);
+        const size_t need = cpx_unet_ws_bytes(dt, w->unet_ops, w->n_unet_ops, nS);
         CPX_REQUIRE(workspace_bytes >= L.total + need);
-        RUN(cpx_unet_head_forward(w->unet_ops, w->n_unet_ops, nk2, nS, head, w->ld_head, 192, ws + L.total, need, stream));
+        RUN(cpx_unet_head_run(dt, w->unet_ops, w->n_unet_ops, nk2, nS, head, w->ld_head, 192, ws + L.total, need, stream));
     }
+#undef TIMED
+#undef GEMM
 #undef RUN
     return CPX_OK;
 }
 
 // ---------------------------------------------------------------------------
 // UNet semantic head (unet.py:121-196) as a list of convolutions on token-major tensors
+// of element size ES (2: bf16 / fp16, 4: float32); one 16-byte chunk = 16 / ES channels
 // ---------------------------------------------------------------------------
 // gather for conv3x3 (pad 1) / conv2x2 stride 2 from up to two channel-concatenated sources
-__global__ void __launch_bounds__(256) k_conv_gather(const unsigned short *__restrict__ a, int lda, int ca,
-                                                     const unsigned short *__restrict__ b, int ldb, int cb,
+template <int ES>
+__global__ void __launch_bounds__(256) k_conv_gather(const char *__restrict__ a, int lda, int ca,
+                                                     const char *__restrict__ b, int ldb, int cb,
                                                      int kind, int h, int w, size_t rows_out, int kpad,
-                                                     unsigned short *__restrict__ out) {
-    const int ctot = ca + cb, c8n = ctot >> 3, taps = kind == 0 ? 9 : (kind == 1 ? 4 : 1);   // kind 3: plain repack
-    const int chunks_per_row = kpad >> 3;
+                                                     char *__restrict__ out) {
+    constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
+    const int ctot = ca + cb, ccn = ctot / EPC, taps = kind == 0 ? 9 : (kind == 1 ? 4 : 1);   // kind 3: plain repack
+    const int chunks_per_row = kpad / EPC;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows_out * chunks_per_row) return;
     size_t row = i / chunks_per_row;
     int ch = (int)(i - row * chunks_per_row);
     uint4 v = make_uint4(0, 0, 0, 0);
     const int ho = kind == 1 ? h >> 1 : h, wo = kind == 1 ? w >> 1 : w;
-    if (ch < taps * c8n) {
-        int tap = ch / c8n, c8 = ch - tap * c8n;
+    if (ch < taps * ccn) {
+        int tap = ch / ccn, cc = ch - tap * ccn;
         size_t s_ = row / (size_t)(ho * wo);
         int t = (int)(row - s_ * ho * wo), y = t / wo, x = t - y * wo;
         int yy, xx;
@@ -648,81 +675,101 @@ __global__ void __launch_bounds__(256) k_conv_gather(const unsigned short *__res
         else { yy = y; xx = x; }
         if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
             size_t src_row = s_ * h * w + (size_t)yy * w + xx;
-            int c = c8 * 8;
-            v = c < ca ? *reinterpret_cast<const uint4 *>(a + src_row * lda + c)
-                       : *reinterpret_cast<const uint4 *>(b + src_row * ldb + (c - ca));
+            int c = cc * EPC;
+            v = c < ca ? *reinterpret_cast<const uint4 *>(a + (src_row * lda + c) * ES)
+                       : *reinterpret_cast<const uint4 *>(b + (src_row * ldb + (c - ca)) * ES);
         }
     }
-    *reinterpret_cast<uint4 *>(out + row * kpad + (size_t)ch * 8) = v;
+    *reinterpret_cast<uint4 *>(out + (row * kpad + (size_t)ch * EPC) * ES) = v;
 }
 
-// depth-to-space for convT2x2 s2: in [rows][ld_in] cols (tap, co) -> half [4*rows][ld_out] or f32 head columns
-template <bool F16>
-__global__ void __launch_bounds__(256) k_depth2space(const unsigned short *__restrict__ in, int ld_in, int cout,
-                                                     int h, int w, size_t rows_in, unsigned short *__restrict__ out,
+// depth-to-space for convT2x2 s2: in [rows][ld_in] cols (tap, co) -> [4*rows][ld_out] or f32 head columns
+// DT: CPX_DT_BF16 / CPX_DT_F16 / CPX_DT_F32
+template <int DT>
+__global__ void __launch_bounds__(256) k_depth2space(const char *__restrict__ in, int ld_in, int cout,
+                                                     int h, int w, size_t rows_in, char *__restrict__ out,
                                                      int ld_out, float *__restrict__ out_f32, int ld_f32, int col0) {
-    const int c8n = cout >> 3;
+    constexpr int ES = DT == CPX_DT_F32 ? 4 : 2, EPC = 16 / ES;
+    const int ccn = cout / EPC;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows_in * 4 * c8n) return;
-    size_t row = i / (4 * c8n);
-    int rem = (int)(i - row * 4 * c8n), tap = rem / c8n, c8 = rem - tap * c8n;
+    if (i >= rows_in * 4 * ccn) return;
+    size_t row = i / (4 * ccn);
+    int rem = (int)(i - row * 4 * ccn), tap = rem / ccn, cc = rem - tap * ccn;
     size_t s_ = row / (size_t)(h * w);
     int t = (int)(row - s_ * h * w), y = t / w, x = t - y * w;
     size_t orow = s_ * 4 * h * w + (size_t)(2 * y + (tap >> 1)) * (2 * w) + 2 * x + (tap & 1);
-    uint4 v = *reinterpret_cast<const uint4 *>(in + row * ld_in + tap * cout + c8 * 8);
+    uint4 v = *reinterpret_cast<const uint4 *>(in + (row * ld_in + tap * cout + cc * EPC) * ES);
     if (out_f32) {
-        const unsigned u[4] = {v.x, v.y, v.z, v.w};
-        float *o = out_f32 + orow * ld_f32 + col0 + c8 * 8;
+        float *o = out_f32 + orow * ld_f32 + col0 + cc * EPC;
+        if constexpr (DT == CPX_DT_F32) {
+            *reinterpret_cast<uint4 *>(o) = v;
+        } else {
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { o[2 * k] = f32_from_h<F16>(u[k] & 0xFFFF); o[2 * k + 1] = f32_from_h<F16>(u[k] >> 16); }
+            for (int k = 0; k < 4; ++k) { o[2 * k] = f32_from_h<DT == CPX_DT_F16>(u[k] & 0xFFFF); o[2 * k + 1] = f32_from_h<DT == CPX_DT_F16>(u[k] >> 16); }
+        }
     } else {
-        *reinterpret_cast<uint4 *>(out + orow * ld_out + c8 * 8) = v;
+        *reinterpret_cast<uint4 *>(out + (orow * ld_out + cc * EPC) * ES) = v;
     }
 }
 
 static inline int up128(long long x) { return (int)((x + 127) / 128 * 128); }
 static inline int up64(int x) { return (x + 63) / 64 * 64; }
 
-// workspace: tensors [rows_pad][ld] half, one per op, + the largest im2col / GEMM staging buffers
-extern "C" size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops, int n_ops, int nS) {
+// workspace: tensors [rows_pad][ld], one per op, + the largest im2col / GEMM staging buffers
+size_t cpx_unet_ws_bytes(int dtype, const cpx_conv_op *ops, int n_ops, int nS) {
+    const size_t es = dtype == CPX_DT_F32 ? 4 : 2;
     size_t tot = 0, col_max = 0, g_max = 0;
     for (int i = 0; i < n_ops; ++i) {
         const cpx_conv_op &o = ops[i];
         const int ho = o.kind == 0 ? o.h : (o.kind == 1 ? o.h / 2 : o.h * 2), wo = o.kind == 0 ? o.w : (o.kind == 1 ? o.w / 2 : o.w * 2);
         const size_t rows_out = (size_t)nS * ho * wo;
-        tot += cpx_align_up((size_t)up128(rows_out) * up128(o.cout) * 2, 256);
-        if (o.kind != 2) col_max = std::max(col_max, (size_t)up128(rows_out) * up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)) * 2);
+        tot += cpx_align_up((size_t)up128(rows_out) * up128(o.cout) * es, 256);
+        if (o.kind != 2) col_max = std::max(col_max, (size_t)up128(rows_out) * up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)) * es);
         else {
-            g_max = std::max(g_max, (size_t)up128((size_t)nS * o.h * o.w) * up128(4 * o.cout) * 2);
-            col_max = std::max(col_max, (size_t)up128((size_t)nS * o.h * o.w) * up64(o.cin_a) * 2);
+            g_max = std::max(g_max, (size_t)up128((size_t)nS * o.h * o.w) * up128(4 * o.cout) * es);
+            col_max = std::max(col_max, (size_t)up128((size_t)nS * o.h * o.w) * up64(o.cin_a) * es);
         }
     }
     return tot + cpx_align_up(col_max, 256) + cpx_align_up(g_max, 256) + 1024;
 }
+extern "C" size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops, int n_ops, int nS, int dtype) {
+    return cpx_unet_ws_bytes(dtype, ops, n_ops, nS);
+}
 
-// feat: neck output [nS*1024][256] half (tensor id 0).  The LAST op must be a convT producing
+// feat: neck output [nS*1024][256] (tensor id 0).  The LAST op must be a convT producing
 // ncls*64 channels at 32x32: it is written as float32 into head[:, col0 : col0 + cout].
-extern "C" int cpx_unet_head_forward(const cpx_conv_op *ops, int n_ops, const void *feat, int nS, float *head,
-                                     int ld_head, int col0, void *workspace, size_t ws_bytes, void *stream) {
+int cpx_unet_head_run(int dtype, const cpx_conv_op *ops, int n_ops, const void *feat, int nS, float *head,
+                      int ld_head, int col0, void *workspace, size_t ws_bytes, void *stream) {
     CPX_REQUIRE(ops && n_ops > 0 && n_ops <= 64 && feat && head && workspace && nS > 0);
-    CPX_REQUIRE(ws_bytes >= cpx_unet_workspace_bytes(ops, n_ops, nS));
+    CPX_REQUIRE(ws_bytes >= cpx_unet_ws_bytes(dtype, ops, n_ops, nS));
     hipStream_t s = (hipStream_t)stream;
-    const bool f16 = cpx_get_half_dtype();
-    struct T { const unsigned short *p; int ld, c, h, w; } tens[66];
-    tens[0] = {(const unsigned short *)feat, 256, 256, 32, 32};
+    const size_t es = dtype == CPX_DT_F32 ? 4 : 2;
+    struct T { const char *p; int ld, c, h, w; } tens[66];
+    tens[0] = {(const char *)feat, 256, 256, 32, 32};
     char *ws = (char *)workspace;
     size_t off = 0, col_max = 0, g_max = 0;
     for (int i = 0; i < n_ops; ++i) {     // sizes of the shared staging buffers first
         const cpx_conv_op &o = ops[i];
         const int ho = o.kind == 0 ? o.h : (o.kind == 1 ? o.h / 2 : o.h * 2), wo = o.kind == 0 ? o.w : (o.kind == 1 ? o.w / 2 : o.w * 2);
-        if (o.kind != 2) col_max = std::max(col_max, (size_t)up128((size_t)nS * ho * wo) * up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)) * 2);
+        if (o.kind != 2) col_max = std::max(col_max, (size_t)up128((size_t)nS * ho * wo) * up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)) * es);
         else {
-            g_max = std::max(g_max, (size_t)up128((size_t)nS * o.h * o.w) * up128(4 * o.cout) * 2);
-            col_max = std::max(col_max, (size_t)up128((size_t)nS * o.h * o.w) * up64(o.cin_a) * 2);
+            g_max = std::max(g_max, (size_t)up128((size_t)nS * o.h * o.w) * up128(4 * o.cout) * es);
+            col_max = std::max(col_max, (size_t)up128((size_t)nS * o.h * o.w) * up64(o.cin_a) * es);
         }
     }
-    unsigned short *colbuf = (unsigned short *)ws; off = cpx_align_up(col_max, 256);
-    unsigned short *gbuf = (unsigned short *)(ws + off); off += cpx_align_up(g_max, 256);
+    char *colbuf = ws; off = cpx_align_up(col_max, 256);
+    char *gbuf = ws + off; off += cpx_align_up(g_max, 256);
+    auto gather = [&](const T &A, int ca, const T &B, int cb, int kind, int h, int w, size_t rows, int Kp) {
+        const size_t n_chunks = rows * (Kp / (16 / es));
+        const dim3 grid((unsigned)((n_chunks + 255) / 256));
+        if (es == 4) hipLaunchKernelGGL(k_conv_gather<4>, grid, dim3(256), 0, s, A.p, A.ld, ca, B.p, B.ld, cb, kind, h, w, rows, Kp, colbuf);
+        else hipLaunchKernelGGL(k_conv_gather<2>, grid, dim3(256), 0, s, A.p, A.ld, ca, B.p, B.ld, cb, kind, h, w, rows, Kp, colbuf);
+    };
+    auto gemm = [&](const void *A, const void *W, int M, int N, int K, int epi, const float *bias, void *out) {
+        if (dtype == CPX_DT_F32) return cpx_gemm_f32((const float *)A, (const float *)W, M, N, K, epi, bias, nullptr, (float *)out, N, stream);
+        return cpx_gemm_half(dtype, A, W, M, N, K, epi, bias, nullptr, out, N, nullptr, nullptr, nullptr, stream);
+    };
     int rc;
     for (int i = 0; i < n_ops; ++i) {
         const cpx_conv_op &o = ops[i];
@@ -736,33 +783,35 @@ extern "C" int cpx_unet_head_forward(const cpx_conv_op *ops, int n_ops, const vo
             const int ho = o.kind == 0 ? o.h : o.h / 2, wo = o.kind == 0 ? o.w : o.w / 2;
             const size_t rows = (size_t)nS * ho * wo;
             const int Mp = up128(rows), Kp = up64((o.kind == 0 ? 9 : 4) * (o.cin_a + o.cin_b)), Np = up128(o.cout);
-            const size_t n_chunks = rows * (Kp / 8);
-            hipLaunchKernelGGL(k_conv_gather, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, A.p, A.ld, o.cin_a,
-                               B.p, B.ld, o.cin_b, o.kind, o.h, o.w, rows, Kp, colbuf);
-            unsigned short *dst = (unsigned short *)(ws + off);
-            off += cpx_align_up((size_t)Mp * Np * 2, 256);
-            rc = cpx_gemm_bf16(colbuf, o.weight, Mp, Np, Kp, o.relu ? CPX_EPI_RELU_BF16 : CPX_EPI_BF16, o.bias, nullptr, dst, Np, stream);
+            gather(A, o.cin_a, B, o.cin_b, o.kind, o.h, o.w, rows, Kp);
+            char *dst = ws + off;
+            off += cpx_align_up((size_t)Mp * Np * es, 256);
+            rc = gemm(colbuf, o.weight, Mp, Np, Kp, o.relu ? CPX_EPI_RELU_BF16 : CPX_EPI_BF16, o.bias, dst);
             if (rc) return rc;
             tens[o.dst] = {dst, Np, o.cout, ho, wo};
         } else {
             const size_t rows = (size_t)nS * o.h * o.w;
             const int Mp = up128(rows), Kp = up64(o.cin_a), Np = up128(4 * o.cout);
             CPX_REQUIRE(o.src_b < 0);
-            const size_t n_chunks = rows * (Kp / 8);
-            hipLaunchKernelGGL(k_conv_gather, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, A.p, A.ld, o.cin_a,
-                               (const unsigned short *)nullptr, 0, 0, 3, o.h, o.w, rows, Kp, colbuf);
-            rc = cpx_gemm_bf16(colbuf, o.weight, Mp, Np, Kp, CPX_EPI_BF16, o.bias, nullptr, gbuf, Np, stream);
+            gather(A, o.cin_a, Bz, 0, 3, o.h, o.w, rows, Kp);
+            rc = gemm(colbuf, o.weight, Mp, Np, Kp, CPX_EPI_BF16, o.bias, gbuf);
             if (rc) return rc;
             const bool last = i == n_ops - 1;
-            unsigned short *dst = (unsigned short *)(ws + off);
+            char *dst = ws + off;
             const int ldo = up128(o.cout);
-            if (!last) off += cpx_align_up((size_t)up128(rows * 4) * ldo * 2, 256);
-            const size_t n_thr = rows * 4 * (o.cout / 8);
-            if (f16) hipLaunchKernelGGL(k_depth2space<true>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, gbuf, Np, o.cout, o.h, o.w, rows, dst, ldo, last ? head : nullptr, ld_head, col0);
-            else hipLaunchKernelGGL(k_depth2space<false>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, gbuf, Np, o.cout, o.h, o.w, rows, dst, ldo, last ? head : nullptr, ld_head, col0);
+            if (!last) off += cpx_align_up((size_t)up128(rows * 4) * ldo * es, 256);
+            const size_t n_thr = rows * 4 * (o.cout / (16 / es));
+            const dim3 grid((unsigned)((n_thr + 255) / 256));
+#define D2S(DT_) hipLaunchKernelGGL(k_depth2space<DT_>, grid, dim3(256), 0, s, gbuf, Np, o.cout, o.h, o.w, rows, dst, ldo, last ? head : nullptr, ld_head, col0)
+            if (dtype == CPX_DT_F32) D2S(CPX_DT_F32); else if (dtype == CPX_DT_F16) D2S(CPX_DT_F16); else D2S(CPX_DT_BF16);
+#undef D2S
             tens[o.dst] = {dst, ldo, o.cout, o.h * 2, o.w * 2};
         }
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;
+}
+extern "C" int cpx_unet_head_forward(const cpx_conv_op *ops, int n_ops, const void *feat, int nS, float *head,
+                                     int ld_head, int col0, int dtype, void *workspace, size_t ws_bytes, void *stream) {
+    return cpx_unet_head_run(dtype, ops, n_ops, feat, nS, head, ld_head, col0, workspace, ws_bytes, stream);
 }

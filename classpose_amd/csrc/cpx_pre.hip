@@ -220,14 +220,14 @@ __device__ __forceinline__ float padded_px(const uint8_t *tiles, const float *st
 }
 
 // one thread = one (sub-tile, token, c, ii) = 8 consecutive k (jj = 0..7)
-extern "C" int cpx_get_half_dtype(void);
 __device__ __forceinline__ unsigned short f32_to_f16(float f) {
     _Float16 h = (_Float16)f;
     return *reinterpret_cast<unsigned short *>(&h);
 }
-template <bool F16>
+// DT: 0 bf16, 1 fp16, 2 float32 patch rows
+template <int DT>
 __global__ void k_make_patches(const uint8_t *__restrict__ tiles, const float *__restrict__ stats,
-                               TilingDev g, unsigned short *__restrict__ patches) {
+                               TilingDev g, void *__restrict__ patches_v) {
     const int tok_per = (g.b / 8) * (g.b / 8);
     const int per_sub = tok_per * 24;                         // 3 channels * 8 rows
     int i = blockIdx.x * NTHR + threadIdx.x;
@@ -244,14 +244,23 @@ __global__ void k_make_patches(const uint8_t *__restrict__ tiles, const float *_
     int y = 8 * ph + ii;
     int sy = fy ? g.b - 1 - y : y;
     union { unsigned short h[8]; uint4 v; } o;
+    float f[8];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         int x = 8 * pw + jj;
         int sx = fx ? g.b - 1 - x : x;
         float v = padded_px(tiles, stats, g, t, g.ys[j] + sy, g.xs[ii_t] + sx, c);
-        o.h[jj] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
+        f[jj] = v;
+        o.h[jj] = DT == 1 ? f32_to_f16(v) : f32_to_bf16(v);
     }
-    *reinterpret_cast<uint4 *>(patches + ((size_t)sub * tok_per + tok) * 192 + c * 64 + ii * 8) = o.v;
+    const size_t e = ((size_t)sub * tok_per + tok) * 192 + c * 64 + ii * 8;
+    if constexpr (DT == 2) {
+        float *patches = (float *)patches_v;
+        *reinterpret_cast<float4 *>(patches + e) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4 *>(patches + e + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+        *reinterpret_cast<uint4 *>((unsigned short *)patches_v + e) = o.v;
+    }
 }
 
 __global__ void k_make_subtiles_f32(const uint8_t *__restrict__ tiles, const float *__restrict__ stats,
@@ -271,19 +280,21 @@ __global__ void k_make_subtiles_f32(const uint8_t *__restrict__ tiles, const flo
     out[(size_t)sub * per + i] = padded_px(tiles, stats, g, t, g.ys[j] + sy, g.xs[ii_t] + sx, c);
 }
 
-extern "C" int cpx_make_subtiles(const uint8_t *tiles, const float *stats, int nT,
-                                 const cpx_tiling *tiling, void *patches, void *stream) {
+extern "C" int cpx_make_patches(const uint8_t *tiles, const float *stats, int nT,
+                                const cpx_tiling *tiling, int dtype, void *patches, void *stream) {
     TilingDev g; int rc = tiling_to_dev(tiling, &g); if (rc) return rc;
-    CPX_REQUIRE(tiles && stats && patches && nT > 0);
+    CPX_REQUIRE(tiles && stats && patches && nT > 0 && dtype >= 0 && dtype <= 2);
     int per_sub = (g.b / 8) * (g.b / 8) * 24;
-    if (cpx_get_half_dtype())
-        hipLaunchKernelGGL(k_make_patches<true>, dim3(cpx_cdiv(per_sub, NTHR), nT * g.ny * g.nx), dim3(NTHR), 0,
-                           (hipStream_t)stream, tiles, stats, g, (unsigned short *)patches);
-    else
-        hipLaunchKernelGGL(k_make_patches<false>, dim3(cpx_cdiv(per_sub, NTHR), nT * g.ny * g.nx), dim3(NTHR), 0,
-                           (hipStream_t)stream, tiles, stats, g, (unsigned short *)patches);
+    const dim3 grid(cpx_cdiv(per_sub, NTHR), nT * g.ny * g.nx);
+    if (dtype == 2) hipLaunchKernelGGL(k_make_patches<2>, grid, dim3(NTHR), 0, (hipStream_t)stream, tiles, stats, g, patches);
+    else if (dtype == 1) hipLaunchKernelGGL(k_make_patches<1>, grid, dim3(NTHR), 0, (hipStream_t)stream, tiles, stats, g, patches);
+    else hipLaunchKernelGGL(k_make_patches<0>, grid, dim3(NTHR), 0, (hipStream_t)stream, tiles, stats, g, patches);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
+}
+extern "C" int cpx_make_subtiles(const uint8_t *tiles, const float *stats, int nT,
+                                 const cpx_tiling *tiling, void *patches, void *stream) {
+    return cpx_make_patches(tiles, stats, nT, tiling, 0, patches, stream);
 }
 
 extern "C" int cpx_make_subtiles_f32(const uint8_t *tiles, const float *stats, int nT,

@@ -23,6 +23,7 @@ from ._lib import CpxBlockWeights, CpxConvOp, CpxNetWeights, CpxRecord, CpxTilin
 PS = 8
 BSIZE = 256
 HALF_DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+NET_DTYPES = {**HALF_DTYPES, "fp32": torch.float32}      # resolve_precision, models.py:37-69
 
 
 # --------------------------------------------------------------------------
@@ -94,8 +95,9 @@ class NetWeights:
     ``from_state_dict`` accepts the reference's state-dict layout
     (predict_wsi.py:1393-1405; ``torch.save(net.state_dict())``, vit_sam.py:269-285)
     and mirrors ``net.load_model`` + ``net.to(dtype)``: every parameter is first
-    rounded to the half dtype, GEMM weights stay in it, vectors are widened back
-    to float32 for the epilogues.
+    rounded to the network dtype, GEMM weights stay in it, vectors are widened back
+    to float32 for the epilogues.  ``fp32`` keeps everything float32 (exact-f32 MFMA
+    kernels, csrc/cpx_net_f32.hip) and never folds LayerNorm.
     """
 
     def __init__(self):
@@ -115,11 +117,12 @@ class NetWeights:
     @classmethod
     def from_state_dict(cls, sd: dict, precision: str = "bf16", device="cuda:0",
                         fuse_ln: bool = True) -> "NetWeights":
-        if precision not in HALF_DTYPES:
-            raise ValueError(f"precision {precision!r}: the MI355X engine computes in bf16 or fp16 "
-                             "(fp32 has no MFMA fast path on gfx950)")
+        if precision not in NET_DTYPES:
+            raise ValueError(f"precision {precision!r}: expected one of {sorted(NET_DTYPES)}")
         sd = {k.removeprefix("module."): v for k, v in sd.items()}
-        hd = HALF_DTYPES[precision]
+        hd = NET_DTYPES[precision]
+        if precision == "fp32":
+            fuse_ln = False
         fts, ncls, depth = cls.infer_structure(sd)
         if fts is not None and (any(c % 8 for c in fts) or len(fts) > 3):
             raise NotImplementedError("UNet semantic head: channel counts must be multiples of 8, at most 3 levels")
@@ -142,7 +145,8 @@ class NetWeights:
         c.depth, c.ncls = depth, ncls
         c.n_head_cols = 192 + (ncls * 64 if ncls > 1 else 0)
         c.ld_head = (c.n_head_cols + 127) // 128 * 128
-        c.dtype = 0 if precision == "bf16" else 1
+        c.dtype = _lib.DTYPE_CODE[precision]
+        c.prof = None
         c.fuse_ln = int(bool(fuse_ln))
 
         def fold_ln(w, b, gamma, beta):
@@ -213,7 +217,7 @@ class NetWeights:
 
     def _build_unet_ops(self, sd, fts, out_ch, half, vec32):
         """Flatten classpose.unet.UNet (unet.py:146-196) into the conv list of cpx_conv_op."""
-        hd = HALF_DTYPES["bf16" if self.c.dtype == 0 else "fp16"]
+        hd = {0: torch.bfloat16, 1: torch.float16, 2: torch.float32}[self.c.dtype]
         up = lambda x, m: (x + m - 1) // m * m
         ops = []
 
@@ -299,7 +303,8 @@ class _Slot:
         nS = nT * eng.n_sub
         self.stats = torch.empty(nT * 3 * 4, dtype=torch.float32, device=d)
         self.hist = torch.empty(nT * 768, dtype=torch.int32, device=d)
-        self.patches = torch.zeros(nS * 1024 * 192, dtype=torch.int16, device=d)   # zeros: a partial first batch still runs all rows
+        # zeros: a partial first batch still runs all rows
+        self.patches = torch.zeros(nS * 1024 * 192 * (2 if eng.w.c.dtype == _lib.DT_F32 else 1), dtype=torch.int16, device=d)
         self.head = torch.empty(nS * 1024 * eng.w.c.ld_head, dtype=torch.float32, device=d)
         self.dP = torch.empty((nT, 2, H, W), dtype=torch.float32, device=d)
         self.cellprob = torch.empty((nT, H, W), dtype=torch.float32, device=d)
@@ -348,14 +353,16 @@ class Engine:
         lo = percentile_params(H * W, 1)
         hi = percentile_params(H * W, 99)
         self.pct = (lo[0], lo[1], hi[0], hi[1])
-        self.net_ws_bytes = self.L.cpx_net_workspace_bytes(nT * self.n_sub)
+        self.net_ws_bytes = self.L.cpx_net_workspace_bytes(nT * self.n_sub, weights.c.dtype)
         if weights.c.n_unet_ops:
             self.net_ws_bytes += self.L.cpx_unet_workspace_bytes(weights.c.unet_ops, weights.c.n_unet_ops,
-                                                                nT * self.n_sub)
+                                                                nT * self.n_sub, weights.c.dtype)
         self.net_ws = torch.empty(self.net_ws_bytes, dtype=torch.uint8, device=d)
         self.taper = torch.from_numpy(taper_1d(BSIZE)).to(d)
         self.pp_ws_bytes = self.L.cpx_postproc_workspace_bytes(nT, H, W)
-        self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 8192)
+        # every label the dynamics can produce gets a record slot; ids are uint16, so 65535 bounds it
+        # (fetch_* raise instead of dropping cells when a tile would exceed the buffer)
+        self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 65535)
         self.max_pts = nT * max(4096, H * W // 8)             # device vertex pool (f1), 16 B per vertex
         self.slots = [_Slot(self) for _ in range(self.N_SLOTS)]
         self.s_net = torch.cuda.Stream(d)
@@ -384,11 +391,10 @@ class Engine:
         self.s_net.wait_event(sl.ev_post)               # this slot's previous batch left the head buffer
         lo_p, lo_g, hi_p, hi_g = self.pct
         sn, sp = self.s_net.cuda_stream, self.s_post.cuda_stream
-        self.L.cpx_set_half_dtype(self.w.c.dtype)
         check(self.L.cpx_normalize_stats_u8(ptr(tiles_u8), n, self.H, self.W, lo_p, lo_g, hi_p, hi_g,
                                             ptr(sl.stats), ptr(sl.hist), sn), "normalize_stats")
-        check(self.L.cpx_make_subtiles(ptr(tiles_u8), ptr(sl.stats), n, C.byref(self.tiling),
-                                       ptr(sl.patches), sn), "make_subtiles")
+        check(self.L.cpx_make_patches(ptr(tiles_u8), ptr(sl.stats), n, C.byref(self.tiling), self.w.c.dtype,
+                                      ptr(sl.patches), sn), "make_patches")
         # the network always runs the full batch (rows of absent tiles hold old patches): kernel selection
         # and tile shapes depend on M, so a partial last batch would otherwise round differently --
         # this keeps a tile's outputs bitwise independent of batch composition, rank and world size
@@ -457,9 +463,10 @@ class Engine:
         total = int(out.n_pts_total.item())
         if total > self.max_pts:
             return None
-        counts = out.rec_counts[:n].cpu().numpy()
-        raw = out.cells.cpu().numpy().view(CELL_DTYPE).reshape(self.nT, self.max_rec)
-        rows = [raw[t, :min(int(counts[t]), self.max_rec)] for t in range(n)]
+        counts = self._checked_counts(out.rec_counts, n)
+        mx = int(counts.max()) if n else 0
+        raw = out.cells.view(self.nT, self.max_rec, CELL_DTYPE.itemsize)[:n, :mx].cpu().numpy().view(CELL_DTYPE).reshape(n, mx)
+        rows = [raw[t, :int(counts[t])] for t in range(n)]
         tile = np.concatenate([np.full(len(r), t, np.int32) for t, r in enumerate(rows)]) if n else np.zeros(0, np.int32)
         cells = np.concatenate(rows) if n else raw[:0, 0]
         return cells, tile, out.xy_pool[:total].cpu().numpy()
@@ -477,10 +484,17 @@ class Engine:
         """Compact per-cell records of a collected batch as a structured numpy array (D2H)."""
         recs = self._last.records if out is None else out.records
         cnts = self._last.rec_counts if out is None else out.rec_counts
-        counts = cnts[:n].cpu().numpy()
-        raw = recs.cpu().numpy().view(RECORD_DTYPE).reshape(self.nT, self.max_rec)
-        return np.concatenate([raw[t, :min(int(counts[t]), self.max_rec)] for t in range(n)]) \
-            if n else raw[:0, 0]
+        counts = self._checked_counts(cnts, n)
+        mx = int(counts.max()) if n else 0
+        raw = recs.view(self.nT, self.max_rec, RECORD_DTYPE.itemsize)[:n, :mx].cpu().numpy().view(RECORD_DTYPE).reshape(n, mx)
+        return np.concatenate([raw[t, :int(counts[t])] for t in range(n)]) if n else raw.reshape(-1)
+
+    def _checked_counts(self, rec_counts: torch.Tensor, n: int) -> np.ndarray:
+        counts = rec_counts[:n].cpu().numpy()
+        if n and int(counts.max()) > self.max_rec:
+            raise RuntimeError(f"a tile holds {int(counts.max())} instances but the record buffer has {self.max_rec} "
+                               "slots per tile: cells would be dropped")
+        return counts
 
 
 CELL_DTYPE = np.dtype([("area", "<f8"), ("perimeter", "<f8"), ("cx", "<f8"), ("cy", "<f8"),

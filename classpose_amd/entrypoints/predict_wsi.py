@@ -15,8 +15,9 @@ the rank that produced the tile instead of one PostProcessor process for all dev
 Multi-GPU: either launch under ``torch.distributed.run`` or pass ``--device cuda:0,1,...``
 (this process then spawns one worker per listed GPU, like the reference does).
 
-Not built yet (raise, never silently ignored): GrandQC tissue/artefact detection, ROI
-filtering, ``--output_type`` csv/spatialdata, slides whose mpp differs from the model mpp.
+Also built: GrandQC tissue / artefact detection, ROI tile selection and cell filters,
+``--output_type csv``, slides whose mpp differs from the model mpp, ``--precision fp32|fp16|bf16``.
+Not built (raises, never silently ignored): ``--output_type spatialdata``.
 """
 from __future__ import annotations
 
@@ -423,10 +424,16 @@ def _check_unsupported(args):
         raise ValueError(f"Tile size must be at least {MIN_TILE_SIZE}, got {args.tile_size}")
 
 
-def _spawn_entry(local_rank: int, world: int, port: int, argv: list[str], dev_ids: list[int], parser_factory=None):
+def _args_dict(args) -> dict:
+    """Plain dict of an argparse namespace OR of the attribute-bag classes the reference's integration
+    tests pass (``type("Args", (), {...})``, tests/test_prediction_integration.py:48-70)."""
+    return {k: getattr(args, k) for k in dir(args) if not k.startswith("_")}
+
+
+def _spawn_entry(local_rank: int, world: int, port: int, arg_dict: dict, dev_ids: list[int]):
     os.environ.update(RANK=str(local_rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev_ids[local_rank]),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    args = (parser_factory or build_parser)().parse_args(argv)
+    args = argparse.Namespace(**arg_dict)
     if not hasattr(args, "model_config"):
         args.model_config = None
     main(args, spawned=True)
@@ -441,7 +448,9 @@ def main(args, spawned: bool = False, parser_factory=None):
         import torch.multiprocessing as mp
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         ids = [d.index or 0 for d in devices]
-        mp.start_processes(_spawn_entry, args=(len(devices), port, sys.argv[1:], ids, parser_factory),
+        # fresh child processes, one per listed GPU (the reference spawns its workers the same way,
+        # predict_wsi.py:1542-1572); they receive the parsed arguments, not sys.argv
+        mp.start_processes(_spawn_entry, args=(len(devices), port, _args_dict(args), ids),
                            nprocs=len(devices), start_method="spawn")
         return
     rank, world, local = parallel.init_distributed()
@@ -477,7 +486,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--overlap", type=int, default=DEFAULT_OVERLAP)
     p.add_argument("--output_type", type=str, nargs="+", default=None, choices=["csv", "spatialdata"])
     p.add_argument("--inference_threads", type=int, default=None,
-                   help="accepted for compatibility; the engine overlaps stages with HIP streams instead")
+                   help="accepted for compatibility (the reference runs N Python threads per GPU to hide its "
+                        "per-tile host work; here batches overlap on HIP streams and the value has no effect)")
     return p
 
 

@@ -23,13 +23,11 @@ PRECISIONS = ("fp32", "fp16", "bf16")
 
 
 def resolve_precision(precision: str, device: torch.device | None = None) -> str:
-    """models.py:37-69.  gfx950 has bf16 MFMA, so bf16 never falls back to fp16; fp32 is
-    served by the bf16 path's accumulate-in-f32 kernels only on explicit request."""
+    """models.py:37-69.  gfx950 has bf16 MFMA, so bf16 never falls back to fp16; fp32 runs on the
+    exact-f32 matrix instruction (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate) with float32
+    weights and activations end to end."""
     if precision not in PRECISIONS:
         raise ValueError(f"Unknown precision '{precision}'. Expected one of {sorted(PRECISIONS)}.")
-    if precision == "fp32":
-        raise NotImplementedError("fp32 network inference is not built for the MI355X engine "
-                                  "(no f32 MFMA fast path); use bf16 (default) or fp16")
     models_logger.info("Using inference precision: %s", precision)
     return precision
 

@@ -98,15 +98,15 @@ def make_subtiles(tiles_u8: torch.Tensor, bsize: int = 256, augment: bool = Fals
 
 
 def make_patches(tiles_u8: torch.Tensor, bsize: int = 256, augment: bool = False,
-                 tile_overlap: float = 0.1):
+                 tile_overlap: float = 0.1, dtype: torch.dtype = torch.bfloat16):
     t, _ = _batched(tiles_u8.contiguous(), 3)
     nT, H, W, _c = t.shape
     til = make_tiling(H, W, bsize, augment, tile_overlap)
     stats = normalize_stats(t)
     nS = nT * til.ny * til.nx
-    out = torch.empty((nS * (bsize // 8) ** 2, 192), dtype=torch.bfloat16, device=t.device)
-    check(_lib.lib().cpx_make_subtiles(ptr(t), ptr(stats), nT, C.byref(til), ptr(out),
-                                       _stream(t.device)), "make_subtiles")
+    out = torch.empty((nS * (bsize // 8) ** 2, 192), dtype=dtype, device=t.device)
+    check(_lib.lib().cpx_make_patches(ptr(t), ptr(stats), nT, C.byref(til), _DT[dtype], ptr(out),
+                                      _stream(t.device)), "make_patches")
     return out, til
 
 
@@ -239,26 +239,29 @@ def gemm(A: torch.Tensor, Wt: torch.Tensor, epilogue: str = "bf16", bias=None, a
     N = Wt.shape[0]
     dev = A.device
     out = torch.empty((M, N), dtype=torch.float32 if epilogue == "f32" else A.dtype, device=dev)
-    check(_lib.lib().cpx_gemm_bf16(ptr(A), ptr(Wt), M, N, K, EPI[epilogue], ptr(bias), ptr(aux),
-                                   ptr(out), N, _stream(dev)), "gemm")
+    check(_lib.lib().cpx_gemm(_DT[A.dtype], ptr(A), ptr(Wt), M, N, K, EPI[epilogue], ptr(bias), ptr(aux),
+                              ptr(out), N, _stream(dev)), "gemm")
     return out
+
+
+_DT = {torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16, torch.float32: _lib.DT_F32}
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6):
     out = torch.empty_like(x)
-    check(_lib.lib().cpx_layernorm_bf16(ptr(x), ptr(w), ptr(b), x.shape[0], x.shape[1], eps, ptr(out),
-                                        _stream(x.device)), "layernorm")
+    check(_lib.lib().cpx_layernorm(_DT[x.dtype], ptr(x), ptr(w), ptr(b), x.shape[0], x.shape[1], eps, ptr(out),
+                                   _stream(x.device)), "layernorm")
     return out
 
 
 def attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor):
-    """qkv (nS*1024, 3072) half; rel_* (64,64) half tables (x8, zero last row)."""
+    """qkv (nS*1024, 3072) bf16 / fp16 / fp32; rel_* (64,64) tables of the same type (x8, zero last row)."""
     M = qkv.shape[0]
     nS = M // 1024
     vt = torch.empty((M, 1024), dtype=qkv.dtype, device=qkv.device)
     out = torch.empty((M, 1024), dtype=qkv.dtype, device=qkv.device)
-    check(_lib.lib().cpx_attention_relpos(ptr(qkv), ptr(rel_h), ptr(rel_w), nS, ptr(vt), ptr(out),
-                                          _stream(qkv.device)), "attention")
+    check(_lib.lib().cpx_attention(_DT[qkv.dtype], ptr(qkv), ptr(rel_h), ptr(rel_w), nS, ptr(vt), ptr(out),
+                                   _stream(qkv.device)), "attention")
     return out
 
 

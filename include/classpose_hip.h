@@ -15,7 +15,11 @@
  *     nothing allocates: the caller supplies workspaces sized by the
  *     *_workspace_bytes() queries (graph-capture safe);
  *   - tiles are batched: leading dimension nT, then the reference's layout;
- *   - thread-safe for distinct streams + distinct workspaces.
+ *   - thread-safe for distinct streams + distinct workspaces: the library keeps no mutable
+ *     process-global compute state (the element type travels in cpx_net_weights.dtype / the
+ *     `dtype` arguments, the optional timing handle in cpx_net_weights.prof); a bf16, an fp16
+ *     and an fp32 engine may run from different host threads.  The A/B and ablation switches
+ *     of include/classpose_hip_debug.h are process-global test hooks and are NOT covered.
  */
 #ifndef CLASSPOSE_HIP_H
 #define CLASSPOSE_HIP_H
@@ -32,7 +36,12 @@ extern "C" {
 #define CPX_ENOMEM (-12)
 #define CPX_EHIP (-5)
 
-/* Library / device identification. Returns the ABI version (this header: 1). */
+/* element types of the network path (cpx_net_weights.dtype and the `dtype` arguments) */
+#define CPX_DT_BF16 0
+#define CPX_DT_F16 1
+#define CPX_DT_F32 2   /* --precision fp32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations */
+
+/* Library / device identification. Returns the ABI version (this header: 2). */
 int cpx_abi_version(void);
 /* Last HIP error string recorded by a failing call on this thread (host ptr). */
 const char *cpx_last_error(void);
@@ -91,6 +100,10 @@ typedef struct cpx_tiling {
  * patches [nT*ny*nx][1024][192], k = c*64 + i*8 + j.                       */
 int cpx_make_subtiles(const uint8_t *tiles_u8, const float *stats, int nT,
                       const cpx_tiling *tiling_host, void *patches_bf16, void *stream);
+/* Same with the element type of the patch rows chosen by `dtype` (CPX_DT_*): what
+ * core._forward's X.to(dtype=net dtype) produces, core.py:61-63.             */
+int cpx_make_patches(const uint8_t *tiles_u8, const float *stats, int nT,
+                     const cpx_tiling *tiling_host, int dtype, void *patches, void *stream);
 /* Same but float32 NCHW sub-tiles [nT*ny*nx][3][bsize][bsize] (what
  * make_tiles returns; used by parity tests and the fp32 debug path).        */
 int cpx_make_subtiles_f32(const uint8_t *tiles_u8, const float *stats, int nT,
@@ -149,8 +162,9 @@ typedef struct cpx_net_weights {
     int ncls;               /* n_cell_classes (W3.shape[1])                    */
     int n_head_cols;        /* 192 + ncls*64                                   */
     int ld_head;            /* n_head_cols rounded up to 128                   */
-    int dtype;              /* 0 = bf16, 1 = fp16                              */
-    int fuse_ln;            /* 1: norm1 / norm2 are folded into qkv / mlp.lin1 (see above) */
+    int dtype;              /* CPX_DT_BF16 / CPX_DT_F16 / CPX_DT_F32: element type of every "void *"
+                               GEMM operand below (vectors are always float32)            */
+    int fuse_ln;            /* 1: norm1 / norm2 are folded into qkv / mlp.lin1 (half types only) */
     const void *pe_w;       /* [1024][192]                                     */
     const float *pe_b;      /* [1024]                                          */
     const float *pos;       /* [1024 tokens][1024] float32                     */
@@ -163,17 +177,29 @@ typedef struct cpx_net_weights {
     const float *head_b;    /* [ld_head]                                       */
     int n_unet_ops;         /* 0: 1x1-conv class head inside head_w; > 0: UNet head below      */
     const cpx_conv_op *unet_ops;   /* HOST array; the last op writes the ncls*64 class columns  */
+    void *prof;             /* NULL, or a handle from cpx_prof_create: per-launch HIP-event timing   */
 } cpx_net_weights;
 
-size_t cpx_net_workspace_bytes(int n_subtiles);
+size_t cpx_net_workspace_bytes(int n_subtiles, int dtype);
 /* extra bytes (appended to the network workspace) when w->n_unet_ops > 0 */
-size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops_host, int n_ops, int n_subtiles);
+size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops_host, int n_ops, int n_subtiles, int dtype);
 int cpx_unet_head_forward(const cpx_conv_op *ops_host, int n_ops, const void *feat, int n_subtiles,
-                          float *head, int ld_head, int col0, void *workspace, size_t workspace_bytes,
-                          void *stream);
-/* patches_bf16 [nS*1024][192] -> head [nS*1024][ld_head] float32.           */
-int cpx_net_forward(const cpx_net_weights *w_host, const void *patches_bf16, int n_subtiles,
+                          float *head, int ld_head, int col0, int dtype, void *workspace,
+                          size_t workspace_bytes, void *stream);
+/* patches [nS*1024][192] of w_host->dtype -> head [nS*1024][ld_head] float32
+ * (the .float() of core._forward, core.py:67).                               */
+int cpx_net_forward(const cpx_net_weights *w_host, const void *patches, int n_subtiles,
                     float *head, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Per-launch timing of the dominant kernels of cpx_net_forward (bench.py's roofline lines): HIP
+ * events recorded on the launch stream around every `stride`-th layer's kernels of the kinds in
+ * kinds_mask (bit 0 mlp.lin1, 1 attention, 2 qkv, 3 attn.proj, 4 mlp.lin2).  The handle is carried in
+ * cpx_net_weights.prof and belongs to one engine / host thread.  cpx_prof_collect (after a stream
+ * sync) fills ms_sum[5] / count[5] per kind and resets the handle.                              */
+#define CPX_PROF_N_KINDS 5
+int cpx_prof_create(int max_launches, int stride, unsigned kinds_mask, void **prof_out);
+int cpx_prof_collect(void *prof, double *ms_sum, int *count);
+void cpx_prof_destroy(void *prof);
 
 /* ------------------------------------------------------------------------
  * a20  GrandQC tissue / artefact networks: UNet++ decoder on an EfficientNet-B0 encoder
@@ -221,6 +247,11 @@ int cpx_qc_forward(const cpx_qc_op *ops_host, int n_ops, const uint8_t *patches_
 int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilogue,
                   const float *bias, const void *resid_or_pos, void *out, int ld_out,
                   void *stream);
+/* Same for any element type.  CPX_DT_F32: A, Wt, resid and out are float32 (out always f32, the
+ * QKV epilogue is the plain one: the f32 attention reads V from the qkv rows), K % 16 == 0.  */
+int cpx_gemm(int dtype, const void *A, const void *Wt, int M, int N, int K, int epilogue,
+             const float *bias, const void *resid_or_pos, void *out, int ld_out, void *stream);
+int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue);
 /* Same with a LayerNorm over the K = 1024 input row folded in (consumer) and/or partial row
  * statistics of the output emitted (producer, RESID epilogue, N = 1024, 256^2-tile shapes):
  *   out = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]     (then the epilogue)
@@ -235,6 +266,11 @@ int cpx_layernorm_bf16(const void *x, const float *w, const float *b, int rows, 
 /* qkv [nS*1024][3072] bf16 (q|k|v, head-major inside) -> attn out [nS*1024][1024]. */
 int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                          void *vT_ws, void *out, void *stream);
+/* any element type (CPX_DT_F32: float32 qkv / tables [64][64] / out; vT_ws unused)           */
+int cpx_layernorm(int dtype, const void *x, const float *w, const float *b, int rows, int C,
+                  float eps, void *out, void *stream);
+int cpx_attention(int dtype, const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                  void *vT_ws, void *out, void *stream);
 
 /* ------------------------------------------------------------------------
  * a11-a16  flows -> instance ids -> classes

@@ -1,0 +1,27 @@
+/*
+ * classpose_hip_debug.h -- A/B, ablation and diagnostic switches of libclasspose_hip.so.
+ *
+ * NOT part of the product ABI (include/classpose_hip.h): these are process-global test hooks used
+ * by tools/*.py and a few tests to compare kernel variants in one process.  They are not
+ * thread-safe, default to the production setting and no product code path calls them.
+ */
+#ifndef CLASSPOSE_HIP_DEBUG_H
+#define CLASSPOSE_HIP_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+void cpx_gemm_set_variant(int glds);        /* 128^2 GEMM: 1 LDS-DMA staging (default), 0 register staging */
+void cpx_gemm_set_big(int on);              /* 1 (default): 256^2 kernel when the shape allows          */
+void cpx_gemm_set_l2_block(int on);         /* 1 (default): 8 x 4 super-tile order per XCD               */
+void cpx_gemm_set_reverse(int on);          /* 0 (default): mlp.lin2 walks M backwards when 1            */
+void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */
+void cpx_attention_set_xcd_order(int on);   /* 1 (default): (sub-tile, head) pairs pinned to one XCD     */
+void cpx_attention_set_trv(int on);         /* 0 (default): V through ds_read_b64_tr_b16                  */
+void cpx_follow_set_early_exit(int on);     /* 1 (default): Euler loop leaves when its orbit closes      */
+/* per-wave cycle stamps of the attention loop segments: dbg [n_subtiles*16*8][4][9] */
+int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                        void *vT_ws, void *out, unsigned *dbg, void *stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -266,3 +266,123 @@ def test_predict_wsi_cpsam_cli(cuda, tmp_path, monkeypatch):
     from scipy.spatial import cKDTree
     d, idx = cKDTree(found).query(np.stack([cx[inner], cy[inner]], 1))
     assert (d < 1.5).mean() > 0.99
+
+
+def _reference_integration_args(slide, out, **over):
+    """the attribute bag of the reference's integration tests
+    (/root/reference/tests/test_prediction_integration.py:48-70): conic, 256 / 64, fp32, batch 1"""
+    d = {"model_config": "conic", "slide_path": slide, "output_folder": str(out),
+         "tissue_detection_model_path": None, "artefact_detection_model_path": None, "filter_artefacts": False,
+         "roi_geojson": None, "roi_class_priority": None, "min_area": 0, "tta": False, "batch_size": 1,
+         "device": "cuda", "tile_size": 256, "precision": "fp32", "overlap": 64, "output_type": None,
+         "inference_threads": 2}
+    d.update(over)
+    return type("Args", (), d)
+
+
+@pytest.mark.parametrize("threads", [2, 1])
+def test_predict_wsi_reference_integration_args_fp32(cuda, tmp_path, monkeypatch, threads):
+    """test_predict_wsi_integration / ..._one_inference_thread of the reference, same argument set
+    (--precision fp32 through the exact-f32 MFMA kernels), same assertions + the nuclei check"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "2")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs = 840, 650
+    predict_wsi.main(_reference_integration_args(f"synthetic://{W}x{Hs}?mpp=0.5&seed=41", tmp_path,
+                                                 inference_threads=threads))
+    cont_p, cent_p = next(tmp_path.glob("*_cell_contours.geojson")), next(tmp_path.glob("*_cell_centroids.geojson"))
+    assert cont_p.exists() and cent_p.exists()
+    cont = json.load(open(cont_p))
+    assert cont["type"] == "FeatureCollection"
+    nx, ny = (W - 256) // 192 + 1, (Hs - 256) // 192 + 1
+    cov_w, cov_h = (nx - 1) * 192 + 256, (ny - 1) * 192 + 256
+    cx, cy, r, _ = synth.nuclei_in_region(41, 0, 0, cov_w, cov_h)
+    inner = (cx - r > 12) & (cx + r < cov_w - 12) & (cy - r > 12) & (cy + r < cov_h - 12)
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[inner], cy[inner]], 1))
+    assert (d < 1.5).mean() > 0.99 and len(np.unique(idx[d < 1.5])) == (d < 1.5).sum()
+
+
+def test_predict_wsi_cpsam_reference_integration_args_fp32(cuda, tmp_path, monkeypatch):
+    """test_predict_wsi_cpsam_integration of the reference (:172-215)"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    from classpose_amd.entrypoints import predict_wsi_cpsam
+    args = _reference_integration_args("synthetic://700x520?mpp=0.5&seed=43", tmp_path, model_path="cpsam", train_mpp=0.5)
+    predict_wsi_cpsam.main(args)
+    assert next(tmp_path.glob("*_cell_contours.geojson")).exists() and next(tmp_path.glob("*_cell_centroids.geojson")).exists()
+
+
+def test_predict_wsi_multi_gpu_integration(tmp_path, monkeypatch):
+    """test_predict_wsi_multi_gpu_integration of the reference (:131-170): --device cuda:0,1 spawns one fresh
+    worker process per GPU (static tile shard k % 2, RCCL all-gather of the cell tables); the result must equal
+    the single-GPU run cell for cell."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("Needs at least 2 GPUs")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    slide = "synthetic://1500x1100?mpp=0.5&seed=45"
+    o1, o2 = tmp_path / "one", tmp_path / "two"
+    predict_wsi.main(_reference_integration_args(slide, o1, device="cuda:0", precision="bf16"))
+    predict_wsi.main(_reference_integration_args(slide, o2, device="cuda:0,1", precision="bf16"))
+    key = lambda f: tuple(m["value"] for m in f["properties"]["measurements"])
+    a = sorted(key(f) for f in json.load(open(next(o1.glob("*_cell_contours.geojson"))))["features"])
+    b = sorted(key(f) for f in json.load(open(next(o2.glob("*_cell_contours.geojson"))))["features"])
+    assert len(a) > 100 and a == b
+
+
+def test_predict_wsi_cli_puma_grandqc(cuda, tmp_path, monkeypatch):
+    """BASELINE configs[2] in one run (scaled down): puma (10 classes, 0.22 um/px, default 1024 / 64 tiles = 25
+    sub-tiles) WITH GrandQC tissue + artefact detection, --filter_artefacts and --output_type csv"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_QC_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs = 6800, 5200
+    out = tmp_path / "out"
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "puma", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.22&seed=47",
+        "--output_folder", str(out), "--device", "cuda:0",
+        "--tissue_detection_model_path", str(tmp_path / "td.pth"),
+        "--artefact_detection_model_path", str(tmp_path / "art.pth"), "--filter_artefacts",
+        "--output_type", "csv"])
+    assert args.tile_size == 1024 and args.overlap == 64 and args.precision == "bf16"
+    predict_wsi.main(args)
+    import pandas as pd
+    df = pd.read_csv(next(out.glob("*_cell_densities.csv")))
+    names = ["Apoptosis", "Tumor", "Endothelial", "Stroma", "Lymphocyte", "Histocyte", "Epithelial", "Melanophage", "Other"]
+    assert list(df["cell_class"]) == names and set(df["region"]) == {"tissue"}
+    cont = json.load(open(next(out.glob("*cell_contours.geojson"))))
+    tissue = json.load(open(next(out.glob("*tissue_contours.geojson"))))
+    art = json.load(open(next(out.glob("*artefact_contours.geojson"))))
+    assert df["count"].sum() == len(cont["features"]) > 500
+    assert len(tissue["features"]) == 1 and len(art["features"]) == 1
+    t_area = tissue["features"][0]["properties"]["measurements"][0]["value"]
+    a_area = art["features"][0]["properties"]["measurements"][0]["value"]
+    assert np.allclose(df["density"], df["count"] / ((t_area - a_area) * 0.22 * 0.22 / 1e6))
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    u, v = found[:, 0] / W, found[:, 1] / Hs
+    tol = 1.5 * (10 / 0.22) / W
+    ell = ((u - 0.5) / (0.40 + tol)) ** 2 + ((v - 0.5) / (0.36 + tol)) ** 2 <= 1.0
+    fold = (u > 0.30 + tol) & (u < 0.42 - tol) & (v > 0.30 + tol) & (v < 0.45 - tol)
+    assert np.all(ell) and not np.any(fold)
+    # every class label follows the nucleus id hash (9 cell types)
+    cx, cy, r, ident = synth.nuclei_in_region(47, 0, 0, W, Hs)
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(np.stack([cx, cy], 1)).query(found)
+    assert (d < 1.5).mean() > 0.995
+    got = [f["properties"]["classification"]["name"] for f in cont["features"]]
+    ok = d < 1.5
+    assert [g for g, k in zip(got, ok) if k] == [names[int(i % np.uint64(9))] for i in ident[idx[ok]]]

@@ -160,7 +160,7 @@ def test_net_forward_vs_oracle(cuda, depth, nS):
         .reshape(nS * 1024, 192).to(torch.bfloat16).to(cuda)
     L = _lib.lib()
     head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
-    ws = torch.empty(L.cpx_net_workspace_bytes(nS), dtype=torch.uint8, device=cuda)
+    ws = torch.empty(L.cpx_net_workspace_bytes(nS, w.c.dtype), dtype=torch.uint8, device=cuda)
     import ctypes as C
     _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
                                  ws.numel(), torch.cuda.current_stream().cuda_stream))
@@ -237,7 +237,6 @@ def test_engine_variants_tta_512_fp16(cuda, H, aug, precision):
     assert _rel(out.logits[0].cpu(), torch.from_numpy(yc)) < tol
     ref = dynamics.compute_masks(out.dP[0].cpu().numpy(), out.cellprob[0].cpu().numpy())
     assert np.array_equal(ops.masks_to_numpy(out.masks)[0], ref)
-    _lib.lib().cpx_set_half_dtype(0)
 
 
 @pytest.mark.parametrize("nS", [2, 32])
@@ -306,7 +305,7 @@ def test_net_forward_fused_vs_unfused_layernorm(cuda, fuse):
     L = _lib.lib()
     import ctypes as C
     head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
-    ws = torch.empty(L.cpx_net_workspace_bytes(nS), dtype=torch.uint8, device=cuda)
+    ws = torch.empty(L.cpx_net_workspace_bytes(nS, w.c.dtype), dtype=torch.uint8, device=cuda)
     _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
                                  ws.numel(), torch.cuda.current_stream().cuda_stream))
     out = head[:1024 * 2, :640].reshape(2, 32, 32, 10, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(2, 10, 256, 256).cpu()
@@ -327,7 +326,7 @@ def test_unet_semantic_head_vs_oracle(cuda, fts, nS):
     L = _lib.lib()
     import ctypes as C
     head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
-    nbytes = L.cpx_net_workspace_bytes(nS) + L.cpx_unet_workspace_bytes(w.c.unet_ops, w.c.n_unet_ops, nS)
+    nbytes = L.cpx_net_workspace_bytes(nS, w.c.dtype) + L.cpx_unet_workspace_bytes(w.c.unet_ops, w.c.n_unet_ops, nS, w.c.dtype)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=cuda)
     _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
                                  ws.numel(), torch.cuda.current_stream().cuda_stream))
