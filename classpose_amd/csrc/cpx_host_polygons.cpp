@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/classpose_hip.h"
+#include "cpx_ring_metrics.h"
 
 namespace {
 const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
@@ -168,19 +169,8 @@ extern "C" int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, con
         o.n_pts = np;
         used += np;
         if (np < 4) continue;                              // "curr_coords.shape[0] < 4" -> invalid cell
-        // shoelace area / centroid about the first vertex, perimeter incl. the closing edge
-        double a2 = 0, cx = 0, cy = 0, per = 0;
-        const double bx = xy[0], by = xy[1];
-        for (int i = 0; i < np; ++i) {
-            const double x0 = xy[2 * i] - bx, y0 = xy[2 * i + 1] - by;
-            const double x1 = xy[2 * ((i + 1) % np)] - bx, y1 = xy[2 * ((i + 1) % np) + 1] - by;
-            const double cr = x0 * y1 - x1 * y0;
-            a2 += cr; cx += (x0 + x1) * cr; cy += (y0 + y1) * cr;
-            per += std::sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));   // same expression as cpx_polygons.hip
-        }
-        o.area = std::fabs(a2) / 2;
-        o.perimeter = per;
-        if (a2 != 0) { o.cx = bx + cx / (3 * a2); o.cy = by + cy / (3 * a2); }
+        // GEOS-order area / length / centroid (cpx_ring_metrics.h)
+        const double a2 = cpx_ring_metrics(xy, np, &o.area, &o.perimeter, &o.cx, &o.cy);
         o.valid = (a2 != 0 && ring_is_valid(xy, np)) ? 1 : 0;
     }
     return used;

@@ -13,6 +13,7 @@
 // contours[0] (the component found LAST) is the last such start.
 // Built with -ffp-contract=off (the double arithmetic is spelled out).
 #include "cpx_common.h"
+#include "cpx_ring_metrics.h"
 
 #define PG_THR 64
 
@@ -172,19 +173,7 @@ __global__ void k_poly_write(const uint16_t *__restrict__ masks, const cpx_recor
         pg_trace<2>(g, start[id] % W, start[id] / W, nullptr, xy, scale, origins[2 * t], origins[2 * t + 1]);
         o.n_pts = np;
         if (np >= 4) {
-            double a2 = 0, cx = 0, cy = 0, per = 0;
-            const double bx = xy[0], by = xy[1];
-            for (int i = 0; i < np; ++i) {
-                const int j = (i + 1) % np;
-                const double x0 = xy[2 * i] - bx, y0 = xy[2 * i + 1] - by;
-                const double x1 = xy[2 * j] - bx, y1 = xy[2 * j + 1] - by;
-                const double cr = x0 * y1 - x1 * y0;
-                a2 += cr; cx += (x0 + x1) * cr; cy += (y0 + y1) * cr;
-                per += sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
-            }
-            o.area = fabs(a2) / 2;
-            o.perimeter = per;
-            if (a2 != 0) { o.cx = bx + cx / (3 * a2); o.cy = by + cy / (3 * a2); }
+            const double a2 = cpx_ring_metrics(xy, np, &o.area, &o.perimeter, &o.cx, &o.cy);
             o.valid = (a2 != 0 && pg_ring_is_valid(xy, np)) ? 1 : 0;
         }
     }

@@ -373,3 +373,62 @@ def test_engine_full_batch_is_order_and_slot_invariant(cuda):
     eng1 = engine.Engine(w, 256, batch_tiles=1)                 # one tile per launch: small-tile GEMM kernels
     d = eng1.run(t[4:5].contiguous())
     assert float((d.dP - a_dp[4:5]).abs().max()) < 0.05 * float(a_dp.abs().max())   # other kernel variant: tolerance only
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_benched_path_depth24_32_subtiles_vs_oracle(cuda, precision):
+    """The configuration bench.py times -- depth 24, 32 sub-tiles per launch, fuse_ln=True, i.e. the 256^2
+    k_gemm256 kernels with the folded LayerNorm, the RESID statistics epilogue and the QKV / V^T epilogue in
+    every layer -- against the fp32 oracle on 3 of the 32 sub-tiles (first, middle, last), at the SURVEY 8c
+    half-precision tolerance (rel-L2 <= 2e-2) and within 1.5x the error of the reference's own torch path
+    run in the same dtype."""
+    L = _lib.lib()
+    nS, depth = 32, 24
+    assert L.cpx_gemm_uses_big_tile(nS * 1024, 3072, 1024, ops.EPI["qkv"]) and L.cpx_gemm_uses_big_tile(nS * 1024, 1024, 4096, ops.EPI["resid"])
+    sd = synth.make_state_dict(7, None, depth=depth, seed=3)
+    w = engine.NetWeights.from_state_dict(sd, precision, cuda, fuse_ln=True)
+    assert w.c.fuse_ln == 1
+    hd = engine.HALF_DTYPES[precision]
+    x = np.random.default_rng(0).random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5) \
+        .reshape(nS * 1024, 192).to(hd).to(cuda)
+    import ctypes as C
+    head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+    ws = torch.empty(L.cpx_net_workspace_bytes(nS, w.c.dtype), dtype=torch.uint8, device=cuda)
+    _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), torch.cuda.current_stream().cuda_stream))
+    out = head[:, :640].reshape(nS, 32, 32, 10, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(nS, 10, 256, 256)
+    pick = [0, 17, 31]
+    ours = torch.cat([out[pick][:, 3:], out[pick][:, :3]], 1).cpu()
+    xs = torch.from_numpy(x[pick])
+    ref32 = onet.class_transformer_forward(sd, xs)
+    sdh = {k: v.to(hd) if v.is_floating_point() else v for k, v in sd.items()}
+    refh = onet.class_transformer_forward(sdh, xs[:1], hd)             # the reference's own half-precision path (1 sub-tile)
+    e_ours, e_ref = _rel(ours, ref32), _rel(refh, ref32[:1])
+    per = [_rel(ours[i], ref32[i]) for i in range(len(pick))]
+    print(f"{precision} depth 24 / 32 sub-tiles (256^2 fused-LN kernels): rel-L2 vs fp32 oracle {e_ours:.4f} "
+          f"(per sub-tile {per}); torch-CPU {precision} vs fp32 {e_ref:.4f}; max-abs {float((ours - ref32).abs().max()):.4f}")
+    assert e_ours < 2e-2
+    assert e_ours < 1.5 * e_ref + 2e-3
+
+
+def test_engine_fp16_512px_vs_oracle(cuda):
+    """BASELINE configs[4] geometry on one GPU: Cellpose-SAM backbone + semantic head in fp16 on 512-px
+    tiles (9 sub-tiles each), depth 2: network outputs vs the fp32 oracle, ids bit-exact on the device tensors"""
+    from oracle import classmask, dynamics
+    sd = synth.make_state_dict(7, None, depth=2, seed=19)
+    w = engine.NetWeights.from_state_dict(sd, "fp16", cuda)
+    eng = engine.Engine(w, 512, batch_tiles=2)
+    assert eng.n_sub == 9
+    tiles = np.stack([synth.render_region(4321, 100, 50, 512, 512), synth.render_region(4321, 900, 700, 512, 512)])
+    out = eng.run(torch.from_numpy(tiles).to(cuda))
+    fw = onet.make_forward(sd)
+    for i in range(2):
+        dP, cp, yc = tiling.run_net(fw, tiling.normalize_img(tiles[i:i + 1]), batch_size=8)
+        for a, b, name in ((out.dP[i], dP, "dP"), (out.cellprob[i], cp, "cellprob"), (out.logits[i], yc, "logits")):
+            assert _rel(a.cpu(), torch.from_numpy(b)) < 5e-3, name
+        ref = dynamics.compute_masks(out.dP[i].cpu().numpy(), out.cellprob[i].cpu().numpy())
+        assert np.array_equal(ops.masks_to_numpy(out.masks)[i], ref)
+        cm, _ = classmask.compute_class_masks(ref, out.logits[i].cpu().numpy())
+        assert np.array_equal(out.class_masks[i].cpu().numpy(), cm.astype(np.uint8))
+

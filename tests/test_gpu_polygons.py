@@ -1,9 +1,12 @@
-"""GPU: device polygonisation (cpx_polygonize_device, f1) == the host restatement (cpx_polygonize_host), bit for bit."""
+"""GPU: device polygonisation (cpx_polygonize_device, f1) against the CPU oracle (oracle/polygons.py: Suzuki-Abe
+border following in OpenCV's contour order + GEOS ring metrics, predict_wsi.py:601-652) and, bit for bit, against
+the product's host polygoniser (cpx_polygonize_host, itself oracle-checked in tests/test_oracle_polygons.py)."""
 import numpy as np
 import pytest
 import torch
 
 from classpose_amd import engine, postprocess, synth
+from oracle import polygons as opoly
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +36,16 @@ def test_device_polygons_equal_host(cuda, T, nT, scale):
         for a, b in zip(dc, hc):
             assert np.array_equal(xy[a["offset"]: a["offset"] + a["n_pts"]], hxy[b["offset"]: b["offset"] + b["n_pts"]])
         n_seen += len(dc)
+        # the independent oracle: PostProcessor.__call__ restated (valid cells only, label order)
+        cm = out.class_masks[t].cpu().numpy()
+        ref = opoly.post_process_tile(masks[t], cm, origins[t], scale)
+        dv = dc[dc["valid"] == 1]
+        assert len(dv) == len(ref)
+        for a, r in zip(dv, ref):
+            assert np.array_equal(xy[a["offset"]: a["offset"] + a["n_pts"]], r["coords"])
+            assert a["area"] == r["area"] and abs(a["perimeter"] - r["perimeter"]) <= 1e-12 * r["perimeter"]
+            assert abs(a["cx"] - r["centroid_raw"][0]) < 1e-9 and abs(a["cy"] - r["centroid_raw"][1]) < 1e-9
+            assert a["cls"] - 1 == r["class_int"]
     # offsets are an exclusive scan in (tile, record) order and the pool is densely used
     assert np.array_equal(cells["offset"], np.concatenate([[0], np.cumsum(cells["n_pts"])[:-1]]))
     assert len(xy) == int(cells["n_pts"].sum()) and n_seen == len(cells)
@@ -82,3 +95,11 @@ def test_device_polygons_multi_component_and_tiny(cuda):
     assert v1.tolist() == [[30, 20], [30, 23], [35, 23], [35, 20]]            # the second component
     assert by_label[2]["n_pts"] == 1 and by_label[2]["valid"] == 0 and by_label[3]["valid"] == 0
     assert by_label[4]["valid"] == 1 and by_label[4]["n_pts"] >= 8
+    # oracle: every label's contour is OpenCV-order contours[0] of its bbox crop; validity as GEOS decides it
+    for lab, c in by_label.items():
+        ys, xs = np.nonzero(m == lab)
+        cont = opoly.find_contours_external_simple((m == lab)[ys.min(): ys.max() + 1, xs.min(): xs.max() + 1])[0]
+        exp = (cont + [xs.min(), ys.min()]).astype(np.float64)
+        assert np.array_equal(xy[c["offset"]: c["offset"] + c["n_pts"]], exp), lab
+        assert bool(c["valid"]) == opoly.polygon_metrics(exp)["valid"], lab
+
