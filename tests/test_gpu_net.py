@@ -432,3 +432,52 @@ def test_engine_fp16_512px_vs_oracle(cuda):
         cm, _ = classmask.compute_class_masks(ref, out.logits[i].cpu().numpy())
         assert np.array_equal(out.class_masks[i].cpu().numpy(), cm.astype(np.uint8))
 
+
+# ---- vectors minted by the reference's own functions (tests/golden/make_golden_network.py) -----------------
+def _gold_net():
+    import os, sys
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    import make_golden_network as mgn
+    return mgn, np.load(os.path.join(d, "reference_network.npz"))
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("fp16", 3e-3), ("bf16", 1.5e-2)])
+def test_hip_attention_block_equals_reference_flash_forward(cuda, precision, tol):
+    """qkv GEMM -> rel-pos flash attention -> proj GEMM on the device vs the output of the reference's own
+    classpose.vit_sam.flash_forward (vit_sam.py:15-65) on a ViT-L sized attention module"""
+    mgn, gold = _gold_net()
+    dim, heads, hw, rh, rw, B, seed, stride = (int(v) for v in gold["ff_vitl_cfg"])
+    x, p = mgn.attention_case(dim, heads, hw, rh, rw, B, seed)
+    assert mgn.checksum(x) == pytest.approx(float(gold["ff_vitl_xsum"]), rel=1e-12)
+    dt = engine.NET_DTYPES[precision]
+    epi = "f32" if precision == "fp32" else "bf16"
+    dev = lambda t: t.to(dt).to(cuda).contiguous()
+    table = lambda t: dev(torch.cat([engine.interp_rel_pos(t.to(dt)).float() * 8.0, torch.zeros(1, 64)], 0))
+    qkv = ops.gemm(dev(x.reshape(B * hw * hw, dim)), dev(p["qkv.weight"]), epi, p["qkv.bias"].to(dt).float().to(cuda))
+    ao = ops.attention(qkv, table(p["rel_pos_h"]), table(p["rel_pos_w"]))
+    y = ops.gemm(ao, dev(p["proj.weight"]), epi, p["proj.bias"].to(dt).float().to(cuda))
+    got = y.float().reshape(B, hw * hw, dim)[:, ::stride].cpu()
+    ref = torch.from_numpy(gold["ff_vitl_y"])
+    r = _rel(got, ref)
+    print(f"flash_forward golden, {precision}: rel-L2 {r:.3e}, max-abs {float((got - ref).abs().max()):.3e}")
+    assert r < tol
+
+
+def test_hip_tiling_equals_reference_run_net(cuda):
+    """normalise -> pad -> sub-tile (+TTA flips) on the device, the golden's elementwise stand-in network, then
+    un-augment -> taper average -> crop on the device: bit-identical to what the reference's own
+    classpose.core.run_net (core.py:75-231) returned for the same tile"""
+    mgn, gold = _gold_net()
+    for k in range(int(gold["rn_n"])):
+        H, W, aug, ncls, bs, seed = (int(v) for v in gold[f"rn_{k}_cfg"])
+        tile = mgn.run_net_tile(H, W, seed)
+        sub, til = ops.make_subtiles(torch.from_numpy(tile)[None].to(cuda), 256, bool(aug), 0.1)
+        o = mgn.fake_net_outputs(sub.cpu(), ncls)
+        dP, cp, lg = ops.blend_subtiles(o[:, ncls:].contiguous().to(cuda), o[:, :ncls].contiguous().to(cuda), til, 1)
+        yf = torch.cat([dP[0], cp], 0).permute(1, 2, 0).cpu().numpy()
+        assert np.array_equal(yf[::5, ::5], gold[f"rn_{k}_yf"]), k
+        assert np.array_equal(lg[0].permute(1, 2, 0).cpu().numpy()[::5, ::5], gold[f"rn_{k}_ycf"]), k
+        assert np.array_equal(yf[H // 2], gold[f"rn_{k}_yf_row"]), k
+
