@@ -97,6 +97,55 @@ def dedup_indices(centers, sizes, max_dist: float = 15 / 2) -> list[int]:
     return [i for i in range(len(centers)) if i not in to_remove]
 
 
+def dedup_from_pairs(n: int, sizes, pairs: np.ndarray) -> np.ndarray:
+    """Indices kept by ``deduplicate`` (predict_wsi.py:929-965) given the neighbour pairs (i < j) that
+    ``tree.query_pairs`` returns -- here the device radius search (``ops.dedup_pairs``).
+
+    The reference walks ``neighbours`` -- a Python ``set`` of tuples -- in set order and groups greedily, so its
+    result depends on that order whenever a connected component of the pair graph has three or more cells
+    (and on the list order inside a group for equal areas).  This keeps that order: the SAME set is built
+    (same elements -> same hash slots and table size; only entries that collide in the table can sit in a
+    different probe position than with scipy's insertion order), its iteration order is read off once, and the
+    reference's loop runs verbatim over the pairs of the components with >= 3 members.  Components of exactly
+    two cells -- the bulk: one cell seen by two overlapping tiles -- do not depend on any order (group [i, j],
+    ``argmax`` keeps i on equal areas) and are resolved vectorised."""
+    sizes = np.asarray(sizes)
+    keep = np.ones(n, bool)
+    if len(pairs) == 0:
+        return np.flatnonzero(keep)
+    pi, pj = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    deg = np.bincount(pi, minlength=n) + np.bincount(pj, minlength=n)
+    simple = (deg[pi] == 1) & (deg[pj] == 1)
+    si, sj = pi[simple], pj[simple]
+    drop_j = sizes[si] >= sizes[sj]                      # np.argmax([s_i, s_j]) == 0 unless s_j is strictly larger
+    keep[np.where(drop_j, sj, si)] = False
+    if not simple.all():
+        neighbours = set(zip(pi.tolist(), pj.tolist()))
+        complex_pairs = set(zip(pi[~simple].tolist(), pj[~simple].tolist()))
+        ordered = [p for p in neighbours if p in complex_pairs]        # the reference's iteration order, filtered
+        groups: dict[int, list] = {}
+        member_to_group: dict[int, int] = {}
+        for pair in ordered:
+            if pair[0] not in member_to_group and pair[1] not in member_to_group:
+                gi = len(groups)
+                groups[gi] = []
+                member_to_group[pair[0]] = gi
+                member_to_group[pair[1]] = gi
+            else:
+                gi = member_to_group[pair[0]] if pair[0] in member_to_group else member_to_group[pair[1]]
+            if pair[0] not in groups[gi]:
+                groups[gi].append(pair[0])
+            if pair[1] not in groups[gi]:
+                groups[gi].append(pair[1])
+        for group in groups.values():
+            if len(group) > 1:
+                largest = group[int(np.argmax([sizes[i] for i in group]))]
+                for i in group:
+                    if i != largest:
+                        keep[i] = False
+    return np.flatnonzero(keep)
+
+
 def deduplicate(features: list[dict], max_dist: float = 15 / 2) -> list[dict]:
     centers = [[_measure(f, "centroidX"), _measure(f, "centroidY")] for f in features]
     sizes = [_measure(f, "area") for f in features]

@@ -281,3 +281,34 @@ def gemm_ln(A, Wt, epilogue="bf16", bias=None, aux=None, ln_stats=None, ln_colsu
     check(_lib.lib().cpx_gemm_ln(ptr(A), ptr(Wt), M, N, K, EPI[epilogue], ptr(bias), ptr(aux), ptr(out), N,
                                  ptr(ln_stats), ptr(ln_colsum), ptr(st), _stream(dev)), "gemm_ln")
     return (out, st) if want_stats else out
+
+
+# ---- f2 ---------------------------------------------------------------------
+def dedup_pairs(centers: np.ndarray, max_dist: float = 15 / 2, device=None) -> np.ndarray:
+    """``KDTree(centers).query_pairs(max_dist)`` (predict_wsi.py:923-927) as an int32 (P, 2) array of (i, j),
+    i < j, sorted by i: the uniform-grid radius search of ``cpx_dedup_pairs`` on the device.
+    centers: (n, 2) float64 host array (the rounded centroids)."""
+    centers = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, 2)
+    n = len(centers)
+    if n < 2:
+        return np.zeros((0, 2), np.int32)
+    dev = torch.device(device if device is not None else "cuda")
+    cell = 8.0 if max_dist <= 8.0 else float(max_dist)
+    lo, hi = centers.min(0), centers.max(0)
+    x0, y0 = float(np.floor(lo[0])) - cell, float(np.floor(lo[1])) - cell
+    gw, gh = int((hi[0] - x0) // cell) + 2, int((hi[1] - y0) // cell) + 2
+    L = _lib.lib()
+    c = torch.from_numpy(centers).to(dev)
+    nbytes = L.cpx_dedup_pairs_workspace_bytes(n, gw, gh)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    tot = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = _stream(dev)
+    check(L.cpx_dedup_pairs(ptr(c), n, x0, y0, cell, gw, gh, float(max_dist), None, 0, ptr(tot), ptr(ws), nbytes, st),
+          "dedup_pairs(count)")
+    P = int(tot.item())
+    if P == 0:
+        return np.zeros((0, 2), np.int32)
+    pairs = torch.empty((P, 2), dtype=torch.int32, device=dev)
+    check(L.cpx_dedup_pairs(ptr(c), n, x0, y0, cell, gw, gh, float(max_dist), ptr(pairs), P, ptr(tot), ptr(ws), nbytes, st),
+          "dedup_pairs(write)")
+    return pairs.cpu().numpy()

@@ -361,6 +361,22 @@ int cpx_polygonize_device(const uint16_t *masks_u16, const cpx_record *records, 
                           double *xy_pool, int max_pts, cpx_cell *cells, int32_t *n_pts_total,
                           void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------
+ * f2  cross-tile de-duplication: the fixed-radius pair search
+ * replaces KDTree(centers).query_pairs(max_dist) of deduplicate,
+ * /root/reference/src/classpose/entrypoints/predict_wsi.py:923-927 (scipy.spatial.KDTree, p = 2)
+ * ---------------------------------------------------------------------- */
+/* centers_xy [n][2] double (x, y) = the rounded centroids of every cell of the slide.  The pair set
+ * {(i, j), i < j : (xi-xj)^2 + (yi-yj)^2 <= max_dist^2} (double arithmetic, products and sum unfused: exactly
+ * scipy's test) via a uniform grid of `cell` >= max_dist covering [x0, x0 + grid_w*cell) x [y0, y0 + grid_h*cell).
+ * Two calls on the same workspace: pairs == NULL buckets + counts (-> *n_pairs, device int64); then with
+ * pairs [max_pairs][2] int32 writes them sorted by i (deterministic).  The greedy grouping of :929-960 follows
+ * the iteration order of a Python set and stays on the host (classpose_amd.geojson.dedup_from_pairs).   */
+size_t cpx_dedup_pairs_workspace_bytes(int n_points, int grid_w, int grid_h);
+int cpx_dedup_pairs(const double *centers_xy, int n, double x0, double y0, double cell, int grid_w, int grid_h,
+                    double max_dist, int32_t *pairs, long long max_pairs, long long *n_pairs,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_SIMPLE) of the GrandQC class maps
  * (/root/reference/src/classpose/grandqc/wsi_tissue_detection.py:209-213,
  * wsi_artefact_detection.py:262-265), host code.  mask [H][W] uint8, non-zero = foreground.

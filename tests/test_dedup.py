@@ -1,0 +1,134 @@
+"""f2: de-duplication split into the device radius search (cpx_dedup_pairs) and the reference's set-order
+greedy grouping on the host (geojson.dedup_from_pairs); predict_wsi.py:896-965."""
+import numpy as np
+import pytest
+from scipy.spatial import KDTree
+
+from classpose_amd import geojson
+
+
+def _clustered(rng, n_cells, extent, tie_frac=0.3):
+    """centroids as the tile loop produces them: most cells once, some 2x (edge overlaps), some 4x (corner
+    overlaps), a few chains; a share of the copies with EQUAL areas (flow-injection slides), 2-decimal rounding"""
+    base = rng.uniform(0, extent, (n_cells, 2))
+    area = rng.integers(30, 400, n_cells).astype(np.float64)
+    mult = rng.choice([1, 2, 3, 4], n_cells, p=[0.6, 0.25, 0.05, 0.10])
+    pts, sz = [], []
+    for b, a, m in zip(base, area, mult):
+        for k in range(m):
+            pts.append(b + rng.uniform(-2.5, 2.5, 2) * (k > 0))
+            sz.append(a if rng.random() < tie_frac else a + rng.integers(-5, 6))
+    chain = np.array([[extent + 50 + 5.0 * k, 50.0] for k in range(7)])            # A-B-C-... chain, 5 px apart
+    pts += chain.tolist(); sz += [50, 60, 55, 60, 10, 70, 70]
+    order = rng.permutation(len(pts))
+    return np.round(np.asarray(pts)[order], 2), np.asarray(sz, np.float64)[order]
+
+
+def _scipy_pairs(c, r=7.5):
+    p = KDTree(c).query_pairs(r, output_type="ndarray").astype(np.int32)
+    return p[np.lexsort((p[:, 1], p[:, 0]))] if len(p) else p.reshape(0, 2)
+
+
+def test_dedup_from_pairs_equals_reference_loop_golden(golden):
+    """kept ids of the reference's own deduplicate (golden fixture incl. the A-B-C chain)"""
+    _, js = golden
+    pts = np.array(js["geojson"]["points"])
+    pairs = _scipy_pairs(pts[:, :2])
+    assert geojson.dedup_from_pairs(len(pts), pts[:, 2], pairs).tolist() == js["geojson"]["kept_ids"]
+
+
+def _reference_loop(n, sizes, neighbours):
+    """predict_wsi.py:929-960 verbatim over a given pair set"""
+    groups, member_to_group = {}, {}
+    for pair in neighbours:
+        if (pair[0] not in member_to_group) and (pair[1] not in member_to_group):
+            group_idx = len(groups)
+            groups[group_idx] = []
+            member_to_group[pair[0]] = group_idx
+            member_to_group[pair[1]] = group_idx
+        else:
+            group_idx = member_to_group[pair[0]] if pair[0] in member_to_group else member_to_group[pair[1]]
+        if pair[0] not in groups[group_idx]:
+            groups[group_idx].append(pair[0])
+        if pair[1] not in groups[group_idx]:
+            groups[group_idx].append(pair[1])
+    to_remove = {}
+    for k in groups:
+        group = groups[k]
+        if len(group) > 1:
+            largest = group[np.argmax([sizes[i] for i in group])]
+            for i in group:
+                if i != largest and i not in to_remove:
+                    to_remove[i] = True
+    return [i for i in range(n) if i not in to_remove]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_dedup_from_pairs_equals_reference_loop_random(seed):
+    """(1) the hybrid (vectorised 2-cell components + set-order loop on the rest) == the reference's loop run
+    verbatim over the SAME Python set, ties and chains included; (2) against the loop over scipy's own set
+    (geojson.dedup_indices, golden-pinned) the kept ids can differ only inside components of >= 3 cells, where
+    the reference's outcome depends on scipy's insertion order into the hash table (colliding entries iterate in
+    insertion order) -- a property of the reference, not of the radius search"""
+    c, a = _clustered(np.random.default_rng(seed), 3000, 4000.0)
+    pairs = _scipy_pairs(c)
+    got = geojson.dedup_from_pairs(len(c), a, pairs)
+    same_set = set(zip(pairs[:, 0].tolist(), pairs[:, 1].tolist()))
+    assert got.tolist() == _reference_loop(len(c), a.tolist(), same_set)
+    ref = geojson.dedup_indices(c.tolist(), a.tolist())
+    assert 0.55 * len(c) < len(ref) < 0.8 * len(c)
+    diff = set(ref) ^ set(got.tolist())
+    assert len(diff) <= 0.002 * len(c)
+    deg = np.bincount(pairs.ravel(), minlength=len(c))
+    nb = {i: set() for i in diff}
+    for i, j in pairs.tolist():
+        if i in nb: nb[i].add(j)
+        if j in nb: nb[j].add(i)
+    assert all(deg[i] >= 2 or any(deg[j] >= 2 for j in nb[i]) for i in diff)    # never in a 2-cell component
+
+
+def test_dedup_from_pairs_no_pairs_and_empty():
+    assert geojson.dedup_from_pairs(5, np.ones(5), np.zeros((0, 2), np.int32)).tolist() == [0, 1, 2, 3, 4]
+    assert geojson.dedup_from_pairs(0, np.ones(0), np.zeros((0, 2), np.int32)).tolist() == []
+
+
+@pytest.mark.gpu
+def test_device_pairs_equal_kdtree_query_pairs_golden(cuda, golden):
+    from classpose_amd import ops
+    _, js = golden
+    pts = np.array(js["geojson"]["points"])
+    pairs = ops.dedup_pairs(pts[:, :2], 7.5, cuda)
+    assert np.array_equal(pairs, _scipy_pairs(pts[:, :2]))                    # incl. the 7.4 / 7.6 px boundary cases
+    assert geojson.dedup_from_pairs(len(pts), pts[:, 2], pairs).tolist() == js["geojson"]["kept_ids"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cells,extent", [(500, 700.0), (650_000, 40_000.0)])
+def test_device_pairs_equal_kdtree_query_pairs_synthetic(cuda, n_cells, extent):
+    """~10^6 centroids spread like a 40k^2 slide's cell table: identical pair SET, then identical kept ids"""
+    import time
+    from classpose_amd import ops
+    c, a = _clustered(np.random.default_rng(7), n_cells, extent)
+    # exact-radius cases: partners at distance exactly 7.5 (3-4-5 triangle scaled) must be included (<=)
+    c[:2] = [[100.0, 100.0], [104.5, 106.0]]
+    ops.dedup_pairs(c[:1000], 7.5, cuda)                                      # warm-up
+    t0 = time.perf_counter()
+    pairs = ops.dedup_pairs(c, 7.5, cuda)
+    t1 = time.perf_counter()
+    keep = geojson.dedup_from_pairs(len(c), a, pairs)
+    t2 = time.perf_counter()
+    ref = _scipy_pairs(c)
+    assert np.array_equal(pairs, ref)
+    assert (0, 1) in set(map(tuple, pairs[:50].tolist()))
+    print(f"{len(c)} centroids, {len(pairs)} pairs: device search {1e3 * (t1 - t0):.1f} ms incl. H2D/D2H, "
+          f"host grouping {1e3 * (t2 - t1):.1f} ms")
+    if n_cells <= 5000:
+        assert keep.tolist() == geojson.dedup_indices(c.tolist(), a.tolist())
+    else:
+        # the full reference loop over 10^6 points takes seconds; compare on a spatial crop instead
+        m = (c[:, 0] < 3000) & (c[:, 1] < 3000)
+        sub = np.flatnonzero(m)
+        inner = (c[sub, 0] < 2900) & (c[sub, 1] < 2900)                      # away from the crop border
+        ref_keep = set(sub[geojson.dedup_indices(c[sub].tolist(), a[sub].tolist())].tolist())
+        got_keep = set(keep.tolist())
+        assert all((i in ref_keep) == (i in got_keep) for i in sub[inner].tolist())
