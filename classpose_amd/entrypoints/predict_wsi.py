@@ -82,7 +82,7 @@ class TileStream:
     device with hipMemcpyAsync on a side stream, so reads / copies overlap the engine.  ``extra``
     (optional) computes per-tile side inputs in the same pool (flow-injection tests)."""
 
-    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3, extra=None):
+    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3, extra=None, autostart: bool = True):
         self.slide, self.plan, self.idxs, self.nT = slide, plan, list(idxs), nT
         self.dev, self.extra = device, extra
         n_workers = max(2, min(32, (os.cpu_count() or 4) // 2))
@@ -94,7 +94,13 @@ class TileStream:
         self.copy_stream = torch.cuda.Stream(device)
         self.readers = ThreadPoolExecutor(max_workers=n_workers)
         self.t = threading.Thread(target=self._run, daemon=True)
-        self.t.start()
+        if autostart:
+            self.t.start()
+
+    def start(self):
+        """begin reading / copying (``autostart=False``: buffers and threads exist, nothing has been read yet)"""
+        if not self.t.is_alive():
+            self.t.start()
 
     def _submit(self, b):
         chunk = self.idxs[b * self.nT:(b + 1) * self.nT]
