@@ -13,8 +13,8 @@
 // Uniform grid with cell edge >= r: points are bucketed by a deterministic counting sort
 // (atomic histogram -> exclusive scan -> scatter -> per-cell insertion sort by point index), then
 // one thread per point scans the 3 x 3 neighbouring cells twice (count, write) with an exclusive
-// scan between the passes, so the output is compact, sorted by (i, cell, j) and identical from run
-// to run.  HBM-bound integer / double work: every pass is a coalesced sweep over the point arrays,
+// scan between the passes, so the output is compact, sorted lexicographically by (i, j) and identical
+// from run to run.  HBM-bound integer / double work: every pass is a coalesced sweep over the point arrays,
 // the cell table (4 B per 8 x 8 px cell) is touched once per pass.
 #include "cpx_common.h"
 
@@ -155,6 +155,15 @@ __global__ void __launch_bounds__(DD_THR) k_dd_pairs(const double *__restrict__ 
         }
     }
     if (!WRITE) pair_cnt[i] = cnt;
+    else {      // this point's partners sorted by j: the list is then in lexicographic (i, j) order (a handful per point)
+        const long long m = min((long long)cnt, max(max_pairs - w0, 0LL));
+        for (long long a = 1; a < m; ++a) {
+            const int v = pairs[2 * (w0 + a) + 1];
+            long long b = a;
+            while (b > 0 && pairs[2 * (w0 + b - 1) + 1] > v) { pairs[2 * (w0 + b) + 1] = pairs[2 * (w0 + b - 1) + 1]; --b; }
+            pairs[2 * (w0 + b) + 1] = v;
+        }
+    }
 }
 __global__ void k_dd_total(const uint32_t *__restrict__ pair_cnt, const uint32_t *__restrict__ pair_off, int n, long long *__restrict__ total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *total = n > 0 ? (long long)pair_off[n - 1] + pair_cnt[n - 1] : 0;
