@@ -122,11 +122,13 @@ SIGNATURES = {
 _PRIVATE = {
     "cpx_gemm_set_variant": (None, [_i]),
     "cpx_attention_set_trv": (None, [_i]),
+    "cpx_attention_set_variant": (None, [_i]),
     "cpx_follow_set_early_exit": (None, [_i]),
     "cpx_gemm_set_reverse": (None, [_i]),
     "cpx_attention_set_xcd_order": (None, [_i]),
     "cpx_gemm_set_big": (None, [_i]),
     "cpx_attention_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
+    "cpx_attention8_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),
 }

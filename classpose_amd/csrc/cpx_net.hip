@@ -193,7 +193,7 @@ __device__ __forceinline__ int pi_perm(int r) { return (r & ~12) | ((r & 4) << 1
 // TRV: V is read in its natural [token][d] layout straight from the qkv rows and transposed by the LDS read
 // (ds_read_b64_tr_b16) instead of coming pre-transposed from a V^T buffer written by the qkv GEMM
 template <bool F16, bool DBG = false, bool TRV = false>
-__global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short *__restrict__ qkv,
+__global__ void __launch_bounds__(ATT_THREADS, 3) k_attention(const unsigned short *__restrict__ qkv,
                                                            const unsigned short *__restrict__ vT,
                                                            const unsigned short *__restrict__ relh,
                                                            const unsigned short *__restrict__ relw,
@@ -293,7 +293,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
     const uint4 ones_f = r == 0 ? make_uint4(one2, one2, one2, one2) : make_uint4(0, 0, 0, 0);
     float m_run = -1e30f;
     const float cexp = 0.125f * 1.44269504088896340736f;   // softmax scale (64^-0.5) * log2(e)
-    const float RESCALE_THR = 6.0f;                         // defer-max: tolerate p <= 2^6 (exp2 domain)
+    // P is kept HEADROOM octaves below 1 (a uniform factor that cancels in O / l): bf16 has f32's exponent range,
+    // fp16 starts losing mantissa bits below 2^-14, so its headroom is smaller
+    constexpr float HEADROOM = F16 ? 3.0f : 6.0f;
     const int krow = pi_perm(r);                            // key row this lane feeds to the K operand
 
     ATT_STAMP(7);                                      // prologue (Q load, G products, first tiles)
@@ -316,44 +318,50 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
             S = mfma32<F16>(kf, qf[ks], S);
         }
         ATT_FORCE(S[15]); ATT_STAMP(0);                 // gh + K fragment reads + 4 QK MFMAs
-        // online softmax (per lane = per query; the two half-waves hold different keys)
-        float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
+        // online softmax (per lane = per query; the two half-waves hold different keys) without a per-tile max
+        // chain: P is formed against the running reference first and the PACKED words are OR-ed; bit 14 / 30 of
+        // the OR is set iff some p >= 2 (exponent MSB of a non-negative half) or the reference is still -inf.
+        // Only then the exact maximum / rescale runs (wave-uniform branch); it puts the reference HEADROOM
+        // octaves above the true maximum, so it is taken for the first tile and for genuine outliers only.
+        float p[16];
+        unsigned pk[8];
+        const f32x2_t c2 = {cexp, cexp};
+        {
+            const float off = (gh - m_run) * cexp;
+            const f32x2_t off2 = {off, off};
 #pragma unroll
-        for (int i = 3; i < 15; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, S[i]), S[i + 1]);
-        mx = __builtin_fmaxf(mx, S[15]);
-        {   // other half-wave's maximum: one VALU half-swap instead of an LDS bpermute round trip
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __uint_as_float(sw[0])), __uint_as_float(sw[1])) + gh;
+            for (int i = 0; i < 16; i += 2) {
+                f32x2_t sv = {S[i], S[i + 1]};
+                f32x2_t a = sv * c2 + off2;                    // one v_pk_fma_f32
+                p[i] = __builtin_amdgcn_exp2f(a[0]);
+                p[i + 1] = __builtin_amdgcn_exp2f(a[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
         }
-        // deferred rescale: keep the old reference max while the new one is within 2^THR of it
-        if (!__all((mx - m_run) * cexp <= RESCALE_THR)) {
+        ATT_FORCE(__uint_as_float(pk[7])); ATT_STAMP(1);   // fma + exp + pack
+        if (__builtin_expect(__any(((pk[0] | pk[1] | pk[2]) | (pk[3] | pk[4] | pk[5]) | (pk[6] | pk[7])) & 0x40004000u), 0)) {
+            float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, S[i]), S[i + 1]);
+            mx = __builtin_fmaxf(mx, S[15]);
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32)) + gh + HEADROOM / cexp;
             const float m_new = __builtin_fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);
             Lacc[0] *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
             m_run = m_new;
-        }
-        ATT_FORCE(m_run); ATT_STAMP(1);                 // max chain + half swap + vote (+ rescale)
-        const float off = (gh - m_run) * cexp;
-        float p[16];
-        const f32x2_t c2 = {cexp, cexp}, off2 = {off, off};
+            const float off = (gh - m_run) * cexp;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            f32x2_t sv = {S[i], S[i + 1]};
-            f32x2_t a = sv * c2 + off2;                    // one v_pk_fma_f32
-            p[i] = __builtin_amdgcn_exp2f(a[0]);
-            p[i + 1] = __builtin_amdgcn_exp2f(a[1]);
+            for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(S[i] * cexp + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
         }
         // P^T (accumulator layout) -> B operand of the P.V product, natural key order
         uint4 pf[2];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            unsigned u[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) u[jj] = pack2<F16>(p[8 * st + 2 * jj], p[8 * st + 2 * jj + 1]);
-            pf[st] = make_uint4(u[0], u[1], u[2], u[3]);
-        }
+        pf[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        pf[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         ATT_FORCE(__uint_as_float(pf[1].w)); ATT_STAMP(2);   // fma + exp + pack
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -428,7 +436,243 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attention(const unsigned short 
         }
 }
 
+
+// ---------------------------------------------------------------------------
+// flash attention, 8-wave ping-pong layout (the production kernel)
+// ---------------------------------------------------------------------------
+// One workgroup = 512 threads = 8 waves = 8 image rows of queries of one (sub-tile, head); two waves
+// per SIMD.  Every wave runs the same software-pipelined loop over the 32 key tiles (image rows)
+//     V-phase(t):  softmax of tile t from S (VALU: scale+offset, exp2, row sum, pack)      | barrier
+//     MM-phase(t): O += V_t^T P_t ; S = K_{t+1} Q^T + Gw (8 MFMAs) + K/V ring traffic       | barrier
+// and waves 4-7 run ONE barrier interval behind waves 0-3, so that on every SIMD one wave is in
+// its matrix phase while its partner is in its vector phase (MI355X_MICROARCH "Two waves per
+// SIMD": the matrix pipe and the VALU issue of a SIMD are shared by its two waves; complementary
+// segments are what nets).  K / V^T tiles go through a 4-slot LDS ring: each thread loads 16 bytes
+// of tile t+4 in MM(t) and writes the 16 bytes of tile t+2 it loaded two iterations earlier (a slot is
+// rewritten >= 2 barriers after its last read, and read >= 1 barrier after its last write).
+// Softmax without a per-tile max chain: P is formed against the running reference maximum and the
+// PACKED half-precision words are OR-ed together; bit 14 / 30 of the OR is set iff some p >= 2 (or
+// the reference is still -inf), and only then the exact maximum / rescale path runs (wave-uniform
+// branch); that path puts the reference HEADROOM octaves above the true maximum, so it is taken for
+// the first tile and for genuine outliers only.  Row sums are f32 VALU adds in the vector phase (the matrix phase is the longer one here).
+#define A8_THREADS 512
+#define A8_SLOT_BYTES 8192              // K tile (32 keys x 64 d) + V^T tile (64 d x 32 keys), halves
+#define A8_STAMP(i)                                                                            \
+    do {                                                                                       \
+        if constexpr (DBG) {                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            seg[i] += (unsigned)(t_ - tprev);                                                  \
+            tprev = t_;                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    } while (0)
+template <bool F16, bool DBG = false>
+__global__ void __launch_bounds__(A8_THREADS, 2) k_attention8(const unsigned short *__restrict__ qkv,
+                                                              const unsigned short *__restrict__ vT,
+                                                              const unsigned short *__restrict__ relh,
+                                                              const unsigned short *__restrict__ relw,
+                                                              unsigned short *__restrict__ out, int xcd_order,
+                                                              unsigned *__restrict__ dbg = nullptr) {
+    unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0, tstart = 0;
+    if constexpr (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory"); tprev = tstart; }
+    __shared__ __attribute__((aligned(16))) unsigned short sKV[4 * A8_SLOT_BYTES / 2];
+    __shared__ float sG[8][32 * GS_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    // the 4 workgroups of one (sub-tile, head) pair stream the same 256 KB of K / V^T: same XCD (lin % 8)
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    int rg = blockIdx.x, head = blockIdx.y, s = blockIdx.z;
+    if (xcd_order) {
+        const int j = lin >> 3, pair = (j >> 2) * 8 + (lin & 7);
+        rg = j & 3; head = pair & 15; s = pair >> 4;
+    }
+    const int qh = rg * 8 + wave;
+    const size_t tok0 = (size_t)s * 1024;
+    const unsigned short *qrow = qkv + (tok0 + qh * 32 + r) * 3072 + head * 64;
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(qrow + 16 * ks + 8 * h2);
+
+    // K / V^T ring staging: threads 0..255 move K chunks (key = tid>>3, chunk = tid&7), 256..511 V^T chunks
+    const bool is_k = tid < 256;
+    const int t2 = tid & 255;
+    const int k_key = t2 >> 3, k_c = t2 & 7, v_d = t2 >> 2, v_c = t2 & 3;
+    const unsigned short *gsrc = is_k ? qkv + (tok0 + k_key) * 3072 + 1024 + head * 64 + k_c * 8
+                                      : vT + (((size_t)s * 16 + head) * 64 + v_d) * 1024 + v_c * 8;
+    const size_t gstep = is_k ? (size_t)32 * 3072 : 32;
+    const int sdst = is_k ? k_key * 64 + ((k_c ^ (k_key & 7)) * 8) : 2048 + v_d * 32 + ((v_c ^ ((v_d >> 2) & 3)) * 8);
+    const uint4 st0 = *reinterpret_cast<const uint4 *>(gsrc);
+    const uint4 st1 = *reinterpret_cast<const uint4 *>(gsrc + gstep);
+    // staged registers: at the top of iteration kh, st_a / st_b (kh even / odd) holds tile kh + 2, loaded two iterations ago
+    uint4 st_a = *reinterpret_cast<const uint4 *>(gsrc + 2 * gstep);
+    uint4 st_b = *reinterpret_cast<const uint4 *>(gsrc + 3 * gstep);
+
+    // G = Q . table^T (tables hold rel_pos / scale, row 63 = 0) -> this wave's LDS scratch [q][j]
+    float *G = sG[wave];
+    auto compute_G = [&](const unsigned short *table) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 tf = *reinterpret_cast<const uint4 *>(table + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+                acc = mfma32<F16>(tf, qf[ks], acc);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) G[r * GS_LD + jb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = acc[i];
+        }
+    };
+    compute_G(relw);
+    f32x16 GW;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) GW[i] = G[r * GS_LD + (r - pi_perm((i & 3) + 8 * (i >> 2) + 4 * h2) + 31)];
+    compute_G(relh);
+
+    *reinterpret_cast<uint4 *>(&sKV[0 * (A8_SLOT_BYTES / 2) + sdst]) = st0;
+    *reinterpret_cast<uint4 *>(&sKV[1 * (A8_SLOT_BYTES / 2) + sdst]) = st1;
+    __syncthreads();
+
+    const int krow = pi_perm(r);
+    auto qk = [&](const int slot) {          // S'^T = K . Q^T + Gw for the tile in ring slot `slot`
+        const unsigned short *kb = &sKV[slot * (A8_SLOT_BYTES / 2) + krow * 64];
+        f32x16 S = mfma32<F16>(*reinterpret_cast<const uint4 *>(kb + ((h2 ^ (krow & 7)) * 8)), qf[0], GW);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks)
+            S = mfma32<F16>(*reinterpret_cast<const uint4 *>(kb + (((2 * ks + h2) ^ (krow & 7)) * 8)), qf[ks], S);
+        return S;
+    };
+    f32x16 S = qk(0);
+    f32x16 O0, O1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O0[i] = 0.f; O1[i] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    const float cexp = 0.125f * 1.44269504088896340736f;   // softmax scale (64^-0.5) * log2(e)
+    const f32x2_t c2 = {cexp, cexp};
+    // P is kept a few octaves below 1 (a uniform factor that cancels in O / l): bf16 has f32's exponent range,
+    // fp16 starts losing mantissa bits below 2^-14, so its headroom is smaller
+    constexpr float HEADROOM = F16 ? 3.0f : 6.0f;
+
+    A8_STAMP(7);                                            // prologue
+    if (wave >= 4) __builtin_amdgcn_s_barrier();            // waves 4-7 run one barrier interval behind
+    A8_STAMP(6);
+
+    // one key tile: kh = tile index, SLOT = kh & 3 (static)
+    auto tile = [&](const int kh, auto slot_tag, uint4 &st) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        // ---- vector phase: softmax of tile kh
+        const float gh = G[r * GS_LD + (qh - kh + 31)];
+        unsigned pk[8];
+        float p[16];
+        {
+            const float off = (gh - m_run) * cexp;
+            const f32x2_t off2 = {off, off};
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2_t sv = {S[i], S[i + 1]};
+                const f32x2_t a = sv * c2 + off2;
+                p[i] = __builtin_amdgcn_exp2f(a[0]);
+                p[i + 1] = __builtin_amdgcn_exp2f(a[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
+        }
+        // some p >= 2 (bit 14 of a half = exponent MSB; p is never negative) or the reference is still -inf?
+        const unsigned big = F16 ? 0x40004000u : 0x40004000u;
+        if (__builtin_expect(__any(((pk[0] | pk[1] | pk[2]) | (pk[3] | pk[4] | pk[5]) | (pk[6] | pk[7])) & big), 0)) {
+            float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, S[i]), S[i + 1]);
+            mx = __builtin_fmaxf(mx, S[15]);
+            // new reference = (true maximum so far) + HEADROOM octaves: P stays <= 2^-HEADROOM until a score beats
+            // the old maximum by more than HEADROOM + 1 octaves, so this branch is rare (first tile, true outliers)
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32)) + gh + HEADROOM / cexp;
+            const float m_new = __builtin_fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+            const float off = (gh - m_run) * cexp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(S[i] * cexp + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
+        }
+        {
+            float a0 = (p[0] + p[1]) + (p[2] + p[3]), a1 = (p[4] + p[5]) + (p[6] + p[7]);
+            float a2 = (p[8] + p[9]) + (p[10] + p[11]), a3 = (p[12] + p[13]) + (p[14] + p[15]);
+            l_run += (a0 + a1) + (a2 + a3);
+        }
+        const uint4 pf0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), pf1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        if constexpr (DBG) { asm volatile("" ::"v"(pf0.x), "v"(pf1.w), "v"(l_run)); }
+        A8_STAMP(0);                                        // vector phase
+        __builtin_amdgcn_s_barrier();
+        A8_STAMP(1);                                        // wait at the first barrier
+        // ---- matrix phase: ring traffic, O += V_kh^T P, S = K_{kh+1} Q^T + Gw
+        if (kh + 2 < 32) *reinterpret_cast<uint4 *>(&sKV[((SLOT + 2) & 3) * (A8_SLOT_BYTES / 2) + sdst]) = st;     // tile kh + 2
+        if (kh + 4 < 32) st = *reinterpret_cast<const uint4 *>(gsrc + (size_t)(kh + 4) * gstep);                   // two iterations to land
+        {
+            const unsigned short *vb = &sKV[SLOT * (A8_SLOT_BYTES / 2) + 2048];
+            const int d0 = r, d1 = 32 + r;
+            const uint4 v00 = *reinterpret_cast<const uint4 *>(vb + d0 * 32 + (((0 + h2) ^ ((d0 >> 2) & 3)) * 8));
+            const uint4 v01 = *reinterpret_cast<const uint4 *>(vb + d0 * 32 + (((2 + h2) ^ ((d0 >> 2) & 3)) * 8));
+            const uint4 v10 = *reinterpret_cast<const uint4 *>(vb + d1 * 32 + (((0 + h2) ^ ((d1 >> 2) & 3)) * 8));
+            const uint4 v11 = *reinterpret_cast<const uint4 *>(vb + d1 * 32 + (((2 + h2) ^ ((d1 >> 2) & 3)) * 8));
+            O0 = mfma32<F16>(v00, pf0, O0);
+            O1 = mfma32<F16>(v10, pf0, O1);
+            O0 = mfma32<F16>(v01, pf1, O0);
+            O1 = mfma32<F16>(v11, pf1, O1);
+        }
+        if (kh + 1 < 32) S = qk((SLOT + 1) & 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this thread's ring write has landed
+        if constexpr (DBG) { asm volatile("" ::"v"(S[15]), "v"(O0[15]), "v"(O1[15])); }
+        A8_STAMP(2);                                        // matrix phase
+        __builtin_amdgcn_s_barrier();
+        A8_STAMP(3);                                        // wait at the second barrier
+    };
+    using std::integral_constant;
+    for (int kh0 = 0; kh0 < 32; kh0 += 4) {
+        tile(kh0 + 0, integral_constant<int, 0>{}, st_a);
+        tile(kh0 + 1, integral_constant<int, 1>{}, st_b);
+        tile(kh0 + 2, integral_constant<int, 2>{}, st_a);
+        tile(kh0 + 3, integral_constant<int, 3>{}, st_b);
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();             // re-balance the barrier count of the two wave groups
+    if constexpr (DBG) {
+        unsigned long long tend;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
+        if (lane == 0) {
+            unsigned *d = dbg + ((size_t)lin * 8 + wave) * 9;
+            for (int i = 0; i < 8; ++i) d[i] = seg[i];
+            d[8] = (unsigned)(tend - tstart);
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    unsigned short *orow = out + (tok0 + qh * 32 + r) * 1024 + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = db * 32 + 8 * g4 + 4 * h2;
+            const f32x16 &O = db ? O1 : O0;
+            uint2 o;
+            o.x = pack2<F16>(O[4 * g4 + 0] * inv, O[4 * g4 + 1] * inv);
+            o.y = pack2<F16>(O[4 * g4 + 2] * inv, O[4 * g4 + 3] * inv);
+            *reinterpret_cast<uint2 *>(orow + d) = o;
+        }
+}
+
 static int g_att_xcd = 1;          // XCD-aware workgroup order (debug / A-B switch)
+static int g_att_v8 = 0;           // 0: 4-wave kernel, 3 workgroups per CU (production: faster in one-process A/B); 1: the 8-wave ping-pong experiment
+extern "C" void cpx_attention_set_variant(int v8) { g_att_v8 = v8; }
 extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 // experiment switch (default off): V read from the qkv rows through ds_read_b64_tr_b16, no V^T buffer and a plain
 // qkv epilogue.  Bitwise identical outputs; the whole engine step measured 24.57 vs 24.44 ms (one-process A/B,
@@ -445,6 +689,18 @@ extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const voi
     hipLaunchKernelGGL((k_attention<false, true>), dim3(8, 16, n_subtiles), dim3(ATT_THREADS), 0, s,
                        (const unsigned short *)qkv, (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
                        (const unsigned short *)rel_w, (unsigned short *)out, dbg, g_att_xcd);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+// diagnostic build of the 8-wave kernel: dbg [n_subtiles*16*4 blocks][8 waves][9] cycle sums
+extern "C" int cpx_attention8_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
+                       (const unsigned short *)qkv, (unsigned short *)vT_ws);
+    hipLaunchKernelGGL((k_attention8<false, true>), dim3(4, 16, n_subtiles), dim3(A8_THREADS), 0, s,
+                       (const unsigned short *)qkv, (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
+                       (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd, dbg);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -467,6 +723,17 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
     if (transpose_v && !g_att_trv)
         hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
                            (const unsigned short *)qkv, (unsigned short *)vT_ws);
+    if (g_att_v8 && !g_att_trv) {
+        const dim3 grid8(4, 16, n_subtiles);
+        if (dtype == CPX_DT_F16)
+            hipLaunchKernelGGL((k_attention8<true, false>), grid8, dim3(A8_THREADS), 0, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        else
+            hipLaunchKernelGGL((k_attention8<false, false>), grid8, dim3(A8_THREADS), 0, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd, (unsigned *)nullptr);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
     dim3 grid(8, 16, n_subtiles);
 #define ATT_LAUNCH(F16_, TRV_)                                                                              \
     hipLaunchKernelGGL((k_attention<F16_, false, TRV_>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv, \

@@ -97,18 +97,63 @@ def dedup_indices(centers, sizes, max_dist: float = 15 / 2) -> list[int]:
     return [i for i in range(len(centers)) if i not in to_remove]
 
 
+_XXP1, _XXP2, _XXP5 = np.uint64(11400714785074694791), np.uint64(14029467366897019727), np.uint64(2870177450012600261)
+
+
+def _tuple2_hash(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """CPython >= 3.8 ``hash((a, b))`` for non-negative ints below 2**61 - 1 (tupleobject.c, xxHash-style), vectorised."""
+    with np.errstate(over="ignore"):
+        acc = np.full(a.shape, _XXP5, np.uint64)
+        for lane in (a.astype(np.uint64), b.astype(np.uint64)):
+            acc = acc + lane * _XXP2
+            acc = (acc << np.uint64(31)) | (acc >> np.uint64(33))
+            acc = acc * _XXP1
+        acc = acc + (np.uint64(2) ^ (_XXP5 ^ np.uint64(3527539)))
+    return acc
+
+
+def _set_table_mask(n: int) -> int:
+    """mask of a CPython ``set`` after n distinct ``add`` calls (setobject.c: grow when fill*5 >= mask*3, to the
+    first power of two above 4x (2x beyond 50 000) the number of entries)"""
+    mask = 7
+    for used in range(1, n + 1):
+        if used * 5 >= mask * 3:
+            minused = used * 2 if used > 50000 else used * 4
+            size = 8
+            while size <= minused:
+                size <<= 1
+            mask = size - 1
+    return mask
+
+
+def _fast_set_table_mask(n: int) -> int:
+    mask, used = 7, 0
+    while True:
+        # entries at which the next resize happens with the current mask
+        trig = -(-(mask * 3) // 5)
+        if trig > n:
+            return mask
+        used = trig
+        minused = used * 2 if used > 50000 else used * 4
+        size = 8
+        while size <= minused:
+            size <<= 1
+        mask = size - 1
+
+
 def dedup_from_pairs(n: int, sizes, pairs: np.ndarray) -> np.ndarray:
     """Indices kept by ``deduplicate`` (predict_wsi.py:929-965) given the neighbour pairs (i < j) that
     ``tree.query_pairs`` returns -- here the device radius search (``ops.dedup_pairs``).
 
     The reference walks ``neighbours`` -- a Python ``set`` of tuples -- in set order and groups greedily, so its
     result depends on that order whenever a connected component of the pair graph has three or more cells
-    (and on the list order inside a group for equal areas).  This keeps that order: the SAME set is built
-    (same elements -> same hash slots and table size; only entries that collide in the table can sit in a
-    different probe position than with scipy's insertion order), its iteration order is read off once, and the
-    reference's loop runs verbatim over the pairs of the components with >= 3 members.  Components of exactly
-    two cells -- the bulk: one cell seen by two overlapping tiles -- do not depend on any order (group [i, j],
-    ``argmax`` keeps i on equal areas) and are resolved vectorised."""
+    (and on the list order inside a group for equal areas).  Components of exactly two cells -- the bulk: one
+    cell seen by two overlapping tiles -- do not depend on any order (group [i, j], ``argmax`` keeps i on equal
+    areas) and are resolved vectorised.  The pairs of the larger components go through the reference's loop
+    verbatim, visited in the order of their slot in the hash table the reference's set would have
+    (``hash((i, j)) & mask`` with the mask of a set holding ALL pairs): that IS the set's iteration order except
+    for entries displaced by hash collisions, whose position also depends on scipy's insertion order (a property
+    of the reference's set that no pair list can carry)."""
     sizes = np.asarray(sizes)
     keep = np.ones(n, bool)
     if len(pairs) == 0:
@@ -120,9 +165,10 @@ def dedup_from_pairs(n: int, sizes, pairs: np.ndarray) -> np.ndarray:
     drop_j = sizes[si] >= sizes[sj]                      # np.argmax([s_i, s_j]) == 0 unless s_j is strictly larger
     keep[np.where(drop_j, sj, si)] = False
     if not simple.all():
-        neighbours = set(zip(pi.tolist(), pj.tolist()))
-        complex_pairs = set(zip(pi[~simple].tolist(), pj[~simple].tolist()))
-        ordered = [p for p in neighbours if p in complex_pairs]        # the reference's iteration order, filtered
+        ci, cj = pi[~simple], pj[~simple]
+        slot = _tuple2_hash(ci, cj) & np.uint64(_fast_set_table_mask(len(pairs)))
+        order = np.argsort(slot, kind="stable")
+        ordered = list(zip(ci[order].tolist(), cj[order].tolist()))
         groups: dict[int, list] = {}
         member_to_group: dict[int, int] = {}
         for pair in ordered:
@@ -137,9 +183,10 @@ def dedup_from_pairs(n: int, sizes, pairs: np.ndarray) -> np.ndarray:
                 groups[gi].append(pair[0])
             if pair[1] not in groups[gi]:
                 groups[gi].append(pair[1])
+        szl = sizes.tolist() if hasattr(sizes, "tolist") else list(sizes)
         for group in groups.values():
             if len(group) > 1:
-                largest = group[int(np.argmax([sizes[i] for i in group]))]
+                largest = group[int(np.argmax([szl[i] for i in group]))]
                 for i in group:
                     if i != largest:
                         keep[i] = False
