@@ -270,6 +270,9 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         in_flight = None                     # one batch runs on the device while the previous one is collected
         for chunk, tiles_dev, ev, f in stream:
             torch.cuda.current_stream(device).wait_event(ev)
+            # the raw batch was allocated on the copy stream: tell the allocator that this stream reads it too,
+            # or its block could be handed to the next H2D copy while the resize kernel is still reading
+            tiles_dev.record_stream(torch.cuda.current_stream(device))
             tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
             inject = None
             if extra is not None:

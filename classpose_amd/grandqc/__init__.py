@@ -290,23 +290,39 @@ class _Stub:
 
 
 class _StateOnlyUnpickler(pickle.Unpickler):
-    """Resolves torch / collections / builtins normally and every other class to ``_Stub``: a
-    pickled ``nn.Module`` tree (``torch.save(model)``, wsi_artefact_detection.py:124) can be read
-    for its tensors without importing -- or executing -- the packages that defined it."""
-    SAFE_PREFIXES = ("torch", "collections", "numpy", "_codecs")
+    """Reads a pickled ``nn.Module`` tree (``torch.save(model)``, wsi_artefact_detection.py:124) for its tensors
+    only.  ``find_class`` resolves an EXPLICIT allow-list of (module, name) pairs -- the tensor / storage
+    rebuild helpers, dtypes, ``OrderedDict``, the numpy array reconstructors, ``copyreg``'s object
+    constructors and a few value builtins; every other global (smp / timm / torch.nn classes,
+    ``functools.partial``, anything else) becomes an inert ``_Stub`` subclass that only keeps instance state.
+    No attribute lookup (``getattr``), no callable of the defining packages and no whole-module prefix is
+    reachable from the pickle stream."""
+    ALLOWED = {
+        ("collections", "OrderedDict"), ("collections", "defaultdict"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+        ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+        ("torch._utils", "_rebuild_qtensor"), ("torch._tensor", "_rebuild_from_type_v2"),
+        ("torch.nn.parameter", "Parameter"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+        ("torch.serialization", "_get_layout"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode"),
+        ("copyreg", "_reconstructor"), ("copyreg", "__newobj__"),
+    }
     SAFE_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes",
-                     "bytearray", "complex", "slice", "range", "object", "getattr"}
+                     "bytearray", "complex", "slice", "range", "object"}
 
     def find_class(self, module, name):
-        root = module.split(".")[0]
-        if root in self.SAFE_PREFIXES:
+        if (module, name) in self.ALLOWED:
             return super().find_class(module, name)
+        if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+            return super().find_class(module, name)              # torch.FloatStorage ..., torch.float32 ...
         if module == "builtins":
             if name in self.SAFE_BUILTINS:
                 return super().find_class(module, name)
             raise pickle.UnpicklingError(f"refusing builtins.{name} in a model checkpoint")
-        if root in ("copyreg", "functools"):
-            return super().find_class(module, name)
+        if module.split(".")[0] in ("os", "posix", "nt", "subprocess", "sys", "importlib", "runpy", "shutil", "socket"):
+            raise pickle.UnpicklingError(f"refusing {module}.{name} in a model checkpoint")
         return type(name, (_Stub,), {"__module__": module})
 
 
@@ -347,7 +363,9 @@ def load_qc_state_dict(path: str, n_classes: int, seed: int) -> dict:
                                 "manually, see the reference's MODEL_URL_PATH)")
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except Exception as e:
+        grandqc_logger.warning(f"{path} is not a plain state dict ({type(e).__name__}): reading it as a pickled module "
+                               "through the state-only unpickler (allow-listed globals, no package code runs)")
         obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_StatePickle)
     if isinstance(obj, dict):
         sd = obj.get("state_dict", obj)

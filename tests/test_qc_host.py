@@ -204,3 +204,23 @@ def test_map_cells_to_roi_classes_priority():
     assert [len(m[k]) for k in ("Tumour", "Stroma", "Necrosis")] == [2, 1, 0]
     m = outputs.map_cells_to_roi_classes(cells, classes, ["Stroma", "Missing"])
     assert [len(m[k]) for k in ("Tumour", "Stroma", "Necrosis")] == [1, 2, 0]
+
+
+def test_pickle_loader_allow_list_blocks_getattr_chain(tmp_path):
+    """the ADVICE exploit shape: GLOBAL torch.serialization.os -> builtins.getattr -> REDUCE.  Neither a
+    whole-module torch prefix nor getattr is reachable: the first global is an inert stub, the second is refused"""
+    import pickle
+    import pickletools  # noqa: F401
+    payload = (b"\x80\x02cbuiltins\ngetattr\n(ctorch.serialization\nos\nX\x06\x00\x00\x00systemtR(X\x0b\x00\x00\x00echo pwned!tR.")
+    p = tmp_path / "chain.pth"
+    p.write_bytes(payload)
+    with pytest.raises(Exception) as ei:
+        grandqc.load_qc_state_dict(str(p), 2, 0)
+    assert "refusing builtins.getattr" in str(ei.value) or isinstance(ei.value, pickle.UnpicklingError)
+    up = grandqc._StateOnlyUnpickler(__import__("io").BytesIO(b""))
+    stub = up.find_class("torch.serialization", "os")
+    assert issubclass(stub, grandqc._Stub) and stub.__module__ == "torch.serialization"
+    assert issubclass(up.find_class("functools", "partial"), grandqc._Stub)
+    assert issubclass(up.find_class("torch.nn.modules.conv", "Conv2d"), grandqc._Stub)
+    with pytest.raises(pickle.UnpicklingError):
+        up.find_class("os", "system")
