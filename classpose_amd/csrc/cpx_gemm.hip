@@ -628,6 +628,338 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     }
 }
 
+
+// ===========================================================================
+// persistent form of the 256^2 kernel: one workgroup per CU walks its tiles
+// ===========================================================================
+// Same main loop, LDS map and phase schedule as k_gemm256.  What changes is everything around it:
+//   * grid = min(#tiles, #CUs); workgroup b takes the virtual tile ids b, b + grid, b + 2 grid ... (id % 8 is
+//     unchanged, so an XCD still sweeps its own contiguous tile range super-tile by super-tile);
+//   * the epilogue works in two 128-row halves through a 66 KB staging area that lies in the SECOND K-tile
+//     buffer, so the first K-tile buffer is free while it runs: the four half-tile DMAs of the NEXT tile's
+//     K-tile 0 are issued at the start of the epilogue and land under its convert / GELU / store work
+//     instead of being waited for in front of the next main loop (a 256^2 tile's prologue costs 2-4 us of
+//     its ~37 us; fc1 runs 8 tiles per CU);
+//   * the epilogue has no global loads any more: bias and the folded-LayerNorm column sums of the tile's 256
+//     columns are parked in the LDS tail next to the LayerNorm row parameters under the prologue's latency
+//     (hipcc drains every LDS-DMA in flight with vmcnt(0) at the first use of an ordinary load's result);
+//     its barriers are raw s_barriers for the same reason (__syncthreads adds vmcnt(0) while a DMA is in flight).
+// The residual epilogue (its residual rows ARE global loads) and the V^T tiles of the qkv projection (their
+// transposed image needs the whole LDS) keep the un-overlapped order: prefetch after the epilogue.
+#define G2P_STG_OFF G2_BUF                          // staging area = second K-tile buffer + 2 KB
+#define G2P_TAIL G2_LN_OFF                          // 2 KB LayerNorm row params, 1 KB bias, 1 KB column sums
+#define G2P_LDS_BYTES (G2_LN_OFF + 4096)
+template <int EPI, bool F16, int FLAGS>
+__global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
+    constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16;
+    constexpr bool STATS = (FLAGS & G2F_STATS) != 0 && EPI == CPX_EPI_RESID_BF16;
+    constexpr bool DBG = (FLAGS & G2F_DBG) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int K = g.K, nk = K / 64, nblk = g.n_blocks, tiles_m = g.n_blocks / g.tiles_n;
+    auto coords = [&](int v, int &m0_, int &n0_, int &tn_) {
+        const int nxcd = 8, q = nblk / nxcd, r = nblk % nxcd, x = v % nxcd;
+        int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / nxcd;
+        int tile_m, tile_n;
+        if (g.l2_block && (tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
+            const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2;
+            const int rg = grp / cgn, cg = grp - rg * cgn;
+            tile_m = rg * 8 + (w_ >> 2);
+            tile_n = cg * 4 + (w_ & 3);
+        } else {
+            tile_m = bid / g.tiles_n;
+            tile_n = bid - tile_m * g.tiles_n;
+        }
+        if (g.rev_m) tile_m = tiles_m - 1 - tile_m;
+        m0_ = tile_m * 256; n0_ = tile_n * 256; tn_ = tile_n;
+    };
+    const size_t k64 = (size_t)64 * K, k128 = (size_t)128 * K;
+    char *sdst = smem + wave * 1024;
+    auto stage_at = [&](const unsigned short *pX_, const unsigned short *pW_, int which, int t) {
+        const unsigned short *p = (which < 2 ? pX_ : pW_) + (which & 1) * k128 + (size_t)t * 64;
+        char *d = sdst + (t & 1) * G2_BUF + which * G2_HALF;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                         (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p + k64),
+                                         (__attribute__((address_space(3))) void *)(d + 8192), 16, 0, 0);
+    };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    int v = blockIdx.x, m0, n0, tile_n;
+    coords(v, m0, n0, tile_n);
+    bool prefetched = false;                     // K-tile 0 of the current tile already in flight / landed in buffer 0
+    for (;;) {
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < nblk;
+        int m0n = 0, n0n = 0, tile_nn = 0;
+        if (has_next) coords(vn, m0n, n0n, tile_nn);
+        // every lane-dependent constant is re-derived per tile from an opaque copy of the thread id: hoisted out of
+        // the tile loop they would stay live through the epilogue, be spilled, and their scratch reloads (VMEM) would
+        // make hipcc drain the prefetch DMA with vmcnt(0)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, fr = lane & 15, fq = lane >> 4, c16 = tid & 31;
+        const int srow = tid >> 3, kc = (tid & 7) ^ (srow & 7);
+        unsigned xb[2][2], wb[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned sw = (unsigned)(((ks * 4 + fq) ^ (fr & 7)) << 4);
+            xb[0][ks] = lds0 + (wm * 64 + fr) * 128 + sw;
+            wb[0][ks] = lds0 + (wn * 32 + fr) * 128 + sw;
+            xb[1][ks] = xb[0][ks] + G2_BUF;
+            wb[1][ks] = wb[0][ks] + G2_BUF;
+        }
+        const unsigned short *pX = g.A + (size_t)(m0 + srow) * K + kc * 8;
+        const unsigned short *pW = g.W + (size_t)(n0 + srow) * K + kc * 8;
+        auto stage = [&](int which, int t) { stage_at(pX, pW, which, t); };
+        // per-tile vectors, requested BEFORE this tile's DMAs (in-order vmcnt): LayerNorm row statistics by
+        // threads 0..255, bias and column sums of the tile's 256 columns by threads 256..511
+        float4 st_a = make_float4(0.f, 0.f, 0.f, 0.f), st_b = st_a;
+        float bias_v = 0.f, csum_v = 0.f;
+        if (tid < 256) {
+            if (LN_IN) {
+                st_a = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8);
+                st_b = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8 + 4);
+            }
+        } else {
+            if (g.bias) bias_v = g.bias[n0 + tid - 256];
+            if (LN_IN) csum_v = g.ln_colsum[n0 + tid - 256];
+        }
+        auto park_tile_vectors = [&]() {              // first use of the loads above (hipcc waits vmcnt(0) here while a DMA is in flight)
+            if (tid < 256) {
+                if (LN_IN) {
+                    const float inv_k = 1.0f / K;
+                    const float sum = (st_a.x + st_a.z) + (st_b.x + st_b.z), sq = (st_a.y + st_a.w) + (st_b.y + st_b.w);
+                    const float mean = sum * inv_k;
+                    const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-6f);
+                    *reinterpret_cast<float2 *>(smem + G2P_TAIL + tid * 8) = make_float2(rstd, -mean * rstd);
+                }
+            } else {
+                *reinterpret_cast<float *>(smem + G2P_TAIL + 2048 + (tid - 256) * 4) = bias_v;
+                *reinterpret_cast<float *>(smem + G2P_TAIL + 3072 + (tid - 256) * 4) = csum_v;
+            }
+        };
+        if (prefetched) {
+            // K-tile 0 was requested an epilogue ago: consuming the small loads first costs only their own latency,
+            // and K-tile 1's DMAs are issued AFTER that wait so that they are not drained by it
+            park_tile_vectors();
+            if (nk > 1) { stage(0, 1); stage(3, 1); }
+        } else {
+            stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+            if (nk > 1) { stage(0, 1); stage(3, 1); }
+            park_tile_vectors();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G2_BAR();
+        if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
+
+        f32x4 acc[2][2][4][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4 fx[4][2], fw[2][2];
+#define G2_TILE(T, B)                                                                       \
+    {                                                                                       \
+        const int t_ = (T);                                                                 \
+        g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
+        g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                               \
+        if (t_ + 1 < nk) stage(1, t_ + 1);                                                  \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[0][0], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        g2_read_w<1>(fw, wb[B][0], wb[B][1]);                                               \
+        if (t_ + 1 < nk) stage(2, t_ + 1);                                                  \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[0][1], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                               \
+        if (t_ + 2 < nk) stage(0, t_ + 2);                                                  \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[1][1], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
+        if (t_ + 2 < nk) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+        else if (t_ + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+        G2_BAR(); G2_LGKM0();                                                               \
+        g2_mma<F16>(acc[1][0], fx, fw);                                                     \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+    }
+        for (int t = 0; t < nk; t += 2) {
+            G2_TILE(t, 0)
+            G2_TILE(t + 1, 1)
+        }
+#undef G2_TILE
+        if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue
+        const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;
+        const bool main_only = DBG && (g.dbg & 4);
+        bool next_issued = false;
+        const unsigned short *pXn = g.A + (size_t)(m0n + srow) * K + kc * 8;
+        const unsigned short *pWn = g.W + (size_t)(n0n + srow) * K + kc * 8;
+        auto prefetch_next = [&]() {                 // K-tile 0 of the next tile -> buffer 0 (free since K-tile nk - 2)
+            stage_at(pXn, pWn, 0, 0); stage_at(pXn, pWn, 2, 0); stage_at(pXn, pWn, 3, 0); stage_at(pXn, pWn, 1, 0);
+            next_issued = true;
+        };
+        if (main_only) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) asm volatile("" ::"v"(acc[a][b][c][d]));
+        } else if (vt_tile) {
+            // V third of the qkv projection: transposed image [channel][token] over the whole LDS, as in k_gemm256
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int ml = hm * 128 + wm * 64 + mb * 16 + fr;
+                            const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
+                            f32x4 vv = acc[hm][hn][mb][nb];
+                            const float4 b = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 2048 + nl * 4);
+                            if constexpr (LN_IN) {
+                                const float4 cs = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 3072 + nl * 4);
+                                const float2 pr = *reinterpret_cast<const float2 *>(smem + G2P_TAIL + ml * 8);
+                                vv[0] = fmaf(vv[0], pr.x, fmaf(pr.y, cs.x, b.x)); vv[1] = fmaf(vv[1], pr.x, fmaf(pr.y, cs.y, b.y));
+                                vv[2] = fmaf(vv[2], pr.x, fmaf(pr.y, cs.z, b.z)); vv[3] = fmaf(vv[3], pr.x, fmaf(pr.y, cs.w, b.w));
+                            } else {
+                                vv[0] += b.x; vv[1] += b.y; vv[2] += b.z; vv[3] += b.w;
+                            }
+                            // (tail reads above complete before the staging writes below reach the tail: rows < 256)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                *reinterpret_cast<unsigned short *>(smem + (nl + r) * G2_EPI_LD + ml * 2) = to_half<F16>(vv[r]);
+                        }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G2_BAR();
+            unsigned short *vT = (unsigned short *)g.aux;
+            const size_t s_ = (size_t)(m0 >> 10), t0 = (size_t)(m0 & 1023);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 16 + (tid >> 5);
+                const int c = n0 - 2048 + row;
+                uint4 vv = *reinterpret_cast<const uint4 *>(smem + row * G2_EPI_LD + c16 * 16);
+                *reinterpret_cast<uint4 *>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8) = vv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G2_BAR();
+        } else {
+            if constexpr (EPI != CPX_EPI_RESID_BF16) {
+                if (has_next) prefetch_next();       // no global load result is consumed from here to the next tile top
+            }
+            char *stg = smem + G2P_STG_OFF;
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm) {
+                uint4 rres[8];                       // residual rows of this half: requested now, consumed after the LDS pass
+                if constexpr (EPI == CPX_EPI_RESID_BF16) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+                        rres[it] = *reinterpret_cast<const uint4 *>((const unsigned short *)g.aux +
+                                                                    (size_t)(m0 + hm * 128 + it * 16 + (tid >> 5)) * g.ld_out + n0 + c16 * 8);
+                }
+                float ln_rs[4], ln_nm[4];
+                if constexpr (LN_IN) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const float2 pr = *reinterpret_cast<const float2 *>(smem + G2P_TAIL + (hm * 128 + wm * 64 + mb * 16 + fr) * 8);
+                        ln_rs[mb] = pr.x; ln_nm[mb] = pr.y;
+                    }
+                }
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
+                        const float4 b = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 2048 + nl * 4);
+                        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (LN_IN) cs = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 3072 + nl * 4);
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) {
+                            const int mlh = wm * 64 + mb * 16 + fr;          // row inside this half
+                            f32x4 vv = acc[hm][hn][mb][nb];
+                            if constexpr (LN_IN) {
+                                const float nm = ln_nm[mb], rs = ln_rs[mb];
+                                vv[0] = fmaf(vv[0], rs, fmaf(nm, cs.x, b.x)); vv[1] = fmaf(vv[1], rs, fmaf(nm, cs.y, b.y));
+                                vv[2] = fmaf(vv[2], rs, fmaf(nm, cs.z, b.z)); vv[3] = fmaf(vv[3], rs, fmaf(nm, cs.w, b.w));
+                            } else {
+                                vv[0] += b.x; vv[1] += b.y; vv[2] += b.z; vv[3] += b.w;
+                            }
+                            if constexpr (EPI == CPX_EPI_GELU_BF16) {
+                                if (!DBG || !(g.dbg & 2)) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
+                                }
+                            } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
+                            }
+                            uint2 o;
+                            o.x = (unsigned)to_half<F16>(vv[0]) | ((unsigned)to_half<F16>(vv[1]) << 16);
+                            o.y = (unsigned)to_half<F16>(vv[2]) | ((unsigned)to_half<F16>(vv[3]) << 16);
+                            *reinterpret_cast<uint2 *>(stg + mlh * G2_EPI_LD + nl * 2) = o;
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                G2_BAR();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int mlh = it * 16 + (tid >> 5);
+                    uint4 vv = *reinterpret_cast<const uint4 *>(stg + mlh * G2_EPI_LD + c16 * 16);
+                    const int ml = hm * 128 + mlh;
+                    const size_t go = (size_t)(m0 + ml) * g.ld_out + n0 + c16 * 8;
+                    if constexpr (EPI == CPX_EPI_RESID_BF16) {
+                        const uint4 rr = rres[it];
+                        unsigned a[4] = {vv.x, vv.y, vv.z, vv.w}, b[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float lo = from_half<F16>(a[i] & 0xFFFF) + from_half<F16>(b[i] & 0xFFFF);
+                            float hi = from_half<F16>(a[i] >> 16) + from_half<F16>(b[i] >> 16);
+                            a[i] = (unsigned)to_half<F16>(lo) | ((unsigned)to_half<F16>(hi) << 16);
+                        }
+                        vv = make_uint4(a[0], a[1], a[2], a[3]);
+                    }
+                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = vv;
+                    if constexpr (STATS) {
+                        unsigned a[4] = {vv.x, vv.y, vv.z, vv.w};
+                        float sm = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float lo = from_half<F16>(a[i] & 0xFFFF), hi = from_half<F16>(a[i] >> 16);
+                            sm += lo + hi; sq += lo * lo + hi * hi;
+                        }
+                        sm = half_wave_sum(sm); sq = half_wave_sum(sq);
+                        if (c16 == 16)
+                            *reinterpret_cast<float2 *>(g.stats_out + ((size_t)(m0 + ml) * LN_SLOTS + tile_n) * 2) = make_float2(sm, sq);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                G2_BAR();
+            }
+        }
+        if (!has_next) break;
+        prefetched = next_issued;
+        v = vn; m0 = m0n; n0 = n0n; tile_n = tile_nn;
+    }
+}
+
+static int g_gemm_persist = 1;      // 1 = persistent 256^2 kernel (k_gemm256p), 0 = one workgroup per tile (k_gemm256)
+extern "C" void cpx_gemm_set_persistent(int on) { g_gemm_persist = on; }
+
 static int g_gemm_variant = 1;     // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
 extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
 
@@ -645,6 +977,22 @@ extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 
 template <int EPI, bool F16, int FLAGS>
 static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
+    // the qkv projection keeps one workgroup per tile: a third of its tiles (the V^T ones) cannot overlap their
+    // epilogue with the next prefetch and cost more, and a static tile list cannot balance that (measured +3 %)
+    if (g_gemm_persist && EPI != CPX_EPI_QKV_BF16) {
+        static CpxOncePerDevice once_p;
+        static int n_cu = 0;
+        once_p([] {
+            (void)hipFuncSetAttribute((const void *)k_gemm256p<EPI, F16, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2P_LDS_BYTES);
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            n_cu = cus > 0 ? cus : 256;
+        });
+        const int grid = a.n_blocks < n_cu ? a.n_blocks : n_cu;
+        hipLaunchKernelGGL((k_gemm256p<EPI, F16, FLAGS>), dim3(grid), dim3(G2_THREADS), G2P_LDS_BYTES, s, a);
+        return;
+    }
     static CpxOncePerDevice once;
     once([] { (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES); });
     hipLaunchKernelGGL((k_gemm256<EPI, F16, FLAGS>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
