@@ -82,9 +82,13 @@ class TileStream:
     device with hipMemcpyAsync on a side stream, so reads / copies overlap the engine.  ``extra``
     (optional) computes per-tile side inputs in the same pool (flow-injection tests)."""
 
-    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3, extra=None, autostart: bool = True):
+    def __init__(self, slide, plan, idxs, nT, H, W, device, depth: int = 3, extra=None, autostart: bool = True,
+                 gate_at: int | None = None):
         self.slide, self.plan, self.idxs, self.nT = slide, plan, list(idxs), nT
         self.dev, self.extra = device, extra
+        # optional gate: batches >= gate_at are not read (nor copied) before release() -- bench.py times a region that
+        # starts with a warm reader thread but with none of its tiles read ahead
+        self.gate_at, self.gate = gate_at, threading.Event()
         n_workers = max(2, min(32, (os.cpu_count() or 4) // 2))
         self.ahead = max(depth, -(-n_workers // max(nT, 1)))        # batches being decoded at once
         self.q: queue.Queue = queue.Queue(maxsize=depth)
@@ -96,6 +100,9 @@ class TileStream:
         self.t = threading.Thread(target=self._run, daemon=True)
         if autostart:
             self.t.start()
+
+    def release(self):
+        self.gate.set()
 
     def start(self):
         """begin reading / copying (``autostart=False``: buffers and threads exist, nothing has been read yet)"""
@@ -121,6 +128,10 @@ class TileStream:
             nxt = 0
             while nxt < n_batches or pending:
                 while nxt < n_batches and len(pending) < self.ahead:
+                    if self.gate_at is not None and nxt >= self.gate_at and not self.gate.is_set():
+                        if pending:
+                            break                        # hand over what was read before the gate first
+                        self.gate.wait()
                     pending.append(self._submit(nxt))
                     nxt += 1
                 chunk, slot, futs = pending.pop(0)
