@@ -325,17 +325,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention(const unsigned sho
         // octaves above the true maximum, so it is taken for the first tile and for genuine outliers only.
         float p[16];
         unsigned pk[8];
-        const f32x2_t c2 = {cexp, cexp};
         {
+            // scale + offset as 16 single fmas with the scale as a literal (v_fmamk_f32, a VOP2 encoding): measured on
+            // gfx950 (tools/micro/valu_issue.hip) a v_pk_fma_f32 costs ~9.7 issue cycles per wave with three waves
+            // on the SIMD against ~3.7 for v_fma_f32, i.e. the packed form is slower per element
             const float off = (gh - m_run) * cexp;
-            const f32x2_t off2 = {off, off};
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                f32x2_t sv = {S[i], S[i + 1]};
-                f32x2_t a = sv * c2 + off2;                    // one v_pk_fma_f32
-                p[i] = __builtin_amdgcn_exp2f(a[0]);
-                p[i + 1] = __builtin_amdgcn_exp2f(a[1]);
-            }
+            for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], cexp, off));
 #pragma unroll
             for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
         }

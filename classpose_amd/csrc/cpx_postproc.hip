@@ -423,6 +423,45 @@ __global__ void k_init_stats(PPLayout lay, void *ws) {
     WS(int, off_first)[v] = 0x7FFFFFFF;
 }
 
+// one launch for everything a stage needs initialised (was 3-5 k_fill_i32 / k_init_stats / k_zero_f64 launches):
+//   PPI_SCAL  the PP_NSCAL scalars = 0          PPI_STATS  the per-label tables of k_init_stats
+//   PPI_PAD   h1 and M1 (padded frames) = 0     PPI_T      the two fp64 diffusion planes = 0
+//   PPI_CLS   the class-vote table = 0          PPI_NLAB   scalar SC_NLAB = 0 only
+#define PPI_SCAL 1
+#define PPI_STATS 2
+#define PPI_PAD 4
+#define PPI_T 8
+#define PPI_CLS 16
+#define PPI_NLAB 32
+__global__ void k_pp_init(unsigned what, PPLayout lay, void *ws) {
+    const int i = blockIdx.x * NTHR + threadIdx.x;
+    if ((what & PPI_SCAL) && i < PP_NSCAL) WS(int, off_scal)[i] = 0;
+    if ((what & PPI_NLAB) && i == 0) WS(int, off_scal)[SC_NLAB] = 0;
+    if ((what & PPI_STATS) && i < lay.L) {
+        int *bb = WS(int, off_bbox) + 4 * i;
+        bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
+        WS(int, off_cnt)[i] = 0;
+        WS(unsigned long long, off_sumy)[i] = 0;
+        WS(unsigned long long, off_sumx)[i] = 0;
+        WS(unsigned long long, off_d2)[i] = 0xFFFFFFFFFFFFFFFFull;
+        WS(int, off_center)[i] = 0x7FFFFFFF;
+        WS(int, off_flag)[i] = 0;
+        WS(int, off_first)[i] = 0x7FFFFFFF;
+    }
+    if ((what & PPI_PAD) && i < lay.HWp) { WS(int, off_h1)[i] = 0; WS(int, off_M1)[i] = 0; }
+    if ((what & PPI_T) && i < 2 * lay.THW) WS(double, off_T)[i] = 0.0;
+    if ((what & PPI_CLS) && i < lay.L * PP_MAXCLS) WS(int, off_cls)[i] = 0;
+}
+static void pp_init(unsigned what, int nT, const PPLayout &lay, void *ws, hipStream_t s) {
+    int n = 1;
+    if (what & PPI_SCAL) n = n > PP_NSCAL ? n : PP_NSCAL;
+    if (what & PPI_STATS) n = n > lay.L ? n : lay.L;
+    if (what & PPI_PAD) n = n > lay.HWp ? n : lay.HWp;
+    if (what & PPI_T) n = n > 2 * lay.THW ? n : 2 * lay.THW;
+    if (what & PPI_CLS) n = n > lay.L * PP_MAXCLS ? n : lay.L * PP_MAXCLS;
+    hipLaunchKernelGGL(k_pp_init, dim3(cpx_cdiv(n, NTHR), nT), dim3(NTHR), 0, s, what, lay, ws);
+}
+
 __device__ __forceinline__ double center_d2(int y, int x, const int *bb, int n,
                                             unsigned long long sy, unsigned long long sx) {
     // yi, xi are bbox-relative; ymed = yi.mean(), xmed = xi.mean() (exact int sums / n)
@@ -673,7 +712,7 @@ __global__ void k_count_labels(const int32_t *__restrict__ masks, PPLayout lay, 
 
 // counts = unique(masks, return_counts=True)[1][1:]; remove label VALUE (i+1) where
 // counts[i] < min_size  -- positional indexing, reference quirk kept (see oracle).
-// One workgroup per tile (serial prefix over <= L labels, L is small).
+// One workgroup per tile; ranks by a parallel prefix over per-thread label slices.
 __global__ void __launch_bounds__(1024) k_size_filter(int min_size, PPLayout lay, void *ws) {
     __shared__ int s_part[1024];
     const int vmax = min(WS(int, off_scal)[SC_VMAX], lay.L - 1);
@@ -686,12 +725,13 @@ __global__ void __launch_bounds__(1024) k_size_filter(int min_size, PPLayout lay
     for (int v = lo; v <= hi; ++v) c += cnt[v] > 0;
     s_part[threadIdx.x] = c;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; ++i) { int t = s_part[i]; s_part[i] = run; run += t; }
+    for (int o = 1; o < 1024; o <<= 1) {          // inclusive Hillis-Steele scan over the 1024 partial counts
+        const int t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += t;
+        __syncthreads();
     }
-    __syncthreads();
-    int rank = s_part[threadIdx.x];               // #present nonzero labels below lo
+    int rank = s_part[threadIdx.x] - c;           // exclusive: #present nonzero labels below lo
     for (int v = lo; v <= hi; ++v) {
         if (cnt[v] <= 0) continue;
         ++rank;                                    // 1-based rank among present nonzero labels
@@ -997,11 +1037,9 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
 // zero labels flagged? no: shared tail "renumber by first appearance"
 static int pp_renumber(int32_t *masks, int nT, const PPLayout &lay, void *ws, hipStream_t s,
                        bool first_already) {
-    if (!first_already) {
-        hipLaunchKernelGGL(k_fill_i32, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay.off_first, lay.L, 0x7FFFFFFF, lay, ws);
-        hipLaunchKernelGGL(k_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    }
-    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal + sizeof(int) * SC_NLAB, 1, 0, lay, ws);
+    // (`first` was set to INT_MAX by the stage's PPI_STATS init and nothing has written it since)
+    if (!first_already) hipLaunchKernelGGL(k_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    pp_init(PPI_NLAB, nT, lay, ws, s);
     hipLaunchKernelGGL(k_renumber_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, SC_VMAX, lay, ws);
     hipLaunchKernelGGL(k_relabel, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     return CPX_OK;
@@ -1014,10 +1052,7 @@ extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, doubl
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    hipLaunchKernelGGL(k_fill_i32, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay.off_h1, lay.HWp, 0, lay, ws);
-    hipLaunchKernelGGL(k_fill_i32, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay.off_M1, lay.HWp, 0, lay, ws);
-    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
-    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    pp_init(PPI_PAD | PPI_SCAL | PPI_STATS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_hist, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, lay, ws);
     hipLaunchKernelGGL(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_seed_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
@@ -1041,9 +1076,7 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
-    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_zero_f64, dim3(cpx_cdiv(2 * lay.THW, NTHR), nT), dim3(NTHR), 0, s, lay.off_T, 2 * lay.THW, lay, ws);
+    pp_init(PPI_SCAL | PPI_STATS | PPI_T, nT, lay, ws, s);
     hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
@@ -1058,8 +1091,7 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
 
 static void pp_size_filter(int32_t *masks, int nT, int min_size, const PPLayout &lay, void *ws,
                            hipStream_t s) {
-    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
-    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
     hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
@@ -1076,15 +1108,14 @@ extern "C" int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int
     ws = pp_tiles(ws, nT, H, W);
     if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s);
     else {   // labels may be non-contiguous: bbox loop below handles absent labels (slc None)
-        hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
-        hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+        pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
         hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
         hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, lay, ws);
     }
     // find_objects(masks): bbox per label, then fill
     int nlab_saved_slot = SC_NLAB;
     (void)nlab_saved_slot;
-    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    pp_init(PPI_STATS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_copy_to_tmp, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, lay, ws);
@@ -1102,7 +1133,7 @@ extern "C" int cpx_compute_class_masks(const int32_t *masks, const float *logits
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    hipLaunchKernelGGL(k_fill_i32, dim3(cpx_cdiv(lay.L * PP_MAXCLS, NTHR), nT), dim3(NTHR), 0, s, lay.off_cls, lay.L * PP_MAXCLS, 0, lay, ws);
+    pp_init(PPI_CLS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_class_count, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, logits, ncls, lay, ws);
     hipLaunchKernelGGL(k_class_pick, GRID_LAB(lay, nT), dim3(NTHR), 0, s, ncls, lay, ws);
     hipLaunchKernelGGL(k_class_write, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
@@ -1168,8 +1199,7 @@ extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *cl
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     CPX_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * nT, s));
-    hipLaunchKernelGGL(k_fill_i32, dim3(1, nT), dim3(NTHR), 0, s, lay.off_scal, PP_NSCAL, 0, lay, ws);
-    hipLaunchKernelGGL(k_init_stats, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_rec_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks_u16, lay, ws);
     hipLaunchKernelGGL(k_rec_write, GRID_LAB(lay, nT), dim3(NTHR), 0, s, class_masks, max_rec, records, counts, lay, ws);
     CPX_CHECK_LAUNCH();
