@@ -515,6 +515,18 @@ __global__ void k_niter(PPLayout lay, void *ws) {
 // heat diffusion from the centre inside one label (fp64 Jacobi, 9-neighbour mean
 // summed in neighbour order 0..8 then / 9).  One workgroup per (label, tile).
 #define DIFF_LDS_CELLS 3584     // (bh+2)*(bw+2) <= this -> T ping-pong in LDS (56 KB) + flags
+// s / 9.0 correctly rounded without the IEEE division sequence (v_div_scale / v_rcp_f64 / v_div_fmas / v_div_fixup):
+// q = RN(s * c) with c = RN(1/9) is within 1 ulp of s / 9, r = s - 9 q is exact in one fma, and RN(q + r * c) is the
+// correctly rounded quotient (Markstein's FMA division finish; a quotient of two doubles is never a rounding tie).
+// The values here are >= 0 and far from the subnormal range (9^-n_iter).  Bit-identical to torch's mean over the
+// 9 neighbours (sum / 9), which the stage-wise parity tests check.
+__device__ __forceinline__ double div9(double s) {
+    const double c = 1.0 / 9.0;
+    const double q = s * c;
+    const double r = fma(-9.0, q, s);
+    return fma(r, c, q);
+}
+
 __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ masks, PPLayout lay,
                                                   void *ws) {
     __shared__ double sT[2 * DIFF_LDS_CELLS];
@@ -560,7 +572,7 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
                     int q = c + off9[k];
                     if (sL[q]) s = s + To[q];
                 }
-                Tn[c] = s / 9.0;
+                Tn[c] = div9(s);
             }
             __syncthreads();
             cur ^= 1;
@@ -593,7 +605,7 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
                         m[yy * lay.W + xx] == lab)
                         s = s + To[(yy + 1) * lay.TW + xx + 1];
                 }
-                Tn[(gy + 1) * lay.TW + gx + 1] = s / 9.0;
+                Tn[(gy + 1) * lay.TW + gx + 1] = div9(s);
             }
             __threadfence_block();
             __syncthreads();
