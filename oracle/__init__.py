@@ -18,7 +18,14 @@ Parity status
   tests/test_remove_border_instances.py), ``unaugment_class_tiles``
   (transforms/transforms.py:4), ``UNet`` (unet.py:121), ``deduplicate``
   (predict_wsi.py:896), ``SlideLoader._get_coords`` (predict_wsi.py:366),
-  ``to_geojson_polygon`` / ``polygons_to_centroids`` (predict_wsi.py:813,1336).
+  ``to_geojson_polygon`` / ``polygons_to_centroids`` (predict_wsi.py:813,1336),
+  ``calculate_cellular_densities`` (outputs.py), and the Classpose-owned network glue
+  (``tests/golden/make_golden_network.py``): ``flash_forward`` (vit_sam.py:15-65),
+  ``ClassTransformer.forward`` (vit_sam.py:148-197) and ``core.run_net`` / ``_forward``
+  (core.py:51-231) -- called with the oracle's restatements standing in at the boundary
+  to the absent wheels only, so the qkv reshape, SDPA-with-bias semantics, bias einsum,
+  block order, pixel shuffles, channel order / split and the tiling control flow of
+  ``net.py`` / ``tiling.py`` are pinned (tests/test_oracle_network_pins.py).
 * PARITY UNPINNED (no reference test holds a golden value, and the arithmetic
   lives in wheels that are absent from /root/reference and from this image):
   everything restated from ``cellpose==4.0.8`` (uv.lock:352) --
@@ -30,6 +37,8 @@ Parity status
   reference's call bottoms out in a library that IS in this image
   (``torch.nn.functional.grid_sample``, ``np.percentile``, ``scipy.ndimage``),
   the oracle calls that library itself rather than restating it.
+  ``polygons.py`` (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_SIMPLE + shapely ring
+  metrics) is pinned by OpenCV's documented known answers only (tests/test_oracle_polygons.py).
   Also unpinned: ``grandqc.py`` (``smp.UnetPlusPlus("timm-efficientnet-b0")`` of
   segmentation-models-pytorch 0.3.1 / timm 0.4.12, restated from their published layer
   tables; the reference's own test asserts output types only,
