@@ -363,6 +363,7 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
         logger.info(f"Number of cells after filtering: {len(keep)}")
     bx, by = plan.bounds
     total_tissue_area = total_artefact_area = 0
+    art_shown = []                               # artefact polygons in display coordinates (after the bounds shift)
     out = Path(args.output_folder)
     out.mkdir(parents=True, exist_ok=True)
     base = Path(args.slide_path.split("?")[0]).stem if "://" not in args.slide_path else \
@@ -407,6 +408,7 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
             for i, poly in enumerate(art):
                 feats.extend(roi.polygon_to_geojson(poly, id=f"artefact_{i}", object_type="annotation",
                                                     additional_properties={"classification": {"name": "artefact", "color": [255, 0, 0]}}))
+            art_shown = art
             total_artefact_area = sum(a.area for a in art)
             logger.info(f"Total artefact area: {total_artefact_area}")
             with open(out / get_geojson_output_filename("artefact_contours", base), "w") as f:
@@ -417,9 +419,6 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
         dens_labels = labels or ["cell"]
         names = np.array([(labels[int(c) - 1] if labels is not None else "cell") for c in cells["cls"][keep]], dtype=object)
         if plan.roi_class_dict is not None:
-            if args.artefact_detection_model_path:
-                raise NotImplementedError("csv densities per ROI class with artefact detection need polygon "
-                                          "intersection areas (GEOS), which are not restated")
             prio = [c.strip() for c in args.roi_class_priority] if args.roi_class_priority else None
             # polygon centroids (unrounded; the bounds offset is applied like the reference does before this step)
             region = outputs.map_points_to_roi_classes(cells["cx"][keep] - bx, cells["cy"][keep] - by,
@@ -428,7 +427,10 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
                         for k in plan.roi_class_dict}
             df = outputs.calculate_cellular_densities(
                 by_class, {k: sum(p.area for p in v) for k, v in plan.roi_class_dict.items()},
-                {k: 0 for k in plan.roi_class_dict}, plan.mpp[0], plan.mpp[1], dens_labels)
+                # artefact area inside each ROI class: sum of polygon intersection areas (predict_wsi.py:1818-1828)
+                {k: sum(roi.intersection_area(a, p) for a in art_shown for p in v) if args.artefact_detection_model_path else 0
+                 for k, v in plan.roi_class_dict.items()},
+                plan.mpp[0], plan.mpp[1], dens_labels)
         else:
             df = outputs.densities_from_counts("tissue", {l: int((names == l).sum()) for l in dens_labels},
                                                total_tissue_area, total_artefact_area, plan.mpp[0], plan.mpp[1],

@@ -8,8 +8,9 @@ Mirrors ``load_roi_polygons`` (/root/reference/src/classpose/entrypoints/predict
 shapely/GEOS (absent from this image); the predicates it uses -- ``intersects`` between a
 polygon and an axis-aligned square, point ``within`` polygon, chord lengths of axis-parallel
 lines -- are restated here on float64 with the same open/closed conventions (``intersects`` is
-closed, ``within`` excludes the boundary).  ``make_valid`` is NOT restated: an ROI ring that
-self-intersects raises instead of being silently repaired differently from GEOS.
+closed, ``within`` excludes the boundary).  ``make_valid``: a self-intersecting ROI ring is cut into its
+simple loops (``make_valid_polygon``), which is what GEOS' structure-preserving repair yields wherever the
+loops do not overlap each other.
 """
 from __future__ import annotations
 
@@ -269,6 +270,129 @@ def _ring_is_simple(ring: np.ndarray) -> bool:
 
 
 # ---------------------------------------------------------------------------------
+def _edges(poly: "RoiPolygon"):
+    a = np.concatenate([r[:-1] for r in poly.rings])
+    b = np.concatenate([r[1:] for r in poly.rings])
+    keep = a[:, 1] != b[:, 1]                       # horizontal edges carry no area in a y-sweep
+    return a[keep], b[keep]
+
+
+def _chords_length_overlap(ea, eb, y: float) -> float:
+    """length of (A_y intersect B_y) at height y: even-odd x-intervals of both edge sets, merged"""
+    def crossings(e):
+        a, b = e
+        m = (np.minimum(a[:, 1], b[:, 1]) < y) & (y < np.maximum(a[:, 1], b[:, 1]))
+        t = (y - a[m, 1]) / (b[m, 1] - a[m, 1])
+        return np.sort(a[m, 0] + t * (b[m, 0] - a[m, 0]))
+    xa, xb = crossings(ea), crossings(eb)
+    if len(xa) < 2 or len(xb) < 2:
+        return 0.0
+    ia, ib = xa[: len(xa) // 2 * 2].reshape(-1, 2), xb[: len(xb) // 2 * 2].reshape(-1, 2)
+    lo = np.maximum(ia[:, None, 0], ib[None, :, 0])
+    hi = np.minimum(ia[:, None, 1], ib[None, :, 1])
+    return float(np.clip(hi - lo, 0.0, None).sum())
+
+
+def intersection_area(pa: "RoiPolygon", pb: "RoiPolygon") -> float:
+    """``pa.intersection(pb).area`` of shapely (predict_wsi.py:1822-1826: artefact area inside an ROI class)
+    without constructing the intersection: sweep in y over the slabs between consecutive events (vertices of
+    either polygon, crossings of an edge of one with an edge of the other).  Inside a slab no edge starts, ends
+    or crosses, so the overlap length of the two even-odd chord sets is LINEAR in y and its integral is
+    height x (length at mid-height) exactly.  Holes subtract through the even-odd rule."""
+    ax0, ay0, ax1, ay1 = pa.bounds
+    bx0, by0, bx1, by1 = pb.bounds
+    ylo, yhi = max(ay0, by0), min(ay1, by1)
+    if ylo >= yhi or max(ax0, bx0) >= min(ax1, bx1):
+        return 0.0
+    ea, eb = _edges(pa), _edges(pb)
+    ys = [np.array([ylo, yhi])]
+    for r in pa.rings + pb.rings:
+        ys.append(r[:, 1])
+    # edge(A) x edge(B) crossings, vectorised: solve a0 + t (a1 - a0) = b0 + u (b1 - b0)
+    (a0, a1), (b0, b1) = ea, eb
+    if len(a0) and len(b0):
+        da, db = (a1 - a0)[:, None, :], (b1 - b0)[None, :, :]
+        w = (b0[None, :, :] - a0[:, None, :])
+        den = da[..., 0] * db[..., 1] - da[..., 1] * db[..., 0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (w[..., 0] * db[..., 1] - w[..., 1] * db[..., 0]) / den
+            u = (w[..., 0] * da[..., 1] - w[..., 1] * da[..., 0]) / den
+        hit = (den != 0) & (t > 0) & (t < 1) & (u > 0) & (u < 1)
+        if hit.any():
+            ii = np.nonzero(hit)
+            ys.append(a0[ii[0], 1] + t[hit] * (a1[ii[0], 1] - a0[ii[0], 1]))
+    ys = np.unique(np.concatenate(ys))
+    ys = ys[(ys >= ylo) & (ys <= yhi)]
+    area = 0.0
+    for y0, y1 in zip(ys[:-1], ys[1:]):
+        if y1 > y0:
+            area += (y1 - y0) * _chords_length_overlap(ea, eb, 0.5 * (y0 + y1))
+    return area
+
+
+def split_self_intersections(ring: np.ndarray, max_splits: int = 256) -> list[np.ndarray]:
+    """Repair of a self-intersecting ring in the spirit of ``shapely.make_valid(polygon, method="structure")``
+    (predict_wsi.py:1029-1047): the ring is noded at its proper self-crossings and cut into simple closed loops
+    (a bow tie becomes its two triangles), each of which is then a valid polygon of the resulting MultiPolygon.
+    Where loops overlap each other GEOS dissolves them into one area; here they stay separate parts (the point
+    sets agree, a cell in the overlap can then match two parts -- the reference's own behaviour for overlapping
+    ROI polygons, :1290-1305)."""
+    r = np.asarray(ring, dtype=np.float64)[:, :2]
+    if len(r) and np.array_equal(r[0], r[-1]):
+        r = r[:-1]
+    work, out = [r], []
+    while work and max_splits > 0:
+        cur = work.pop()
+        n = len(cur)
+        found = None
+        for i in range(n):
+            a, b = cur[i], cur[(i + 1) % n]
+            for j in range(i + 2, n):
+                if i == 0 and j == n - 1:
+                    continue                                  # neighbours through the closing edge
+                c, d = cur[j], cur[(j + 1) % n]
+                o1, o2, o3, o4 = _orient(a, b, c), _orient(a, b, d), _orient(c, d, a), _orient(c, d, b)
+                if o1 * o2 < 0 and o3 * o4 < 0:               # proper crossing
+                    t = o3 / (o3 - o4)
+                    found = (i, j, a + t * (b - a))
+                    break
+            if found:
+                break
+        if not found:
+            if len(cur) >= 3 and abs(_ring_area(np.concatenate([cur, cur[:1]]))) > 0:
+                out.append(np.concatenate([cur, cur[:1]]))
+            continue
+        i, j, pnt = found
+        max_splits -= 1
+        work.append(np.concatenate([cur[: i + 1], pnt[None], cur[j + 1:]]))      # outer remainder
+        work.append(np.concatenate([pnt[None], cur[i + 1: j + 1]]))              # the loop that was cut off
+    return out
+
+
+def make_valid_polygon(exterior, holes=()) -> list["RoiPolygon"]:
+    """``make_valid`` (predict_wsi.py:1050-1084) for one polygon: a valid polygon comes back as it is, an invalid
+    exterior is cut into its simple loops (see ``split_self_intersections``); holes go to the loop that contains
+    their first vertex, invalid holes are dropped."""
+    try:
+        return [RoiPolygon(exterior, holes)]
+    except ValueError:
+        pass
+    parts = []
+    good_holes = []
+    for h in holes:
+        try:
+            good_holes.append(RoiPolygon(h).exterior)
+        except ValueError:
+            continue
+    for loop in split_self_intersections(exterior):
+        shell = RoiPolygon(loop, validate=False)
+        mine = [h for h in good_holes if shell.contains_point_strict(float(h[0, 0]), float(h[0, 1]))]
+        parts.append(RoiPolygon(loop, mine, validate=False))
+    if not parts:
+        raise ValueError("ROI ring is degenerate (no area)")
+    return parts
+
+
 def load_roi_polygons(roi_geojson_path: str, group_by_class: bool = False):
     """GeoJSON FeatureCollection / feature list / single feature -> list[RoiPolygon] (or None when
     empty); with ``group_by_class`` also ``{classification.name: [polygons]}`` like the reference.
@@ -287,11 +411,11 @@ def load_roi_polygons(roi_geojson_path: str, group_by_class: bool = False):
             continue
         kind, coords = geom.get("type"), geom.get("coordinates")
         if kind == "Polygon":
-            parts = [RoiPolygon(coords[0], coords[1:])]
+            parts = make_valid_polygon(coords[0], coords[1:])
         elif kind == "MultiPolygon":
-            parts = [RoiPolygon(c[0], c[1:]) for c in coords]
+            parts = [p for c in coords for p in make_valid_polygon(c[0], c[1:])]
         elif kind == "LineString":
-            parts = [RoiPolygon(coords)]
+            parts = make_valid_polygon(coords)
         else:
             continue                                           # points etc. are ignored by the reference too
         name = feat.get("properties", {}).get("classification", {}).get("name", "unknown")

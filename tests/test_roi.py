@@ -146,3 +146,61 @@ def test_vectorised_predicates_match_scalar():
                     for r in poly.rings for k in range(len(r) - 1) for j in range(4)) \
             or scalar_locate(poly, x0, y0) >= 0 or (x0 <= poly.exterior[0][0] <= x0 + s and y0 <= poly.exterior[0][1] <= y0 + s)
         assert poly.intersects_square(x0, y0, s) == brute
+
+
+def test_intersection_area_known_answers_and_monte_carlo():
+    """roi.intersection_area = shapely's a.intersection(b).area (predict_wsi.py:1822-1826), by an exact y-sweep"""
+    from classpose_amd.roi import RoiPolygon, intersection_area
+    sq = lambda x0, y0, x1, y1: [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
+    a = RoiPolygon(sq(0, 0, 10, 10))
+    assert intersection_area(a, RoiPolygon(sq(5, 5, 15, 15))) == 25.0
+    assert intersection_area(a, RoiPolygon(sq(10, 0, 20, 10))) == 0.0                # touching edge
+    assert intersection_area(a, RoiPolygon(sq(20, 20, 30, 30))) == 0.0                # disjoint
+    assert intersection_area(a, a) == 100.0
+    assert intersection_area(a, RoiPolygon(sq(2, 2, 4, 4))) == 4.0                    # contained
+    holed = RoiPolygon(sq(0, 0, 10, 10), [sq(3, 3, 7, 7)])
+    assert intersection_area(holed, RoiPolygon(sq(0, 0, 10, 10))) == 84.0
+    assert intersection_area(holed, RoiPolygon(sq(4, 4, 6, 6))) == 0.0               # inside the hole
+    assert intersection_area(holed, RoiPolygon(sq(2, 2, 8, 8))) == 36.0 - 16.0
+    tri = RoiPolygon([[0, 0], [10, 0], [0, 10]])
+    assert abs(intersection_area(tri, RoiPolygon(sq(0, 0, 5, 5))) - 25.0) < 1e-12
+    assert abs(intersection_area(tri, RoiPolygon(sq(4, 4, 10, 10))) - 2.0) < 1e-12    # corner triangle (4,4),(6,4),(4,6)
+    # symmetric, and agrees with a dense point-sampling estimate on ragged polygons
+    rng = np.random.default_rng(3)
+
+    def blob(cx, cy, r, n):
+        th = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rr = r * rng.uniform(0.5, 1.0, n)
+        return RoiPolygon(np.stack([cx + rr * np.cos(th), cy + rr * np.sin(th)], 1))
+    for k in range(4):
+        p, q = blob(50, 50, 40, 23), blob(65 + 5 * k, 55, 35, 31)
+        ia = intersection_area(p, q)
+        assert abs(ia - intersection_area(q, p)) < 1e-9 * max(ia, 1.0)
+        xs, ys = rng.uniform(0, 120, 400_000), rng.uniform(0, 120, 400_000)
+        mc = float((p.contains_points_strict(xs, ys) & q.contains_points_strict(xs, ys)).mean()) * 120 * 120
+        assert abs(ia - mc) < 0.02 * max(mc, 1.0), (ia, mc)
+        assert ia <= min(p.area, q.area) + 1e-9
+
+
+def test_make_valid_splits_self_intersecting_rings(tmp_path):
+    """predict_wsi.make_valid (:1050): a bow tie is repaired into its two triangles instead of raising"""
+    import json
+    from classpose_amd import roi
+    bow = [[0, 0], [10, 10], [10, 0], [0, 10]]
+    parts = roi.make_valid_polygon(bow)
+    assert len(parts) == 2 and sorted(round(p.area, 9) for p in parts) == [25.0, 25.0]
+    assert any(p.contains_point_strict(2, 5) for p in parts) and any(p.contains_point_strict(8, 5) for p in parts)
+    assert not any(p.contains_point_strict(5, 2) for p in parts)
+    sq = roi.make_valid_polygon([[0, 0], [4, 0], [4, 4], [0, 4]], [[[1, 1], [2, 1], [2, 2], [1, 2]]])
+    assert len(sq) == 1 and sq[0].area == 15.0
+    # triple bow tie (four lobes: two triangles, two diamonds) and a hole that lands in the first lobe
+    z = [[0, 0], [4, 4], [8, 0], [12, 4], [12, 0], [8, 4], [4, 0], [0, 4]]
+    parts = roi.make_valid_polygon(z, [[[0.5, 1.5], [1.0, 1.5], [1.0, 2.5], [0.5, 2.5]]])
+    assert len(parts) == 4 and abs(sum(p.area for p in parts) - (4 + 8 + 8 + 4 - 0.5)) < 1e-9
+    assert sum(len(p.holes) for p in parts) == 1
+    f = tmp_path / "roi.geojson"
+    f.write_text(json.dumps({"type": "FeatureCollection", "features": [
+        {"type": "Feature", "geometry": {"type": "Polygon", "coordinates": [bow + [bow[0]]]},
+         "properties": {"classification": {"name": "x"}}}]}))
+    polys, by_class = roi.load_roi_polygons(str(f), group_by_class=True)
+    assert len(polys) == 2 and len(by_class["x"]) == 2
