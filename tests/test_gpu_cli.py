@@ -386,3 +386,46 @@ def test_predict_wsi_cli_puma_grandqc(cuda, tmp_path, monkeypatch):
     got = [f["properties"]["classification"]["name"] for f in cont["features"]]
     ok = d < 1.5
     assert [g for g, k in zip(got, ok) if k] == [names[int(i % np.uint64(9))] for i in ident[idx[ok]]]
+
+
+def test_predict_wsi_cli_roi_class_densities_with_artefacts(cuda, tmp_path, monkeypatch):
+    """--roi_geojson with classified ROIs + tissue + artefact detection + --output_type csv: densities per ROI
+    class over (ROI area - artefact area inside the ROI), the artefact share from polygon intersection areas
+    (predict_wsi.py:1797-1836)"""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_QC_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs = 3000, 2400
+    fold = (0.30 * W, 0.30 * Hs, 0.42 * W, 0.45 * Hs)                       # the analytic artefact rectangle
+    rect = lambda x0, y0, x1, y1: [[x0, y0], [x1, y0], [x1, y1], [x0, y1], [x0, y0]]
+    rois = {"tumour": rect(1000, 700, 1700, 1300),                          # overlaps the fold partially
+            "stroma": rect(1800, 1400, 2300, 1900)}                          # no artefact inside
+    roi_path = tmp_path / "roi.geojson"
+    roi_path.write_text(json.dumps({"type": "FeatureCollection", "features": [
+        {"type": "Feature", "geometry": {"type": "Polygon", "coordinates": [r]},
+         "properties": {"classification": {"name": k}}} for k, r in rois.items()]}))
+    out = tmp_path / "out"
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "conic", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.5&seed=33",
+        "--output_folder", str(out), "--tile_size", "256", "--overlap", "32", "--device", "cuda:0",
+        "--roi_geojson", str(roi_path), "--tissue_detection_model_path", str(tmp_path / "td.pth"),
+        "--artefact_detection_model_path", str(tmp_path / "art.pth"), "--output_type", "csv"])
+    predict_wsi.main(args)
+    import pandas as pd
+    df = pd.read_csv(next(out.glob("*_cell_densities.csv")))
+    assert set(df["region"]) == {"tumour", "stroma"} and len(df) == 12
+    ix0, iy0 = max(fold[0], 1000), max(fold[1], 700)
+    ix1, iy1 = min(fold[2], 1700), min(fold[3], 1300)
+    inter = (ix1 - ix0) * (iy1 - iy0)
+    assert inter > 50000
+    for name, r in rois.items():
+        area = (r[2][0] - r[0][0]) * (r[2][1] - r[0][1])
+        eff = area - (inter if name == "tumour" else 0.0)
+        d = df[df["region"] == name]
+        got_eff = (d["count"] / d["density"]).replace([np.inf, -np.inf], np.nan).dropna() * 1e6 / 0.25    # pixels
+        assert len(got_eff) > 0
+        # the artefact contour follows 1.5 um/px thumbnail pixels (3 level-0 px): a few 1e-3 of the ROI area
+        assert np.allclose(got_eff, eff, rtol=0.01), (name, float(got_eff.iloc[0]), eff)
