@@ -666,8 +666,215 @@ __global__ void __launch_bounds__(A8_THREADS, 2) k_attention8(const unsigned sho
         }
 }
 
+
+// ---------------------------------------------------------------------------
+// flash attention, 4 waves per workgroup, LDS-DMA ring + software-pipelined S (variant 2)
+// ---------------------------------------------------------------------------
+// Same decomposition as k_attention (one wave = one image row of 32 queries, key tiles = image rows, rel-pos bias
+// as MFMA C operand + one scalar per lane, P^T fed to the P.V MFMA from the accumulator registers).  What differs:
+//   * K / V^T tiles reach LDS by LDS-DMA (global_load_lds_dwordx4, swizzle on the SOURCE address, lane-linear
+//     image) into a 4-slot ring, requested three tiles ahead: no staging registers (the register ring of
+//     k_attention holds 32 VGPRs), no ds_write, one raw s_barrier per tile behind a counted vmcnt;
+//   * the freed registers hold a second score tile: S = K_{t+1} Q^T + Gw is issued BEFORE the softmax of tile t,
+//     so the dependent QK^T chain (~330 cycles for a lone wave, profiles/r02_attn4_stamps.txt) runs under the
+//     softmax's VALU work instead of in front of it;
+//   * the per-wave G = Q table^T scratch is kept in fp16 (16.5 KB instead of 33 KB per workgroup), which pays
+//     for the deeper ring at three workgroups per CU; row sums are f32 VALU adds (no ones-row MFMA, no Lacc).
+// Every LDS read inside the loop is inline asm: with a DMA in flight hipcc drains it (vmcnt(0)) in front of
+// ordinary LDS reads of the same array and in front of __syncthreads().
+#define A4_SLOT 8192
+#define A4_G_LD 66
+#define A4_LDS_BYTES (4 * A4_SLOT + 4 * 32 * A4_G_LD * 2)
+template <int OFF>
+__device__ __forceinline__ uint4 a4_read128(unsigned addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <bool F16>
+__global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
+                                                                const unsigned short *__restrict__ vT,
+                                                                const unsigned short *__restrict__ relh,
+                                                                const unsigned short *__restrict__ relw,
+                                                                unsigned short *__restrict__ out, int xcd_order) {
+    extern __shared__ __attribute__((aligned(16))) char a4_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    int rg = blockIdx.x, head = blockIdx.y, s = blockIdx.z;
+    if (xcd_order) {
+        const int j = lin >> 3, pair = (j >> 3) * 8 + (lin & 7);
+        rg = j & 7; head = pair & 15; s = pair >> 4;
+    }
+    const int qh = rg * 4 + wave;
+    const size_t tok0 = (size_t)s * 1024;
+    // ---- ring requests: thread -> 16 bytes of K (key tid>>3, position tid&7) and of V^T (d tid>>2, position tid&3)
+    const int kkey = tid >> 3, vd = tid >> 2;
+    // K image: 16-byte chunk c of key row k sits at position c ^ ((k >> 1) & 7): the 16 rows one ds_read_b128 lane group
+    // touches ({0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} after the key permutation) then fall on 16 distinct
+    // 16-byte slots of the 256-byte bank row (the (k & 7) swizzle of k_attention is 2-way conflicted: rows k and k + 8)
+    const unsigned short *ksrc = qkv + (tok0 + kkey) * 3072 + 1024 + head * 64 + (((tid & 7) ^ ((kkey >> 1) & 7)) * 8);
+    const unsigned short *vsrc = vT + (((size_t)s * 16 + head) * 64 + vd) * 1024 + (((tid & 3) ^ ((vd >> 2) & 3)) * 8);
+    char *dma_dst = a4_smem + wave * 1024;
+    auto issue = [&](int kh) {
+        char *d = dma_dst + (kh & 3) * A4_SLOT;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ksrc + (size_t)kh * 32 * 3072),
+                                         (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc + kh * 32),
+                                         (__attribute__((address_space(3))) void *)(d + 4096), 16, 0, 0);
+    };
+    issue(0); issue(1); issue(2);
+
+    const unsigned short *qrow = qkv + (tok0 + qh * 32 + r) * 3072 + head * 64;
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(qrow + 16 * ks + 8 * h2);
+    // G = Q . table^T -> this wave's fp16 scratch [q][j] (values are bias / scale, |G| < ~60: fp16 keeps 2^-11 relative)
+    _Float16 *G = reinterpret_cast<_Float16 *>(a4_smem + 4 * A4_SLOT) + wave * 32 * A4_G_LD;
+    auto compute_G = [&](const unsigned short *table) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 tf = *reinterpret_cast<const uint4 *>(table + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+                acc = mfma32<F16>(tf, qf[ks], acc);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) G[r * A4_G_LD + jb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = (_Float16)acc[i];
+        }
+    };
+    compute_G(relw);
+    f32x16 GW;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) GW[i] = (float)G[r * A4_G_LD + (r - pi_perm((i & 3) + 8 * (i >> 2) + 4 * h2) + 31)];
+    compute_G(relh);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tiles 0..2 and this wave's G rows have landed
+    __builtin_amdgcn_s_barrier();
+
+    // per-lane LDS byte addresses of the fragments (slot offset added as an immediate)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)a4_smem;
+    const int krow = pi_perm(r);
+    unsigned ka[4], va[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = lds0 + (unsigned)(krow * 128 + (((2 * ks + h2) ^ ((krow >> 1) & 7)) * 16));
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int d = db * 32 + r;
+            va[db * 2 + st] = lds0 + 4096u + (unsigned)(d * 64 + (((2 * st + h2) ^ ((d >> 2) & 3)) * 16));
+        }
+    const unsigned gaddr = lds0 + 4u * A4_SLOT + (unsigned)((wave * 32 * A4_G_LD + r * A4_G_LD + qh + 31) * 2);   // - 2 kh per tile
+
+    auto qk = [&](auto slot_tag) {
+        constexpr int SL = decltype(slot_tag)::value;
+        const uint4 k0 = a4_read128<SL * A4_SLOT>(ka[0]), k1 = a4_read128<SL * A4_SLOT>(ka[1]);
+        const uint4 k2 = a4_read128<SL * A4_SLOT>(ka[2]), k3 = a4_read128<SL * A4_SLOT>(ka[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 S = mfma32<F16>(k0, qf[0], GW);
+        S = mfma32<F16>(k1, qf[1], S);
+        S = mfma32<F16>(k2, qf[2], S);
+        S = mfma32<F16>(k3, qf[3], S);
+        return S;
+    };
+    using std::integral_constant;
+    f32x16 S = qk(integral_constant<int, 0>{});
+    f32x16 O0, O1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O0[i] = 0.f; O1[i] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    const float cexp = 0.125f * 1.44269504088896340736f;
+    constexpr float HEADROOM = F16 ? 3.0f : 6.0f;
+
+    auto tile = [&](const int kh, auto slot_tag, auto next_tag) {
+        constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value;
+        // tile kh + 1 (this thread's part) has landed; after the barrier every part has, and every wave is done with
+        // slot (kh - 1) & 3, which the next request overwrites
+        if (kh < 30) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kh + 3 < 32) issue(kh + 3);
+        unsigned gh_bits;
+        asm volatile("ds_read_u16 %0, %1" : "=v"(gh_bits) : "v"(gaddr - 2u * (unsigned)kh));
+        f32x16 Sn = S;
+        if (kh + 1 < 32) Sn = qk(integral_constant<int, SN>{});          // waits lgkmcnt(0): gh is there too
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float gh = (float)__builtin_bit_cast(_Float16, (unsigned short)gh_bits);
+        float p[16];
+        unsigned pk[8];
+        {
+            const float off = (gh - m_run) * cexp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], cexp, off));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
+        }
+        if (__builtin_expect(__any(((pk[0] | pk[1] | pk[2]) | (pk[3] | pk[4] | pk[5]) | (pk[6] | pk[7])) & 0x40004000u), 0)) {
+            float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, S[i]), S[i + 1]);
+            mx = __builtin_fmaxf(mx, S[15]);
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32)) + gh + HEADROOM / cexp;
+            const float m_new = __builtin_fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+            const float off = (gh - m_run) * cexp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], cexp, off));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
+        }
+        {
+            const float a0 = (p[0] + p[1]) + (p[2] + p[3]), a1 = (p[4] + p[5]) + (p[6] + p[7]);
+            const float a2 = (p[8] + p[9]) + (p[10] + p[11]), a3 = (p[12] + p[13]) + (p[14] + p[15]);
+            l_run += (a0 + a1) + (a2 + a3);
+        }
+        const uint4 pf0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), pf1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        {
+            const uint4 v00 = a4_read128<SL * A4_SLOT>(va[0]), v01 = a4_read128<SL * A4_SLOT>(va[1]);
+            const uint4 v10 = a4_read128<SL * A4_SLOT>(va[2]), v11 = a4_read128<SL * A4_SLOT>(va[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            O0 = mfma32<F16>(v00, pf0, O0);
+            O1 = mfma32<F16>(v10, pf0, O1);
+            O0 = mfma32<F16>(v01, pf1, O0);
+            O1 = mfma32<F16>(v11, pf1, O1);
+        }
+        S = Sn;
+    };
+    for (int kh0 = 0; kh0 < 32; kh0 += 4) {
+        tile(kh0 + 0, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+        tile(kh0 + 1, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+        tile(kh0 + 2, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+        tile(kh0 + 3, integral_constant<int, 3>{}, integral_constant<int, 0>{});
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    unsigned short *orow = out + (tok0 + qh * 32 + r) * 1024 + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = db * 32 + 8 * g4 + 4 * h2;
+            const f32x16 &O = db ? O1 : O0;
+            uint2 o;
+            o.x = pack2<F16>(O[4 * g4 + 0] * inv, O[4 * g4 + 1] * inv);
+            o.y = pack2<F16>(O[4 * g4 + 2] * inv, O[4 * g4 + 3] * inv);
+            *reinterpret_cast<uint2 *>(orow + d) = o;
+        }
+}
+
 static int g_att_xcd = 1;          // XCD-aware workgroup order (debug / A-B switch)
-static int g_att_v8 = 0;           // 0: 4-wave kernel, 3 workgroups per CU (production: faster in one-process A/B); 1: the 8-wave ping-pong experiment
+static int g_att_v8 = 2;           // 2: 4-wave kernel with the LDS-DMA ring and software-pipelined S (production); 0: the first 4-wave kernel
+                                   // (register ring); 1: the 8-wave ping-pong experiment
 extern "C" void cpx_attention_set_variant(int v8) { g_att_v8 = v8; }
 extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 // experiment switch (default off): V read from the qkv rows through ds_read_b64_tr_b16, no V^T buffer and a plain
@@ -719,7 +926,23 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
     if (transpose_v && !g_att_trv)
         hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
                            (const unsigned short *)qkv, (unsigned short *)vT_ws);
-    if (g_att_v8 && !g_att_trv) {
+    if (g_att_v8 == 2 && !g_att_trv) {
+        const dim3 grid4(8, 16, n_subtiles);
+        static CpxOncePerDevice once4;
+        once4([] {
+            (void)hipFuncSetAttribute((const void *)k_attention4p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)k_attention4p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+        });
+        if (dtype == CPX_DT_F16)
+            hipLaunchKernelGGL((k_attention4p<true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        else
+            hipLaunchKernelGGL((k_attention4p<false>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
+    if (g_att_v8 == 1 && !g_att_trv) {
         const dim3 grid8(4, 16, n_subtiles);
         if (dtype == CPX_DT_F16)
             hipLaunchKernelGGL((k_attention8<true, false>), grid8, dim3(A8_THREADS), 0, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,

@@ -481,3 +481,36 @@ def test_hip_tiling_equals_reference_run_net(cuda):
         assert np.array_equal(lg[0].permute(1, 2, 0).cpu().numpy()[::5, ::5], gold[f"rn_{k}_ycf"]), k
         assert np.array_equal(yf[H // 2], gold[f"rn_{k}_yf_row"]), k
 
+
+
+@pytest.mark.parametrize("variant", [2, 0, 1])
+def test_attention_variants_repeatable_and_agree(cuda, variant):
+    """race screen for the hand-synchronised attention kernels (LDS-DMA ring behind counted vmcnt + raw barriers,
+    8-wave ping-pong): 40 launches on 32 sub-tiles under concurrent load must be bitwise identical, every variant
+    within bf16 rounding of the float64 reference"""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    nS = 32
+    qkv = (torch.randn(nS * 1024, 3072, generator=g) * 0.7).to(torch.bfloat16).to(cuda)
+    rel = (torch.randn(64, 64, generator=g) * 0.8).to(torch.bfloat16).to(cuda)
+    rel[63] = 0
+    noise = torch.empty((8192, 8192), device=cuda)
+    side = torch.cuda.Stream(cuda)
+    L.cpx_attention_set_variant(variant)
+    try:
+        first = ops.attention(qkv, rel, rel)
+        for i in range(40):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):               # uneven memory load next to the kernel
+                    noise.normal_()
+            assert torch.equal(ops.attention(qkv, rel, rel), first), (variant, i)
+        side.synchronize()
+    finally:
+        L.cpx_attention_set_variant(2)
+    q, k, v = qkv[:1024].double().reshape(1024, 3, 16, 64).permute(1, 2, 0, 3)
+    idx = (torch.arange(32)[:, None] - torch.arange(32)[None, :] + 31).to(cuda)
+    R = rel.double()[idx] / 8
+    qhw = q.reshape(16, 32, 32, 64)
+    bias = (torch.einsum("nhwc,hkc->nhwk", qhw, R)[..., :, None] + torch.einsum("nhwc,wkc->nhwk", qhw, R)[..., None, :]).reshape(16, 1024, 1024)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125 + bias, -1) @ v).transpose(0, 1).reshape(1024, 1024)
+    assert _rel(first[:1024].double(), ref) < 4e-3
