@@ -21,7 +21,7 @@
 // ---------------------------------------------------------------------------
 struct PPLayout {
     int H, W, HW, Hp, Wp, HWp, L, TW, TH, THW;
-    size_t off_h1, off_M1, off_tmp, off_im, off_T, off_e, off_seed_pos, off_seed_cnt,
+    size_t off_h1, off_M1, off_tmp, off_im, off_fg, off_fgcnt, off_T, off_e, off_seed_pos, off_seed_cnt,
         off_rank, off_cnt, off_first, off_remap, off_flag, off_bbox, off_sumy, off_sumx,
         off_d2, off_center, off_err, off_cls, off_scal, per_tile;
 };
@@ -35,6 +35,7 @@ struct PPLayout {
 #define SC_VMAX 6
 #define PP_MAXCLS 32
 
+#define FG_BLOCK 1024       // k_prep_flow workgroup = one segment of the foreground list
 static PPLayout pp_layout(int H, int W) {
     PPLayout p;
     p.H = H; p.W = W; p.HW = H * W; p.Hp = H + 2 * RPAD; p.Wp = W + 2 * RPAD;
@@ -45,6 +46,8 @@ static PPLayout pp_layout(int H, int W) {
     p.off_M1 = take(sizeof(int) * p.HWp);
     p.off_tmp = take(sizeof(int) * p.HW);
     p.off_im = take(sizeof(float) * 2 * p.THW);      // zero-bordered interleaved flow field [H+2][W+2][dx, dy]
+    p.off_fg = take(sizeof(int) * FG_BLOCK * cpx_cdiv(p.THW, FG_BLOCK));   // foreground pixels, one segment per k_prep_flow block
+    p.off_fgcnt = take(sizeof(int) * cpx_cdiv(p.THW, FG_BLOCK));
     p.off_T = take(sizeof(double) * 2 * p.THW);
     p.off_e = take(sizeof(double) * 2 * p.HW);
     p.off_seed_pos = take(sizeof(int) * p.L);
@@ -88,38 +91,56 @@ extern "C" int cpx_postproc_max_labels(int H, int W) { return H * W / 11 + 2; }
 // flow field of the Euler loop: (dX, dY) * mask / 5 * 2/(size-1), interleaved and zero-bordered by one pixel,
 // so that a bilinear sample is two 16-byte loads (one per row) with no bounds tests -- the loop is bound by
 // the texture-addresser rate of its gathers (8 scalar taps per step before)
-__global__ void k_prep_flow(const float *__restrict__ dP, const float *__restrict__ cp, float thr,
-                            float kx, float ky, PPLayout lay, void *ws) {
-    int c = blockIdx.x * NTHR + threadIdx.x;
-    if (c >= lay.THW) return;
+// The same pass writes p = -1 for background pixels and compacts the foreground pixels (cellprob > thr) of each
+// 1024-cell block into that block's segment of the foreground list (ballot + a 16-entry LDS prefix, no atomics, so
+// the list order is fixed): the Euler loop then runs on dense waves instead of one thread per pixel with ~70 % of the
+// lanes idle for 200 dependent steps (it is VALU-issue bound: every resident wave issues the whole loop).
+__global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict__ dP, const float *__restrict__ cp,
+                                                        float thr, float kx, float ky, int32_t *__restrict__ p_final,
+                                                        float *__restrict__ p_float, PPLayout lay, void *ws) {
+    __shared__ int sW[FG_BLOCK / 64];
+    const int c = blockIdx.x * FG_BLOCK + threadIdx.x;
     size_t t = blockIdx.y;
     const int py = c / lay.TW, px = c - py * lay.TW;
     float2 v = make_float2(0.f, 0.f);
-    if (py >= 1 && py <= lay.H && px >= 1 && px <= lay.W) {
-        const int idx = (py - 1) * lay.W + (px - 1);
-        float m = cp[t * lay.HW + idx] > thr ? 1.0f : 0.0f;
+    bool fg = false;
+    int idx = 0;
+    if (c < lay.THW && py >= 1 && py <= lay.H && px >= 1 && px <= lay.W) {
+        idx = (py - 1) * lay.W + (px - 1);
+        fg = cp[t * lay.HW + idx] > thr;
+        float m = fg ? 1.0f : 0.0f;
         float dy = dP[(t * 2 + 0) * lay.HW + idx];
         float dx = dP[(t * 2 + 1) * lay.HW + idx];
         v.x = __fdiv_rn(dx * m, 5.0f) * kx;               // im[0] = dX
         v.y = __fdiv_rn(dy * m, 5.0f) * ky;               // im[1] = dY
+        if (!fg) {
+            p_final[t * lay.HW + idx] = -1;
+            if (p_float) { p_float[(t * 2) * lay.HW + idx] = -1.f; p_float[(t * 2 + 1) * lay.HW + idx] = -1.f; }
+        }
     }
-    reinterpret_cast<float2 *>(WS(float, off_im))[c] = v;
+    if (c < lay.THW) reinterpret_cast<float2 *>(WS(float, off_im))[c] = v;
+    const unsigned long long bal = __ballot(fg);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sW[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < FG_BLOCK / 64; ++w) { int n = sW[w]; base += w < wave ? n : 0; total += n; }
+    if (fg) WS(int, off_fg)[blockIdx.x * FG_BLOCK + base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+    if (threadIdx.x == 0) WS(int, off_fgcnt)[blockIdx.x] = total;
 }
 
 typedef float flow4 __attribute__((ext_vector_type(4), aligned(8)));
 
-__global__ void k_follow(const float *__restrict__ cp, float thr, int niter, float shx, float shy,
+__global__ void k_follow(int niter, float shx, float shy,
                          float hw, float hh, int32_t *__restrict__ p_final,
                          float *__restrict__ p_float, PPLayout lay, void *ws, int early_exit) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
+    // workgroup b handles entries [256 (b & 3), 256 (b & 3) + 256) of foreground segment b >> 2
+    const int seg = blockIdx.x >> 2, ent = (blockIdx.x & 3) * NTHR + threadIdx.x;
+    if (ent >= WS(int, off_fgcnt)[seg]) return;
+    const int idx = WS(int, off_fg)[seg * FG_BLOCK + ent];
     size_t t = blockIdx.y;
     const int H = lay.H, W = lay.W;
-    if (!(cp[t * lay.HW + idx] > thr)) {
-        p_final[t * lay.HW + idx] = -1;
-        if (p_float) { p_float[(t * 2) * lay.HW + idx] = -1.f; p_float[(t * 2 + 1) * lay.HW + idx] = -1.f; }
-        return;
-    }
     const float *im = WS(float, off_im);
     const int TW = lay.TW;
     int y = idx / W, x = idx - y * W;
@@ -530,7 +551,8 @@ __device__ __forceinline__ double div9(double s) {
 __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ masks, PPLayout lay,
                                                   void *ws) {
     __shared__ double sT[2 * DIFF_LDS_CELLS];
-    __shared__ unsigned char sL[DIFF_LDS_CELLS];
+    __shared__ unsigned short sIdx[DIFF_LDS_CELLS];
+    __shared__ int sN;
     // persistent over labels: a fixed grid of workgroups strides through 1..vmax (k_niter left the largest
     // occupied label in SC_VMAX) instead of one 60 KB-LDS workgroup per POSSIBLE label (L-1 = H*W/11 of them,
     // ~99 % of which exited at once but still had to be dispatched and kept the GEMM workgroups off their CUs)
@@ -550,36 +572,48 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
     double *Tg = WS(double, off_T);                      // [THW] final T (shared by all labels)
     const int off9[9] = {0, -pw, pw, -1, 1, -pw - 1, -pw + 1, pw - 1, pw + 1};
     if (cells <= DIFF_LDS_CELLS) {
+        // Cells outside the label hold 0.0 in both planes for the whole run (only label cells are ever written), and
+        // s + 0.0 == s exactly, so the 9-term sum needs no neighbour flags: the label's cells are compacted once into
+        // sIdx and every iteration is 9 LDS reads + 8 adds + the division per label cell, with ONE barrier (the
+        // reference's `T[centre] += 1` in front of iteration it+1 is applied by the centre's owner when it writes
+        // iteration it's value -- the same addition on the same value).
+        if (threadIdx.x == 0) sN = 0;
         for (int c = threadIdx.x; c < cells; c += NTHR) {
-            int ly = c / pw, lx = c - ly * pw;
-            int gy = y0 + ly - 1, gx = x0 + lx - 1;
-            bool in = ly >= 1 && ly <= bh && lx >= 1 && lx <= bw && m[gy * lay.W + gx] == lab;
-            sL[c] = in;
             sT[c] = 0.0;
             sT[DIFF_LDS_CELLS + c] = 0.0;
         }
         __syncthreads();
+        for (int c = threadIdx.x; c < cells; c += NTHR) {
+            int ly = c / pw, lx = c - ly * pw;
+            int gy = y0 + ly - 1, gx = x0 + lx - 1;
+            if (ly >= 1 && ly <= bh && lx >= 1 && lx <= bw && m[gy * lay.W + gx] == lab)
+                sIdx[atomicAdd(&sN, 1)] = (unsigned short)c;
+        }
+        const int cc = cy * pw + cx;
+        if (threadIdx.x == 0 && niter > 0) sT[cc] = 1.0;
+        __syncthreads();
+        const int nl = sN;
+        const int c0 = (int)threadIdx.x < nl ? (int)sIdx[threadIdx.x] : -1;
         int cur = 0;
         for (int it = 0; it < niter; ++it) {
-            double *To = sT + cur * DIFF_LDS_CELLS, *Tn = sT + (cur ^ 1) * DIFF_LDS_CELLS;
-            if (threadIdx.x == 0) To[cy * pw + cx] += 1.0;
-            __syncthreads();
-            for (int c = threadIdx.x; c < cells; c += NTHR) {
-                if (!sL[c]) continue;
+            const double *To = sT + cur * DIFF_LDS_CELLS;
+            double *Tn = sT + (cur ^ 1) * DIFF_LDS_CELLS;
+            const bool more = it + 1 < niter;
+            for (int j = threadIdx.x; j < nl; j += NTHR) {
+                const int c = j == (int)threadIdx.x ? c0 : (int)sIdx[j];
                 double s = To[c];
 #pragma unroll
-                for (int k = 1; k < 9; ++k) {
-                    int q = c + off9[k];
-                    if (sL[q]) s = s + To[q];
-                }
-                Tn[c] = div9(s);
+                for (int k = 1; k < 9; ++k) s = s + To[c + off9[k]];
+                double v = div9(s);
+                if (c == cc && more) v += 1.0;
+                Tn[c] = v;
             }
             __syncthreads();
             cur ^= 1;
         }
         const double *Tf = sT + cur * DIFF_LDS_CELLS;
-        for (int c = threadIdx.x; c < cells; c += NTHR) {
-            if (!sL[c]) continue;
+        for (int j = threadIdx.x; j < nl; j += NTHR) {
+            const int c = sIdx[j];
             int ly = c / pw, lx = c - ly * pw;
             Tg[(y0 + ly) * lay.TW + (x0 + lx)] = Tf[c];     // padded coords: (gy+1, gx+1)
         }
@@ -1038,8 +1072,8 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
-    hipLaunchKernelGGL(k_prep_flow, dim3(cpx_cdiv(lay.THW, NTHR), nT), dim3(NTHR), 0, s, dP, cellprob, thr, kx, ky, lay, ws);
-    hipLaunchKernelGGL(k_follow, GRID_PIX(lay, nT), dim3(NTHR), 0, s, cellprob, thr, niter,
+    hipLaunchKernelGGL(k_prep_flow, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
+    hipLaunchKernelGGL(k_follow, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
                        (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
                        p_float, lay, ws, g_follow_early);
     CPX_CHECK_LAUNCH();
