@@ -40,7 +40,7 @@ struct GemmArgs {
     void *out;
     int ld_out;
     int tiles_n, n_blocks;
-    int l2_block;           // 1: 8 x 4 super-tile order per XCD (debug switch, default on)
+    int l2_block;           // 1 / 2: 8 x 4 super-tile order per XCD, N-sweep / M-sweep (debug switch, default 1)
     int rev_m;              // 1: walk the M tiles from the last row block to the first (see gemm_launch)
     int dbg;                // timing-only ablations of the 256^2 epilogue (0 in production)
     // LayerNorm folded into the GEMM (consumer side): out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
@@ -358,8 +358,10 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     {
         const int tiles_m = g.n_blocks / g.tiles_n;
         if (g.l2_block && (tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
-            const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2;
-            const int rg = grp / cgn, cg = grp - rg * cgn;
+            const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2, rgn = tiles_m >> 3;
+            // mode 1: column groups innermost (an XCD sweeps N for a fixed band of 8 row tiles); mode 2: row groups
+            // innermost (an XCD keeps ONE 4-tile W panel, 2 MB, and streams the activation rows past it)
+            const int rg = g.l2_block == 2 ? grp % rgn : grp / cgn, cg = g.l2_block == 2 ? grp / rgn : grp - rg * cgn;
             tile_m = rg * 8 + (w_ >> 2);
             tile_n = cg * 4 + (w_ & 3);
         } else {
@@ -663,8 +665,10 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / nxcd;
         int tile_m, tile_n;
         if (g.l2_block && (tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
-            const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2;
-            const int rg = grp / cgn, cg = grp - rg * cgn;
+            const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2, rgn = tiles_m >> 3;
+            // mode 1: column groups innermost (an XCD sweeps N for a fixed band of 8 row tiles); mode 2: row groups
+            // innermost (an XCD keeps ONE 4-tile W panel, 2 MB, and streams the activation rows past it)
+            const int rg = g.l2_block == 2 ? grp % rgn : grp / cgn, cg = g.l2_block == 2 ? grp / rgn : grp - rg * cgn;
             tile_m = rg * 8 + (w_ >> 2);
             tile_n = cg * 4 + (w_ & 3);
         } else {
