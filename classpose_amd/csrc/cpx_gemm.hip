@@ -49,6 +49,9 @@ struct GemmArgs {
     const float *ln_colsum;  // [N]
     // producer side (RESID epilogue of the 256^2 kernel): partial row statistics of the OUTPUT rows
     float *stats_out;        // [M][4][2], slot = column tile; or null
+    // implicit 3x3 convolution (128^2 kernel, CONV instantiation): A is the [S*1024][conv_c] token-major activation of
+    // 32 x 32-token images, K = 9 * conv_c with k = tap * conv_c + c (tap = 3 (dy + 1) + (dx + 1)); 0 = plain GEMM
+    int conv_c;
 };
 #define LN_SLOTS 4
 __device__ __forceinline__ void ln_row_params(const float *st, int m, float inv_k, float &mean, float &rstd) {
@@ -113,16 +116,36 @@ __device__ __forceinline__ float from_half(unsigned short u) {
     else return bf16_to_f32(u);
 }
 
-// stage one 128x64 operand tile (rows row0.., k from k0) into LDS at `lds` (16 KB)
-template <bool GLDS>
+// all-zero 16-byte chunk: the source of the out-of-image taps of the implicit convolution (an LDS-DMA cannot
+// zero-fill, but every lane has its own source address)
+__device__ uint4 g_zero_chunk;
+
+// stage one 128x64 operand tile (rows row0.., k from k0) into LDS at `lds` (16 KB).
+// CONV: the operand is never materialised -- row = token (s, y, x), the 64-wide K tile lies inside ONE tap (conv_c is
+// a multiple of 64), so the chunk comes from token (s, y + dy, x + dx) of the activation or from the zero chunk
+template <bool GLDS, bool CONV = false>
 __device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ g, int ldk, int row0, int k0,
-                                           char *lds, int tid, uint4 *regs) {
+                                           char *lds, int tid, uint4 *regs, int conv_c = 0) {
+    int dy = 0, dx = 0, c0 = 0;
+    if constexpr (CONV) {
+        const int tap = k0 / conv_c;
+        c0 = k0 - tap * conv_c;
+        dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int L = q * GEMM_THREADS + tid;          // linear 16-B chunk index in the LDS image
         int row = L >> 3, pc = L & 7;
         int kc = pc ^ (row & 7);                 // source chunk that belongs at this position
-        const unsigned short *src = g + (size_t)(row0 + row) * ldk + k0 + kc * 8;
+        const unsigned short *src;
+        if constexpr (CONV) {
+            const int m = row0 + row, yy = ((m >> 5) & 31) + dy, xx = (m & 31) + dx;
+            src = ((unsigned)yy < 32u && (unsigned)xx < 32u)
+                      ? g + ((size_t)(m & ~1023) + yy * 32 + xx) * conv_c + c0 + kc * 8
+                      : reinterpret_cast<const unsigned short *>(&g_zero_chunk);
+        } else {
+            src = g + (size_t)(row0 + row) * ldk + k0 + kc * 8;
+        }
         if constexpr (GLDS) {
             // LDS destination = wave-uniform base + lane*16 (hardware); base of this wave's 1 KB slab
             char *base = lds + (q * GEMM_THREADS + (tid & ~63)) * 16;
@@ -138,7 +161,7 @@ __device__ __forceinline__ void write_tile(char *lds, int tid, const uint4 *regs
     for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(lds + (q * GEMM_THREADS + tid) * 16) = regs[q];
 }
 
-template <int EPI, bool F16, bool GLDS>
+template <int EPI, bool F16, bool GLDS, bool CONV = false>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,7 +184,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
 
     uint4 ra[4], rw[4];
     // prologue
-    stage_tile<GLDS>(g.A, g.K, m0, 0, smem, tid, ra);
+    stage_tile<GLDS, CONV>(g.A, g.K, m0, 0, smem, tid, ra, g.conv_c);
     stage_tile<GLDS>(g.W, g.K, n0, 0, smem + TILE_BYTES, tid, rw);
     if constexpr (!GLDS) { write_tile(smem, tid, ra); write_tile(smem + TILE_BYTES, tid, rw); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -192,7 +215,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         // phase B: start the next tile's LDS-DMA; it lands while the MFMAs below run
         if (kt + 1 < nk) {
-            stage_tile<GLDS>(g.A, g.K, m0, (kt + 1) * BK, nxt, tid, ra);
+            stage_tile<GLDS, CONV>(g.A, g.K, m0, (kt + 1) * BK, nxt, tid, ra, g.conv_c);
             stage_tile<GLDS>(g.W, g.K, n0, (kt + 1) * BK, nxt + TILE_BYTES, tid, rw);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1096,6 +1119,7 @@ int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K,
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
     a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg;
     a.rev_m = (g_gemm_rev && K >= 4096) ? 1 : 0;
+    a.conv_c = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s, f16); break;
@@ -1106,6 +1130,36 @@ int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K,
         case CPX_EPI_RELU_BF16: launch_gemm<CPX_EPI_RELU_BF16>(a, s, f16); break;
         case CPX_EPI_QKV_BF16: launch_gemm<CPX_EPI_QKV_BF16>(a, s, f16); break;
         default: CPX_REQUIRE(!"unknown epilogue");
+    }
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+// 3x3 convolution (padding 1, no bias unless given) over 32 x 32-token images as an implicit GEMM on the 128^2 kernel:
+// x [M = S*1024][C] token-major, Wt [N][9*C] with k = tap*C + c, out [M][ld_out]; epilogue CPX_EPI_BF16 or CPX_EPI_RELU_BF16.
+// The im2col operand (9x the activation) is never written: the LDS-DMA of each K tile reads the shifted token's chunk,
+// or a zero chunk outside the image.
+int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C, int epilogue, const float *bias,
+                   void *out, int ld_out, void *stream) {
+    CPX_REQUIRE(x && Wt && out && (dtype == CPX_DT_BF16 || dtype == CPX_DT_F16));
+    CPX_REQUIRE(M > 0 && M % 1024 == 0 && N > 0 && N % BN == 0 && C > 0 && C % BK == 0);
+    CPX_REQUIRE(ld_out >= N && ld_out % 4 == 0 && (epilogue == CPX_EPI_BF16 || epilogue == CPX_EPI_RELU_BF16));
+    GemmArgs a;
+    a.A = (const unsigned short *)x; a.W = (const unsigned short *)Wt;
+    a.M = M; a.N = N; a.K = 9 * C; a.bias = bias; a.aux = nullptr; a.out = out; a.ld_out = ld_out;
+    a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
+    a.ln_stats = nullptr; a.ln_colsum = nullptr; a.stats_out = nullptr; a.l2_block = 0; a.dbg = 0; a.rev_m = 0;
+    a.conv_c = C;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(a.n_blocks), block(GEMM_THREADS);
+    const size_t lds = 2 * STAGE_BYTES;
+    const bool f16 = dtype == CPX_DT_F16;
+    if (epilogue == CPX_EPI_BF16) {
+        if (f16) hipLaunchKernelGGL((k_gemm<CPX_EPI_BF16, true, true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_gemm<CPX_EPI_BF16, false, true, true>), grid, block, lds, s, a);
+    } else {
+        if (f16) hipLaunchKernelGGL((k_gemm<CPX_EPI_RELU_BF16, true, true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_gemm<CPX_EPI_RELU_BF16, false, true, true>), grid, block, lds, s, a);
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;

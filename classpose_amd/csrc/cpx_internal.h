@@ -46,6 +46,8 @@ static inline void cpx_prof_end(CpxProf *p, hipStream_t s) {
 int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K, int epilogue, const float *bias,
                   const void *aux, void *out, int ld_out, const float *ln_stats, const float *ln_colsum,
                   float *stats_out, void *stream);
+int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C, int epilogue, const float *bias,
+                   void *out, int ld_out, void *stream);
 int cpx_row_stats_half(int dtype, const void *x, int rows, float *stats, void *stream);
 int cpx_gemm_half_uses_big_tile(int M, int N, int K, int epilogue);
 int cpx_layernorm_half(int dtype, const void *x, const float *w, const float *b, int rows, int C, float eps,

@@ -1,6 +1,6 @@
 // ClassTransformer forward on gfx950 (vit_sam.py:148-197 + flash_forward :15-65):
 // LayerNorm, global attention with the decomposed relative-position bias fused
-// into the flash loop, 3x3 im2col for the neck, and the launch sequence that
+// into the flash loop, the neck (its 3x3 conv is an implicit GEMM), and the launch sequence that
 // strings them together with the MFMA GEMM of cpx_gemm.hip.
 //
 // Attention design (T = 32x32 tokens, 16 heads x 64):
@@ -966,29 +966,10 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
 }
 
 // ---------------------------------------------------------------------------
-// im2col for the neck's 3x3 conv: [S*1024][256] -> [S*1024][9*256], k = tap*256 + c
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_im2col3(const unsigned short *__restrict__ x, size_t n_chunks,
-                                                 unsigned short *__restrict__ out) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // 16-byte chunk index of the output
-    if (i >= n_chunks) return;
-    size_t row = i / 288;
-    int rem = (int)(i - row * 288);
-    int tap = rem >> 5, c8 = rem & 31;
-    int tok = (int)(row & 1023);
-    int ph = tok >> 5, pw = tok & 31;
-    int yy = ph + tap / 3 - 1, xx = pw + tap % 3 - 1;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if ((unsigned)yy < 32u && (unsigned)xx < 32u)
-        v = *reinterpret_cast<const uint4 *>(x + ((row & ~(size_t)1023) + yy * 32 + xx) * 256 + c8 * 8);
-    *reinterpret_cast<uint4 *>(out + row * 2304 + tap * 256 + c8 * 8) = v;
-}
-
-// ---------------------------------------------------------------------------
 // forward driver
 // ---------------------------------------------------------------------------
 struct NetWs {
-    size_t off_x, off_xn, off_qkv, off_vt, off_ao, off_h, off_neck, off_neck2, off_col, off_st, total;
+    size_t off_x, off_xn, off_qkv, off_vt, off_ao, off_h, off_neck, off_neck2, off_st, total;
 };
 static NetWs net_ws(int nS) {
     NetWs w; size_t o = 0; const size_t M = (size_t)nS * 1024;
@@ -1001,7 +982,6 @@ static NetWs net_ws(int nS) {
     w.off_h = take(M * 4096 * 2);
     w.off_neck = take(M * 256 * 2);
     w.off_neck2 = take(M * 256 * 2);
-    w.off_col = take(M * 2304 * 2);
     w.off_st = take(M * 8 * sizeof(float));
     w.total = o;
     return w;
@@ -1068,8 +1048,7 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
     char *ws = (char *)workspace;
     const int M = nS * 1024;
     void *x = ws + L.off_x, *xn = ws + L.off_xn, *qkv = ws + L.off_qkv, *vt = ws + L.off_vt,
-         *ao = ws + L.off_ao, *hb = ws + L.off_h, *nk = ws + L.off_neck, *nk2 = ws + L.off_neck2,
-         *col = ws + L.off_col;
+         *ao = ws + L.off_ao, *hb = ws + L.off_h, *nk = ws + L.off_neck, *nk2 = ws + L.off_neck2;
     CpxProf *prof = (CpxProf *)w->prof;
     hipStream_t hs = (hipStream_t)stream;
     const int trv = cpx_attention_trv_enabled();
@@ -1111,13 +1090,8 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d
     RUN(GEMM(x, w->neck0_w, 256, 1024, CPX_EPI_BF16, nullptr, nullptr, nk, 256));
     RUN(cpx_layernorm_half(dt, nk, w->neck_ln1_w, w->neck_ln1_b, M, 256, 1e-6f, nk2, stream));
-    {
-        size_t n_chunks = (size_t)M * 288;
-        hipLaunchKernelGGL(k_im2col3, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0,
-                           hs, (const unsigned short *)nk2, n_chunks, (unsigned short *)col);
-        CPX_CHECK_LAUNCH();
-    }
-    RUN(GEMM(col, w->neck2_w, 256, 2304, CPX_EPI_BF16, nullptr, nullptr, nk, 256));
+    // 3x3 conv as an implicit GEMM (K = 9 x 256, the shifted operand is read by the LDS-DMA itself: no im2col buffer)
+    RUN(cpx_conv3_half(dt, nk2, w->neck2_w, M, 256, 256, CPX_EPI_BF16, nullptr, nk, 256, stream));
     RUN(cpx_layernorm_half(dt, nk, w->neck_ln2_w, w->neck_ln2_b, M, 256, 1e-6f, nk2, stream));
     // heads: out (192) | out_class (ncls*64), f32 token-major
     RUN(GEMM(nk2, w->head_w, w->ld_head, 256, CPX_EPI_F32, w->head_b, nullptr, head, w->ld_head));

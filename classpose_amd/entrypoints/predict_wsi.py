@@ -34,7 +34,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import engine, geojson, ops, parallel, postprocess, roi, wsi
+from .. import engine, geojson, hooks, ops, parallel, postprocess, roi, wsi
 from ..log import get_logger
 from ..model_configs import DEFAULT_MODEL_CONFIGS, ModelConfig
 
@@ -160,6 +160,7 @@ class TileStream:
 
 def run_rank(args, rank: int, world: int, device: torch.device):
     """Everything one GPU does; returns (cell table, vertex pool) of this rank's shard."""
+    hooks.load_plugins()
     if getattr(args, "model_path", None) is not None:
         # predict_wsi_cpsam: a plain Cellpose-SAM checkpoint, no semantic head, every cell is "cell"
         model_config = ModelConfig(path=args.model_path, url=None, mpp=args.train_mpp, cell_types=[])
@@ -241,14 +242,10 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         nT = max(1, max(args.batch_size, 96) // n_sub)
         eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
         extra = None
-        if os.getenv("CLASSPOSE_FLOW_INJECTION", "0") == "1" and hasattr(slide, "seed"):
-            # test / bench mode for synthetic slides with random weights: the dynamics consume
-            # analytic fields of the procedural nuclei, the network still runs on the pixels
-            from .. import synth
-
+        provider = hooks.field_provider(slide, plan, n_classes) if hooks.field_provider else None
+        if provider is not None:                                 # plug-in supplied dynamics inputs (classpose_amd/hooks.py)
             def extra(ti, R=R, W=W, H=H):
-                return synth.analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R,
-                                             n_classes, W, H)
+                return provider(ti, R, W, H)
         stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra)
         def collect(sid, chunk, keep_alive):
             nonlocal n_done, n_invalid
@@ -323,12 +320,9 @@ def gather_cells(cells: np.ndarray, xy: np.ndarray, device) -> tuple[np.ndarray,
 
 
 def _qc_override(kind: str):
-    """CLASSPOSE_QC_INJECTION=1 (tests on synthetic slides with random GrandQC weights): the class map
-    comes from ``synth.analytic_qc_map`` instead of the network's argmax; the network still runs."""
-    if os.getenv("CLASSPOSE_QC_INJECTION", "0") != "1":
-        return None
-    from .. import synth
-    return lambda image: synth.analytic_qc_map(kind, image.shape[0], image.shape[1])
+    """Class-map override of a plug-in (classpose_amd/hooks.py), else None: the network's arg-max is used."""
+    hooks.load_plugins()
+    return hooks.qc_provider(kind) if hooks.qc_provider else None
 
 
 def write_outputs(args, cells, xy, labels, plan, device=None):

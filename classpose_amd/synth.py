@@ -359,3 +359,22 @@ def analytic_qc_map(kind: str, height: int, width: int) -> np.ndarray:
         return np.where(ell & ~hole, 0, 1).astype(np.int8)
     fold = (u > 0.30) & (u < 0.42) & (v > 0.30) & (v < 0.45)
     return np.where(fold, 2, 1).astype(np.int8)
+
+
+def register(hooks, argument: str) -> None:
+    """Plug-in entry (classpose_amd/hooks.py): ``CLASSPOSE_AMD_PLUGINS=classpose_amd.synth:flow``, ``:qc`` or
+    ``:flow+qc``.  flow: the dynamics of tiles read from a SyntheticSlide consume the analytic fields of its procedural
+    nuclei (other readers are left alone); qc: the GrandQC class maps come from ``analytic_qc_map``."""
+    what = set(filter(None, (argument or "flow").split("+")))
+    unknown = what - {"flow", "qc"}
+    if unknown:
+        raise ValueError(f"classpose_amd.synth plug-in: unknown option(s) {sorted(unknown)}")
+    if "flow" in what:
+        def field_provider(slide, plan, n_classes):
+            if not hasattr(slide, "seed"):
+                return None
+            return lambda ti, R, W, H: analytic_fields(slide.seed, plan.coords[ti][0][0], plan.coords[ti][0][1], R, R,
+                                                       n_classes, W, H)
+        hooks.field_provider = field_provider
+    if "qc" in what:
+        hooks.qc_provider = lambda kind: (lambda image: analytic_qc_map(kind, image.shape[0], image.shape[1]))

@@ -10,10 +10,19 @@ from classpose_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fresh_plugins():
+    """The CLI runs in this process: plug-ins registered by one test must not leak into the next."""
+    from classpose_amd import hooks
+    hooks.reset()
+    yield
+    hooks.reset()
+
+
 def test_predict_wsi_cli_flow_injection(cuda, tmp_path, monkeypatch):
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     W, Hs = 1180, 956
@@ -72,7 +81,7 @@ def test_predict_wsi_cli_default_tile_1024(cuda, tmp_path, monkeypatch):
     """the reference's DEFAULT geometry: --tile_size 1024 --overlap 64 (25 sub-tiles per tile)"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     W, Hs = 2100, 1100                                   # 2 x 1 tiles at stride 960
@@ -99,7 +108,7 @@ def test_predict_wsi_cli_rescaled_slide(cuda, tmp_path, monkeypatch):
     (resize_tile_to_target_mpp) and the polygons come back in level-0 coordinates"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     from classpose_amd import wsi
@@ -139,7 +148,7 @@ def test_predict_wsi_cli_roi(cuda, tmp_path, monkeypatch):
     only when their centroid is inside an ROI"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     rois = [[[400, 300], [1000, 300], [1000, 600], [400, 600], [400, 300]],                 # 600 x 300
@@ -188,8 +197,7 @@ def test_predict_wsi_cli_tissue_and_artefacts(cuda, tmp_path, monkeypatch):
     skipped, cells are filtered by tissue and artefact polygons, both contour files are written"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
-    monkeypatch.setenv("CLASSPOSE_QC_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow+qc")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     W, Hs = 3000, 2400
@@ -246,7 +254,7 @@ def test_predict_wsi_cpsam_cli(cuda, tmp_path, monkeypatch):
     """class-less Cellpose-SAM entry point: --model_path / --train_mpp, every polygon is a "cell" """
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     from classpose_amd.entrypoints import predict_wsi_cpsam
     W, Hs = 800, 600
     args = predict_wsi_cpsam.build_parser().parse_args([
@@ -286,7 +294,7 @@ def test_predict_wsi_reference_integration_args_fp32(cuda, tmp_path, monkeypatch
     (--precision fp32 through the exact-f32 MFMA kernels), same assertions + the nuclei check"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "2")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     W, Hs = 840, 650
@@ -311,7 +319,7 @@ def test_predict_wsi_cpsam_reference_integration_args_fp32(cuda, tmp_path, monke
     """test_predict_wsi_cpsam_integration of the reference (:172-215)"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     from classpose_amd.entrypoints import predict_wsi_cpsam
     args = _reference_integration_args("synthetic://700x520?mpp=0.5&seed=43", tmp_path, model_path="cpsam", train_mpp=0.5)
     predict_wsi_cpsam.main(args)
@@ -327,7 +335,7 @@ def test_predict_wsi_multi_gpu_integration(tmp_path, monkeypatch):
         pytest.skip("Needs at least 2 GPUs")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     slide = "synthetic://1500x1100?mpp=0.5&seed=45"
@@ -345,8 +353,7 @@ def test_predict_wsi_cli_puma_grandqc(cuda, tmp_path, monkeypatch):
     sub-tiles) WITH GrandQC tissue + artefact detection, --filter_artefacts and --output_type csv"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
-    monkeypatch.setenv("CLASSPOSE_QC_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow+qc")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     W, Hs = 6800, 5200
@@ -394,8 +401,7 @@ def test_predict_wsi_cli_roi_class_densities_with_artefacts(cuda, tmp_path, monk
     (predict_wsi.py:1797-1836)"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
-    monkeypatch.setenv("CLASSPOSE_FLOW_INJECTION", "1")
-    monkeypatch.setenv("CLASSPOSE_QC_INJECTION", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow+qc")
     monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
     from classpose_amd.entrypoints import predict_wsi
     W, Hs = 3000, 2400
