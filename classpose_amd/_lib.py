@@ -117,6 +117,7 @@ SIGNATURES = {
     "cpx_polygonize_host": (_i, [_p, _i, _i, _p, _i, _d, _d, _d, _p, _i, _p]),
     "cpx_dedup_pairs_workspace_bytes": (_sz, [_i, _i, _i]),
     "cpx_dedup_pairs": (_i, [_p, _i, _d, _d, _d, _i, _i, _d, _p, C.c_longlong, _p, _p, _sz, _p]),
+    "cpx_write_geojson": (_i, [C.c_char_p, C.c_char_p, _p, C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _i, _d, _d, _i]),
 }
 # include/classpose_hip_debug.h: process-global A/B and ablation switches (tools/, a few tests)
 _PRIVATE = {

@@ -377,6 +377,23 @@ int cpx_dedup_pairs(const double *centers_xy, int n, double x0, double y0, doubl
                     double max_dist, int32_t *pairs, long long max_pairs, long long *n_pairs,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------
+ * f3 / a19  the two GeoJSON FeatureCollections of a slide, streamed (host code, no HIP calls)
+ * replaces json.dump({"type": "FeatureCollection", "features": [...]}) over the features of
+ * to_geojson_polygon / apply_bounds_offset_to_feature / polygons_to_centroids,
+ * /root/reference/src/classpose/entrypoints/predict_wsi.py:813-893,1336-1374,1772-1785.
+ * Byte-identical to CPython's json encoder (", " and ": " separators, float.__repr__ numbers) except for the
+ * random uuid4 ids.  cells [n_cells] rows of {double area, perimeter, cx, cy; int64 n_pts, cls} (48 B);
+ * centroids_xy [n_cells][2] the centroids rounded to 2 decimals; ring i = xy_pool[2*offsets[i] .. 2*offsets[i+1])
+ * (not closed; the writer repeats the first vertex); keep [n_keep] indices of the cells to write, in order;
+ * class_json [n_class_json] the serialised {"name": ..., "color": [...]} object per value of cls;
+ * bounds are subtracted from every coordinate when non-zero; n_threads <= 0 = one per core (max 16). */
+int cpx_write_geojson(const char *contours_path, const char *centroids_path, const void *cells,
+                      int64_t n_cells, const double *centroids_xy, const double *xy_pool,
+                      const int64_t *offsets, const int64_t *keep, int64_t n_keep,
+                      const char *const *class_json, int n_class_json, double bounds_x, double bounds_y,
+                      int n_threads);
+
 /* cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_SIMPLE) of the GrandQC class maps
  * (/root/reference/src/classpose/grandqc/wsi_tissue_detection.py:209-213,
  * wsi_artefact_detection.py:262-265), host code.  mask [H][W] uint8, non-zero = foreground.

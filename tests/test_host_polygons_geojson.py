@@ -148,3 +148,70 @@ def test_streaming_writer_equals_dict_pipeline(tmp_path):
     sel = np.array([5, 2, 9])
     g = geojson.gather_vertices(xy, offs[sel], cells["n_pts"][sel])
     assert np.array_equal(g, np.concatenate([xy[offs[i]:offs[i + 1]] for i in sel]))
+
+
+def test_native_writer_is_bytewise_json_dump(tmp_path):
+    """cpx_write_geojson against json.dumps of the reference-shaped feature dicts, byte for byte (ids masked),
+    on values that exercise every branch of float.__repr__: integers, exponents on both sides of the
+    fixed / scientific switch (1e-4, 1e16), 17-digit values, negative zero, and a bounds offset."""
+    import json
+    import re
+    from classpose_amd.entrypoints.predict_wsi import CELL_ROW
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 1.0, 1e15, 1e16, 1.5e16, 1e-4, 9.999e-5, 1e-5, 123456789012345.6, 2.0 / 3, 0.1 + 0.2,
+                        1e22, 5e-324, 1.7976931348623157e308, 4.35, 100.0, 65536.5, 1234567.891, -3.25, 1e-7, 12345678.9])
+    n = 64
+    cells = np.zeros(n, CELL_ROW)
+    cells["n_pts"] = rng.integers(3, 7, n)
+    cells["cls"] = rng.integers(0, 3, n)
+    cells["area"] = np.resize(special, n)
+    cells["perimeter"] = np.resize(special[::-1], n)
+    cells["cx"] = rng.uniform(0, 1e5, n)
+    cells["cy"] = rng.uniform(0, 1e5, n)
+    tot = int(cells["n_pts"].sum())
+    xy = np.stack([np.resize(special, tot), rng.uniform(-10, 1e5, tot)], 1)
+    xy[5:40] = rng.integers(0, 40000, (35, 2)).astype(np.float64) * 0.5        # what tile contours look like
+    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])])
+    labels = ['a "quoted" name', "b", "ünï"]                                    # json.dumps escapes both
+    keep = [int(k) for k in rng.permutation(n)[:50]] + [3, 3]
+    for bounds in [(0.0, 0.0), (12.5, -7.25)]:
+        feats = []
+        for i in keep:
+            c = cells[i]
+            centroid = np.round([c["cx"], c["cy"]], 2).tolist()
+            f = geojson.to_geojson_polygon(geojson.cell_dict(xy[offs[i]:offs[i + 1]].tolist(), int(c["cls"]), labels,
+                                                            c["area"], c["perimeter"], centroid))
+            feats.append(geojson.apply_bounds_offset_to_feature(f, *bounds) if bounds != (0.0, 0.0) else f)
+        want_c = json.dumps({"type": "FeatureCollection", "features": feats})
+        want_p = json.dumps({"type": "FeatureCollection", "features": geojson.polygons_to_centroids(feats)})
+        geojson.write_feature_collections(tmp_path / "c.json", tmp_path / "p.json", cells, xy, keep, labels, bounds, n_threads=3)
+        mask = lambda t: re.sub(r'"id": "[0-9a-f]{8}-[0-9a-f]{4}-4[0-9a-f]{3}-[89ab][0-9a-f]{3}-[0-9a-f]{12}"', '"id": "X"', t)
+        got_c, got_p = open(tmp_path / "c.json").read(), open(tmp_path / "p.json").read()
+        assert mask(got_c) == mask(want_c)
+        assert mask(got_p) == mask(want_p)
+        assert '"id": "X"' in mask(got_c) and mask(got_c).count('"id": "X"') == len(keep)
+        ids = re.findall(r'"id": "([0-9a-f-]{36})"', got_c + got_p)
+        assert len(set(ids)) == 2 * len(keep)                                    # every feature has its own uuid4
+
+
+def test_native_writer_many_chunks(tmp_path):
+    """more cells than one 8192-cell chunk and more chunks than the in-memory window: order and separators hold"""
+    import json
+    from classpose_amd.entrypoints.predict_wsi import CELL_ROW
+    n = 8192 * 9 + 17
+    cells = np.zeros(n, CELL_ROW)
+    cells["n_pts"] = 3
+    cells["cls"] = 1
+    cells["area"] = np.arange(n)
+    cells["cx"] = np.arange(n) * 0.25
+    xy = np.zeros((3 * n, 2))
+    xy[:, 0] = np.arange(3 * n)
+    geojson.write_feature_collections(tmp_path / "c.json", tmp_path / "p.json", cells, xy, np.arange(n), None, n_threads=2)
+    c = json.load(open(tmp_path / "c.json"))["features"]
+    p = json.load(open(tmp_path / "p.json"))["features"]
+    assert len(c) == len(p) == n
+    assert [f["properties"]["measurements"][0]["value"] for f in c] == list(map(float, range(n)))
+    assert [f["geometry"]["coordinates"][0] for f in p] == [i * 0.25 for i in range(n)]
+    assert c[-1]["geometry"]["coordinates"][0][0] == [3.0 * (n - 1), 0.0] == c[-1]["geometry"]["coordinates"][0][3]
+    with pytest.raises(Exception):
+        geojson.write_feature_collections(tmp_path / "c.json", tmp_path / "p.json", cells, xy, [n], None)   # index out of range
