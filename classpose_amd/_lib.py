@@ -129,6 +129,7 @@ _PRIVATE = {
     "cpx_attention_set_xcd_order": (None, [_i]),
     "cpx_gemm_set_big": (None, [_i]),
     "cpx_gemm_set_persistent": (None, [_i]),
+    "cpx_gemm_set_persistent_qkv": (None, [_i]),
     "cpx_attention_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_attention8_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_gemm_set_dbg": (None, [_i]),

@@ -687,7 +687,17 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         const int nxcd = 8, q = nblk / nxcd, r = nblk % nxcd, x = v % nxcd;
         int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / nxcd;
         int tile_m, tile_n;
-        if (g.l2_block && (tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
+        if (EPI == CPX_EPI_QKV_BF16 && g.l2_block == 3) {
+            // balanced list for the qkv projection (launcher: 256 workgroups, tiles_m % 128 == 0, 12 column tiles): the
+            // V^T tiles cost more (their transposed image needs the whole LDS, so nothing is prefetched under their
+            // epilogue), hence every workgroup gets the same mix -- four q|k tiles, then two V^T tiles, per round -- and the
+            // 32 workgroups of an XCD still cover one 8 x 4 super-tile at a time
+            // (rounds of 6: four q|k super-tiles and the two V^T super-tiles of the same 16 row tiles)
+            const int x = v & 7, slot = (v >> 3) & 31, i = v >> 8, rx = tiles_m >> 3, rnd = i / 6, j = i - rnd * 6;
+            const int rg = 2 * rnd + (j < 4 ? j >> 1 : j - 4), cg = j < 4 ? j & 1 : 2;
+            tile_m = x * rx + rg * 8 + (slot >> 2);
+            tile_n = cg * 4 + (slot & 3);
+        } else if (g.l2_block && (tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
             const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2, rgn = tiles_m >> 3;
             // mode 1: column groups innermost (an XCD sweeps N for a fixed band of 8 row tiles); mode 2: row groups
             // innermost (an XCD keeps ONE 4-tile W panel, 2 MB, and streams the activation rows past it)
@@ -993,6 +1003,8 @@ extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
 static int g_gemm_dbg = 0;
 extern "C" void cpx_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 static int g_gemm_l2 = 1;
+static int g_gemm_persist_qkv = 1;   // balanced persistent tile list for the qkv projection (A/B switch, default on)
+extern "C" void cpx_gemm_set_persistent_qkv(int on) { g_gemm_persist_qkv = on; }
 extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 // experiment switch (default off): mlp.lin2 walks M backwards so that the most recently written rows of the
 // 268 MB hidden tensor (> the 256 MB Infinity Cache) are read first.  Bitwise identical; measured 26.50 vs
@@ -1006,7 +1018,8 @@ template <int EPI, bool F16, int FLAGS>
 static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
     // the qkv projection keeps one workgroup per tile: a third of its tiles (the V^T ones) cannot overlap their
     // epilogue with the next prefetch and cost more, and a static tile list cannot balance that (measured +3 %)
-    if (g_gemm_persist && EPI != CPX_EPI_QKV_BF16) {
+    const bool qkv_balanced = EPI == CPX_EPI_QKV_BF16 && g_gemm_persist_qkv && (a.n_blocks / a.tiles_n) % 128 == 0 && a.tiles_n == 12;
+    if (g_gemm_persist && (EPI != CPX_EPI_QKV_BF16 || qkv_balanced)) {
         static CpxOncePerDevice once_p;
         static int n_cu = 0;
         once_p([] {
@@ -1016,9 +1029,18 @@ static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             n_cu = cus > 0 ? cus : 256;
         });
-        const int grid = a.n_blocks < n_cu ? a.n_blocks : n_cu;
-        hipLaunchKernelGGL((k_gemm256p<EPI, F16, FLAGS>), dim3(grid), dim3(G2_THREADS), G2P_LDS_BYTES, s, a);
-        return;
+        if (EPI == CPX_EPI_QKV_BF16) {
+            if (n_cu == 256) {
+                GemmArgs b = a;
+                b.l2_block = 3;
+                hipLaunchKernelGGL((k_gemm256p<EPI, F16, FLAGS>), dim3(256), dim3(G2_THREADS), G2P_LDS_BYTES, s, b);
+                return;
+            }
+        } else {
+            const int grid = a.n_blocks < n_cu ? a.n_blocks : n_cu;
+            hipLaunchKernelGGL((k_gemm256p<EPI, F16, FLAGS>), dim3(grid), dim3(G2_THREADS), G2P_LDS_BYTES, s, a);
+            return;
+        }
     }
     static CpxOncePerDevice once;
     once([] { (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES); });
