@@ -205,11 +205,13 @@ def main():
     run_steps(it, args.warmup)
     torch.cuda.synchronize(dev)
     cells_acc.zero_()
-    # every launch of the dominant GEMM is timed (BENCH_PROF_STRIDE=8 samples every 8th layer: +0.9 % tiles/s,
-    # but the sampled launches then read ~10 % longer than rocprofv3's serialised average -- the event pairs'
-    # idle gaps let the chip hold a higher clock; measured A/B on one box)
+    # the dominant GEMM is timed on every 4th layer, the sampled layers rotating by one per step so that all 24 are
+    # covered equally (BENCH_PROF_STRIDE): each event pair costs the stream ~6 us of idle time on either side of the
+    # launch (tools/r02_gaps.sh: 0.28 ms per step with every launch timed = 1.1 % of the headline; stride 4: +0.3-0.5 %
+    # tiles/s at the same measured launch duration; stride 8 reads ~3 % longer launches on the same box -- with fewer
+    # idle gaps the chip sustains a lower clock -- DESIGN 5)
     prof = C.c_void_p()
-    _lib.check(L.cpx_prof_create(steps * args.depth + 8, int(os.environ.get("BENCH_PROF_STRIDE", "1")), 1,
+    _lib.check(L.cpx_prof_create(steps * args.depth + 8, int(os.environ.get("BENCH_PROF_STRIDE", "4")), 1,
                                  C.byref(prof)), "prof_create")
     w.c.prof = prof
     parallel.barrier()

@@ -29,11 +29,13 @@ struct CpxProf {
     hipEvent_t *ev = nullptr;      // 2 per timed launch
     int *kind = nullptr;
     int cap = 0, n = 0, stride = 1;
+    int phase = 0;                 // advanced once per forward: layer l is timed when (l + phase) % stride == 0, so a
+                                   // stride > 1 rotates through every layer instead of always sampling the same ones
     unsigned kinds_mask = 1;       // bit k: time kernels of kind k
 };
 // returns true and records the start event when this launch is to be timed
 static inline bool cpx_prof_begin(CpxProf *p, int kind, int layer, hipStream_t s) {
-    if (!p || !p->ev || p->n >= p->cap || !((p->kinds_mask >> kind) & 1) || (layer % p->stride) != 0) return false;
+    if (!p || !p->ev || p->n >= p->cap || !((p->kinds_mask >> kind) & 1) || ((layer + p->phase) % p->stride) != 0) return false;
     p->kind[p->n] = kind;
     return hipEventRecord(p->ev[2 * p->n], s) == hipSuccess;
 }

@@ -1050,6 +1050,7 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
     void *x = ws + L.off_x, *xn = ws + L.off_xn, *qkv = ws + L.off_qkv, *vt = ws + L.off_vt,
          *ao = ws + L.off_ao, *hb = ws + L.off_h, *nk = ws + L.off_neck, *nk2 = ws + L.off_neck2;
     CpxProf *prof = (CpxProf *)w->prof;
+    if (prof) prof->phase = (prof->phase + 1) % prof->stride;
     hipStream_t hs = (hipStream_t)stream;
     const int trv = cpx_attention_trv_enabled();
     int rc;

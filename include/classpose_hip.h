@@ -192,7 +192,8 @@ int cpx_net_forward(const cpx_net_weights *w_host, const void *patches, int n_su
                     float *head, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Per-launch timing of the dominant kernels of cpx_net_forward (bench.py's roofline lines): HIP
- * events recorded on the launch stream around every `stride`-th layer's kernels of the kinds in
+ * events recorded on the launch stream around every `stride`-th layer's kernels (the sampled layers
+ * rotate by one per forward, so every layer is covered equally over `stride` forwards) of the kinds in
  * kinds_mask (bit 0 mlp.lin1, 1 attention, 2 qkv, 3 attn.proj, 4 mlp.lin2).  The handle is carried in
  * cpx_net_weights.prof and belongs to one engine / host thread.  cpx_prof_collect (after a stream
  * sync) fills ms_sum[5] / count[5] per kind and resets the handle.                              */

@@ -1,0 +1,10 @@
+#!/bin/bash
+# kernel trace of a short bench run -> idle gaps between consecutive kernels of the network stream (tools/trace_gaps.py)
+set -u
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02gaps
+rm -rf $O; mkdir -p $O
+rocprofv3 --kernel-trace --output-format csv -d $O/t -o run -- python3 $R/bench.py --gpus 1 --steps 12 --warmup 3 --no-cpu-baseline --no-stages > $O/run.log 2>&1
+python3 $R/tools/trace_gaps.py $O/t > $O/gaps.txt 2>&1
+find $O -type f \( -name "*kernel_trace.csv" -o -name "*.db" -o -name "*agent_info.csv" \) -delete
