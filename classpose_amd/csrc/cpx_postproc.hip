@@ -333,47 +333,89 @@ __device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, 
     return label_runs(lab, base, HW, W, limit, f);
 }
 
+// Per-workgroup aggregation of per-label updates.  A label's table entries are 4-16 bytes apart, so the ~50 row runs of
+// each of a tile's ~80 labels all hit the same three or four cache lines, and the L2 serialises them (k_first: 13 us for a
+// pass that reads 2 MB).  A 256-slot LDS hash keyed by the label collects a workgroup's updates first (2 048 pixels =
+// 8 image rows see a few dozen labels); one global atomic per (label, workgroup) follows.  Integer min / max / add only,
+// so the tables end up identical.  lh_slot returns -1 when 8 probes find no slot: the caller then updates global memory.
+#define LH_SLOTS NTHR
+__device__ __forceinline__ int lh_slot(int *key, int lab) {
+    const unsigned h = ((unsigned)lab * 2654435761u) >> 24;
+#pragma unroll 1
+    for (int p = 0; p < 8; ++p) {
+        const int s = (int)((h + p) & (LH_SLOTS - 1));
+        const int old = atomicCAS(&key[s], 0, lab);
+        if (old == 0 || old == lab) return s;
+    }
+    return -1;
+}
+
 // label gather + per-label pixel count (label 0 not counted)
 __global__ void k_gather(const int32_t *__restrict__ p_final, int32_t *__restrict__ masks,
                          PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vadd[LH_SLOTS];
+    key[threadIdx.x] = 0; vadd[threadIdx.x] = 0;
+    __syncthreads();
     const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
-    if (base >= lay.HW) return;
     const size_t t = blockIdx.y;
-    const int *M1 = WS(int, off_M1);
-    int lab[RUN_PX];
-#pragma unroll
-    for (int i = 0; i < RUN_PX; ++i) {
-        lab[i] = 0;
-        if (base + i < lay.HW) {
-            const int p = p_final[t * lay.HW + base + i];
-            if (p != -1) {
-                int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
-                py = min(max(py, 0), lay.H + RPAD - 1); px = min(max(px, 0), lay.W + RPAD - 1);
-                lab[i] = M1[py * lay.Wp + px];
-            }
-            masks[t * lay.HW + base + i] = lab[i];
-        }
-    }
     int *cnt = WS(int, off_cnt);
-    label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int, int n, int, int) { atomicAdd(&cnt[l], n); });
+    if (base < lay.HW) {
+        const int *M1 = WS(int, off_M1);
+        int lab[RUN_PX];
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) {
+            lab[i] = 0;
+            if (base + i < lay.HW) {
+                const int p = p_final[t * lay.HW + base + i];
+                if (p != -1) {
+                    int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
+                    py = min(max(py, 0), lay.H + RPAD - 1); px = min(max(px, 0), lay.W + RPAD - 1);
+                    lab[i] = M1[py * lay.Wp + px];
+                }
+                masks[t * lay.HW + base + i] = lab[i];
+            }
+        }
+        label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int, int n, int, int) {
+            const int sl = lh_slot(key, l);
+            if (sl >= 0) atomicAdd(&vadd[sl], n); else atomicAdd(&cnt[l], n);
+        });
+    }
+    __syncthreads();
+    if (key[threadIdx.x]) atomicAdd(&cnt[key[threadIdx.x]], vadd[threadIdx.x]);
 }
 
 // big-mask removal (count > H*W*fraction) + first raster index per surviving label
 __global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vmin[LH_SLOTS];
+    key[threadIdx.x] = 0; vmin[threadIdx.x] = 0x7FFFFFFF;
+    __syncthreads();
     const int *cnt = WS(int, off_cnt);
     int *first = WS(int, off_first);
     int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
     for_label_runs(m, lay.HW, lay.W, 0x7FFFFFFF, [&](int lab, int idx, int n, int, int) {
         if ((double)cnt[lab] > big) { for (int i = 0; i < n; ++i) m[idx + i] = 0; }
-        else atomicMin(&first[lab], idx);
+        else {
+            const int sl = lh_slot(key, lab);
+            if (sl >= 0) atomicMin(&vmin[sl], idx); else atomicMin(&first[lab], idx);
+        }
     });
+    __syncthreads();
+    if (key[threadIdx.x]) atomicMin(&first[key[threadIdx.x]], vmin[threadIdx.x]);
 }
 
 // generic: first raster index per label (labels < L)
 __global__ void k_first(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vmin[LH_SLOTS];
+    key[threadIdx.x] = 0; vmin[threadIdx.x] = 0x7FFFFFFF;
+    __syncthreads();
     int *first = WS(int, off_first);
     for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
-                   [&](int lab, int idx, int, int, int) { atomicMin(&first[lab], idx); });
+                   [&](int lab, int idx, int, int, int) {
+                       const int s = lh_slot(key, lab);
+                       if (s >= 0) atomicMin(&vmin[s], idx); else atomicMin(&first[lab], idx);
+                   });
+    __syncthreads();
+    if (key[threadIdx.x]) atomicMin(&first[key[threadIdx.x]], vmin[threadIdx.x]);
 }
 
 __global__ void k_fill_i32(size_t off, int n, int value, PPLayout lay, void *ws) {
@@ -416,18 +458,57 @@ __global__ void k_copy_scalar(int dst, int src, PPLayout lay, void *ws) {
 // ---------------------------------------------------------------------------
 // a13  flow-error filter
 // ---------------------------------------------------------------------------
-// per-label bbox / count / coordinate sums
-__global__ void k_lab_stats(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
+// per-label bbox / count / coordinate sums (+ first raster index and the largest label for the records pass), aggregated
+// per workgroup in LDS (lh_slot).  A workgroup covers 2 048 pixels, so its partial coordinate sums fit 32 bits
+// (H, W <= 16 384).
+struct LabStatsLds {
+    int key[LH_SLOTS], ymin[LH_SLOTS], xmin[LH_SLOTS], ymax[LH_SLOTS], xmax[LH_SLOTS], cnt[LH_SLOTS], first[LH_SLOTS];
+    unsigned sy[LH_SLOTS], sx[LH_SLOTS];
+    int vmax;
+};
+template <typename T, bool REC>
+__device__ __forceinline__ void lab_stats_pass(const T *__restrict__ m, int limit, LabStatsLds &L, const PPLayout &lay, void *ws) {
+    const int i = threadIdx.x;
+    L.key[i] = 0; L.ymin[i] = 0x7FFFFFFF; L.xmin[i] = 0x7FFFFFFF; L.ymax[i] = -1; L.xmax[i] = -1; L.cnt[i] = 0;
+    L.first[i] = 0x7FFFFFFF; L.sy[i] = 0; L.sx[i] = 0;
+    if (i == 0) L.vmax = 0;
+    __syncthreads();
+    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt), *first = WS(int, off_first), *scal = WS(int, off_scal);
     unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
-    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
-                   [&](int lab, int, int n, int y, int x) {
-                       int *bb = bbox + 4 * lab;
-                       atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
-                       atomicAdd(&cnt[lab], n);
-                       atomicAdd(&sumy[lab], (unsigned long long)n * y);
-                       atomicAdd(&sumx[lab], (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2));
-                   });
+    int vmax = 0;
+    for_label_runs(m, lay.HW, lay.W, limit, [&](int lab, int idx, int n, int y, int x) {
+        const unsigned long long ay = (unsigned long long)n * y;
+        const unsigned long long ax = (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2);
+        const int sl = lh_slot(L.key, lab);
+        if (sl >= 0) {
+            atomicMin(&L.ymin[sl], y); atomicMin(&L.xmin[sl], x); atomicMax(&L.ymax[sl], y); atomicMax(&L.xmax[sl], x + n - 1);
+            atomicAdd(&L.cnt[sl], n);
+            atomicAdd(&L.sy[sl], (unsigned)ay); atomicAdd(&L.sx[sl], (unsigned)ax);
+            if (REC) atomicMin(&L.first[sl], idx);
+        } else {
+            int *bb = bbox + 4 * lab;
+            atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
+            atomicAdd(&cnt[lab], n);
+            atomicAdd(&sumy[lab], ay); atomicAdd(&sumx[lab], ax);
+            if (REC) atomicMin(&first[lab], idx);
+        }
+        vmax = max(vmax, lab);
+    });
+    if (REC && vmax > 0) atomicMax(&L.vmax, vmax);
+    __syncthreads();
+    const int lab = L.key[i];
+    if (lab) {
+        int *bb = bbox + 4 * lab;
+        atomicMin(&bb[0], L.ymin[i]); atomicMin(&bb[1], L.xmin[i]); atomicMax(&bb[2], L.ymax[i]); atomicMax(&bb[3], L.xmax[i]);
+        atomicAdd(&cnt[lab], L.cnt[i]);
+        atomicAdd(&sumy[lab], (unsigned long long)L.sy[i]); atomicAdd(&sumx[lab], (unsigned long long)L.sx[i]);
+        if (REC) atomicMin(&first[lab], L.first[i]);
+    }
+    if (REC && i == 0 && L.vmax > 0) atomicMax(&scal[SC_VMAX], L.vmax);
+}
+__global__ void k_lab_stats(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    __shared__ LabStatsLds L;
+    lab_stats_pass<int32_t, false>(masks + (size_t)blockIdx.y * lay.HW, 0x7FFFFFFF, L, lay, ws);
 }
 
 __global__ void k_init_stats(PPLayout lay, void *ws) {
@@ -496,6 +577,10 @@ __device__ __forceinline__ double center_d2(int y, int x, const int *bb, int n,
 }
 
 __global__ void k_center_d2(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS];
+    __shared__ unsigned long long vmin[LH_SLOTS];
+    key[threadIdx.x] = 0; vmin[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull;
+    __syncthreads();
     const int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
     const unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
     unsigned long long *d2min = WS(unsigned long long, off_d2);
@@ -506,8 +591,11 @@ __global__ void k_center_d2(const int32_t *__restrict__ masks, PPLayout lay, voi
                            const double d2 = center_d2(y, x + i, bbox + 4 * lab, cnt[lab], sumy[lab], sumx[lab]);
                            best = min(best, (unsigned long long)__double_as_longlong(d2));
                        }
-                       atomicMin(&d2min[lab], best);
+                       const int sl = lh_slot(key, lab);
+                       if (sl >= 0) atomicMin(&vmin[sl], best); else atomicMin(&d2min[lab], best);
                    });
+    __syncthreads();
+    if (key[threadIdx.x]) atomicMin(&d2min[key[threadIdx.x]], vmin[threadIdx.x]);
 }
 
 __global__ void k_center_pick(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
@@ -747,13 +835,26 @@ __global__ void k_zero_f64(size_t off, int n, PPLayout lay, void *ws) {
 // a14  fill_holes_and_remove_small_masks
 // ---------------------------------------------------------------------------
 __global__ void k_count_labels(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vadd[LH_SLOTS], s_max, s_bg;
+    key[threadIdx.x] = 0; vadd[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_max = 0; s_bg = 0; }
+    __syncthreads();
     int *cnt = WS(int, off_cnt), *scal = WS(int, off_scal);
+    int vmax = 0;
     const bool bg = for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
                                    [&](int lab, int, int n, int, int) {
-                                       atomicAdd(&cnt[lab], n);
-                                       atomicMax(&scal[SC_VMAX], lab);
+                                       const int s = lh_slot(key, lab);
+                                       if (s >= 0) atomicAdd(&vadd[s], n); else atomicAdd(&cnt[lab], n);
+                                       vmax = max(vmax, lab);
                                    });
-    if (bg) scal[SC_HASBG] = 1;
+    if (vmax > 0) atomicMax(&s_max, vmax);
+    if (bg) s_bg = 1;
+    __syncthreads();
+    if (key[threadIdx.x]) atomicAdd(&cnt[key[threadIdx.x]], vadd[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        if (s_max > 0) atomicMax(&scal[SC_VMAX], s_max);
+        if (s_bg) scal[SC_HASBG] = 1;
+    }
 }
 
 // counts = unique(masks, return_counts=True)[1][1:]; remove label VALUE (i+1) where
@@ -949,19 +1050,27 @@ __global__ void k_copy_to_tmp(const int32_t *__restrict__ masks, PPLayout lay, v
 // ---------------------------------------------------------------------------
 __global__ void k_class_count(const int32_t *__restrict__ masks, const float *__restrict__ logits,
                               int ncls, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vadd[LH_SLOTS];           // key = label * PP_MAXCLS + class + 1
+    key[threadIdx.x] = 0; vadd[threadIdx.x] = 0;
+    __syncthreads();
     int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
     size_t t = blockIdx.y;
-    int lab = masks[t * lay.HW + idx];
-    if (lab <= 0) return;
-    const float *lg = logits + t * ncls * lay.HW + idx;
-    float best = lg[0];
-    int bi = 0;
-    for (int c = 1; c < ncls; ++c) {
-        float v = lg[(size_t)c * lay.HW];
-        if (v > best) { best = v; bi = c; }        // first maximum wins (np.argmax)
+    int *cls = WS(int, off_cls);
+    const int lab = idx < lay.HW ? masks[t * lay.HW + idx] : 0;
+    if (lab > 0) {
+        const float *lg = logits + t * ncls * lay.HW + idx;
+        float best = lg[0];
+        int bi = 0;
+        for (int c = 1; c < ncls; ++c) {
+            float v = lg[(size_t)c * lay.HW];
+            if (v > best) { best = v; bi = c; }        // first maximum wins (np.argmax)
+        }
+        const int k = lab * PP_MAXCLS + bi;
+        const int sl = lh_slot(key, k + 1);
+        if (sl >= 0) atomicAdd(&vadd[sl], 1); else atomicAdd(&cls[k], 1);
     }
-    atomicAdd(&WS(int, off_cls)[lab * PP_MAXCLS + bi], 1);
+    __syncthreads();
+    if (key[threadIdx.x]) atomicAdd(&cls[key[threadIdx.x] - 1], vadd[threadIdx.x]);
 }
 
 __global__ void k_class_pick(int ncls, PPLayout lay, void *ws) {
@@ -1013,18 +1122,8 @@ __global__ void k_to_u16(const int32_t *__restrict__ masks, uint16_t *__restrict
 }
 
 __global__ void k_rec_stats(const uint16_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt), *first = WS(int, off_first), *scal = WS(int, off_scal);
-    unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
-    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, lay.L,
-                   [&](int lab, int idx, int n, int y, int x) {
-                       int *bb = bbox + 4 * lab;
-                       atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
-                       atomicAdd(&cnt[lab], n);
-                       atomicAdd(&sumy[lab], (unsigned long long)n * y);
-                       atomicAdd(&sumx[lab], (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2));
-                       atomicMin(&first[lab], idx);
-                       atomicMax(&scal[SC_VMAX], lab);
-                   });
+    __shared__ LabStatsLds L;
+    lab_stats_pass<uint16_t, true>(masks + (size_t)blockIdx.y * lay.HW, lay.L, L, lay, ws);
 }
 
 __global__ void k_rec_write(const uint8_t *__restrict__ cm, int max_rec, cpx_record *__restrict__ rec,
