@@ -244,50 +244,66 @@ __global__ void k_seed_rank(PPLayout lay, void *ws) {
     WS(int, off_rank)[k] = r;
 }
 
-// 11x11 window, 5 x (3x3 dilation & (h > 2)); label = rank+1, later (larger) wins
-__global__ void k_seed_grow(PPLayout lay, void *ws) {
-    int n = min(WS(int, off_scal)[SC_NSEEDS], lay.L);
-    int k = blockIdx.x * NTHR + threadIdx.x;
-    if (k >= n) return;
+// 11x11 window, 5 x (3x3 dilation & (h > 2)); label = rank+1, later (larger) wins.
+// One WAVE per seed: the lanes fetch the 121 window counts two each, two ballots give the 11 "allowed" row masks to
+// every lane (the five dilations are then wave-uniform bit operations), and lane l writes window positions l and l + 64
+// (one thread per seed read its 121 counts one after the other: 35-40 us for ~650 seeds per batch).
+#define SEED_WGS 64                                         // x 4 waves: seeds k, k + 256, ... per wave
+__global__ void __launch_bounds__(NTHR) k_seed_grow(PPLayout lay, void *ws) {
+    const int n = min(WS(int, off_scal)[SC_NSEEDS], lay.L);
+    const int lane = threadIdx.x & 63;
     const int *h1 = WS(int, off_h1);
-    int p = WS(int, off_seed_pos)[k];
-    int label = WS(int, off_rank)[k] + 1;
-    int sy = p / lay.Wp, sx = p - sy * lay.Wp;
-    unsigned allowed[11], m[11];
-#pragma unroll
-    for (int r = 0; r < 11; ++r) {
-        unsigned a = 0;
-        int yy = sy - 5 + r;
-        for (int c = 0; c < 11; ++c) {
-            int xx = sx - 5 + c;
-            int h = ((unsigned)yy < (unsigned)lay.Hp && (unsigned)xx < (unsigned)lay.Wp) ? h1[yy * lay.Wp + xx] : 0;
-            a |= (h > 2 ? 1u : 0u) << c;
+    int *M1 = WS(int, off_M1);
+    for (int k = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6); k < n; k += gridDim.x * (NTHR / 64)) {
+        const int p = WS(int, off_seed_pos)[k];
+        const int label = WS(int, off_rank)[k] + 1;
+        const int sy = p / lay.Wp, sx = p - sy * lay.Wp;
+        bool a0 = false, a1 = false;
+        {
+            const int r = lane / 11, c = lane - r * 11, yy = sy - 5 + r, xx = sx - 5 + c;
+            a0 = (unsigned)yy < (unsigned)lay.Hp && (unsigned)xx < (unsigned)lay.Wp && h1[yy * lay.Wp + xx] > 2;
+            const int q = lane + 64;
+            if (q < 121) {
+                const int r1 = q / 11, c1 = q - r1 * 11, y1 = sy - 5 + r1, x1 = sx - 5 + c1;
+                a1 = (unsigned)y1 < (unsigned)lay.Hp && (unsigned)x1 < (unsigned)lay.Wp && h1[y1 * lay.Wp + x1] > 2;
+            }
         }
-        allowed[r] = a;
-        m[r] = 0;
-    }
-    m[5] = 1u << 5;
-#pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        unsigned hrow[11];
-#pragma unroll
-        for (int r = 0; r < 11; ++r) hrow[r] = (m[r] | (m[r] << 1) | (m[r] >> 1)) & 0x7FFu;
+        const unsigned long long b0 = __ballot(a0), b1 = __ballot(a1);      // window positions 0..63 and 64..120
+        unsigned allowed[11], m[11];
 #pragma unroll
         for (int r = 0; r < 11; ++r) {
-            unsigned v = hrow[r];
-            if (r > 0) v |= hrow[r - 1];
-            if (r < 10) v |= hrow[r + 1];
-            m[r] = v & allowed[r];
+            const int lo = 11 * r;                                           // bit position of (r, 0)
+            unsigned long long v;
+            if (lo + 11 <= 64) v = b0 >> lo;
+            else if (lo >= 64) v = b1 >> (lo - 64);
+            else v = (b0 >> lo) | (b1 << (64 - lo));
+            allowed[r] = (unsigned)v & 0x7FFu;
+            m[r] = 0;
         }
-    }
-    int *M1 = WS(int, off_M1);
+        m[5] = 1u << 5;
 #pragma unroll
-    for (int r = 0; r < 11; ++r) {
-        unsigned v = m[r];
-        while (v) {
-            int c = __ffs(v) - 1;
-            v &= v - 1;
-            atomicMax(&M1[(sy - 5 + r) * lay.Wp + (sx - 5 + c)], label);
+        for (int it = 0; it < 5; ++it) {
+            unsigned hrow[11];
+#pragma unroll
+            for (int r = 0; r < 11; ++r) hrow[r] = (m[r] | (m[r] << 1) | (m[r] >> 1)) & 0x7FFu;
+#pragma unroll
+            for (int r = 0; r < 11; ++r) {
+                unsigned v = hrow[r];
+                if (r > 0) v |= hrow[r - 1];
+                if (r < 10) v |= hrow[r + 1];
+                m[r] = v & allowed[r];
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q = lane + 64 * half;
+            if (q < 121) {
+                const int r = q / 11, c = q - r * 11;
+                unsigned row = 0;
+#pragma unroll
+                for (int rr = 0; rr < 11; ++rr) row = rr == r ? m[rr] : row;
+                if ((row >> c) & 1u) atomicMax(&M1[(sy - 5 + r) * lay.Wp + (sx - 5 + c)], label);
+            }
         }
     }
 }
@@ -770,18 +786,16 @@ __global__ void k_flow_err_pix(const int32_t *__restrict__ masks, const float *_
 }
 
 // scipy.ndimage.mean: per-label sums accumulated in raster order (np.bincount), / count
-// One WAVE per label: the lanes fetch 64 bbox pixels at a time (coalesced), then the wave adds the label's
-// values one by one in raster order -- np.bincount's sequential float64 summation -- by broadcasting lane
-// after lane (v_readlane); the old one-thread-per-label loop chased ~3 dependent loads per pixel (148 us).
-__device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), src_lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+// One WAVE per label: the lanes fetch 64 bbox pixels at a time (coalesced) and park (e_y, e_x) -- or (0, 0) for pixels
+// of other labels: the errors are squares, and s + 0.0 == s exactly -- in the wave's LDS slab; then every lane runs
+// np.bincount's sequential float64 summation over the slab (all lanes read the same address: a broadcast, and the two
+// dependent add chains are the only cost).  History: one thread per label chasing three dependent global loads per
+// pixel 148 us; lane-by-lane v_readlane broadcast 21 us.
+#define FE_SLAB 512                                         // pixels per wave slab (16 B each)
 __global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restrict__ masks, double thr,
                                                          double *__restrict__ errs_out, PPLayout lay, void *ws) {
-    const int lane = threadIdx.x & 63;
+    __shared__ double2 slab[NTHR / 64][FE_SLAB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int v = (blockIdx.x * NTHR + threadIdx.x) / 64 + 1;          // wave-uniform label
     if (v >= lay.L) return;
     const int n = WS(int, off_cnt)[v];
@@ -790,23 +804,25 @@ __global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restri
     const int y0 = bb[0], x0 = bb[1], bw = bb[3] - x0 + 1, npx = (bb[2] - y0 + 1) * bw;
     const int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
     const double *e = WS(double, off_e);
+    double2 *sl = slab[wv];
     double sy = 0.0, sx = 0.0;
-    for (int q0 = 0; q0 < npx; q0 += 64) {
-        const int q = q0 + lane;
-        bool in = false;
-        double ey = 0.0, ex = 0.0;
-        if (q < npx) {
-            const int ly = q / bw, p = (y0 + ly) * lay.W + x0 + (q - ly * bw);
-            in = m[p] == v;
-            if (in) { ey = e[p]; ex = e[lay.HW + p]; }
+    for (int q0 = 0; q0 < npx; q0 += FE_SLAB) {
+        const int cnt = min(FE_SLAB, npx - q0);
+        for (int j = lane; j < cnt; j += 64) {
+            const int q = q0 + j, ly = q / bw, p = (y0 + ly) * lay.W + x0 + (q - ly * bw);
+            double2 val = make_double2(0.0, 0.0);
+            if (m[p] == v) val = make_double2(e[p], e[lay.HW + p]);
+            sl[j] = val;
         }
-        unsigned long long todo = __ballot(in);
-        while (todo) {                                                 // ascending lanes = raster order
-            const int i = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            sy = sy + wave_bcast_f64(ey, i);
-            sx = sx + wave_bcast_f64(ex, i);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the slab is private to this wave
+#pragma unroll 8
+        for (int j = 0; j < cnt; ++j) {
+            const double2 val = sl[j];
+            sy = sy + val.x;
+            sx = sx + val.y;
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane != 0) return;
     double err = 0.0;
@@ -1201,7 +1217,7 @@ extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, doubl
     hipLaunchKernelGGL(k_hist, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, lay, ws);
     hipLaunchKernelGGL(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_seed_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_seed_grow, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    hipLaunchKernelGGL(k_seed_grow, dim3(SEED_WGS, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_gather, GRID_RUN(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
     double big = (double)((long long)H * W) * max_size_fraction;
     hipLaunchKernelGGL(k_big_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
