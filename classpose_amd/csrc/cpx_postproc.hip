@@ -335,7 +335,8 @@ __device__ __forceinline__ bool label_runs(const int (&lab)[RUN_PX], int base, i
     return bg;
 }
 template <typename T, typename F>
-__device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, int W, int limit, F &&f) {
+__device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, int W, int limit, F &&f,
+                                               int32_t *__restrict__ copy_to = nullptr) {
     const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
     if (base >= HW) return false;
     int lab[RUN_PX];
@@ -345,6 +346,11 @@ __device__ __forceinline__ bool for_label_runs(const T *__restrict__ m, int HW, 
     } else {
 #pragma unroll
         for (int i = 0; i < RUN_PX; ++i) lab[i] = base + i < HW ? (int)m[base + i] : 0;
+    }
+    if (copy_to) {                                       // a verbatim copy of the map on the way (fill-holes scratch)
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i)
+            if (base + i < HW) copy_to[base + i] = lab[i];
     }
     return label_runs(lab, base, HW, W, limit, f);
 }
@@ -419,17 +425,37 @@ __global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout la
     if (key[threadIdx.x]) atomicMin(&first[key[threadIdx.x]], vmin[threadIdx.x]);
 }
 
-// generic: first raster index per label (labels < L)
-__global__ void k_first(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+// generic: first raster index per label (labels < L); also clears the SC_NLAB scalar for the rank kernel that follows.
+// APPLY_FLAGS: labels whose flag is set are zeroed in the map on the way (the size filter's removal pass, one launch
+// instead of k_zero_flagged + k_first).
+template <bool APPLY_FLAGS>
+__global__ void k_first(int32_t *__restrict__ masks, PPLayout lay, void *ws) {
     __shared__ int key[LH_SLOTS], vmin[LH_SLOTS];
     key[threadIdx.x] = 0; vmin[threadIdx.x] = 0x7FFFFFFF;
+    if (blockIdx.x == 0 && threadIdx.x == 0) WS(int, off_scal)[SC_NLAB] = 0;
     __syncthreads();
     int *first = WS(int, off_first);
-    for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
-                   [&](int lab, int idx, int, int, int) {
-                       const int s = lh_slot(key, lab);
-                       if (s >= 0) atomicMin(&vmin[s], idx); else atomicMin(&first[lab], idx);
-                   });
+    int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
+    if (base < lay.HW) {
+        int lab[RUN_PX];
+        bool changed = false;
+        const int *flag = WS(int, off_flag);
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) {
+            lab[i] = base + i < lay.HW ? m[base + i] : 0;
+            if (APPLY_FLAGS && lab[i] > 0 && flag[lab[i]]) { lab[i] = 0; changed = true; }
+        }
+        if (APPLY_FLAGS && changed) {
+#pragma unroll
+            for (int i = 0; i < RUN_PX; ++i)
+                if (base + i < lay.HW) m[base + i] = lab[i];
+        }
+        label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int idx, int, int, int) {
+            const int sl = lh_slot(key, l);
+            if (sl >= 0) atomicMin(&vmin[sl], idx); else atomicMin(&first[l], idx);
+        });
+    }
     __syncthreads();
     if (key[threadIdx.x]) atomicMin(&first[key[threadIdx.x]], vmin[threadIdx.x]);
 }
@@ -456,8 +482,9 @@ __global__ void k_renumber_rank(int vmax_slot, PPLayout lay, void *ws) {
     atomicMax(&WS(int, off_scal)[SC_NLAB], r);
 }
 
-__global__ void k_relabel(int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+__global__ void k_relabel(int32_t *__restrict__ masks, int32_t *__restrict__ nlabels_out, PPLayout lay, void *ws) {
     int idx = blockIdx.x * NTHR + threadIdx.x;
+    if (idx == 0 && nlabels_out) nlabels_out[blockIdx.y] = WS(int, off_scal)[SC_NLAB];   // final after k_renumber_rank
     if (idx >= lay.HW) return;
     size_t t = blockIdx.y;
     int lab = masks[t * lay.HW + idx];
@@ -467,8 +494,11 @@ __global__ void k_relabel(int32_t *__restrict__ masks, PPLayout lay, void *ws) {
 __global__ void k_store_scalar(int slot, int32_t *__restrict__ out, PPLayout lay, void *ws) {
     if (threadIdx.x == 0) out[blockIdx.y] = WS(int, off_scal)[slot];
 }
-__global__ void k_copy_scalar(int dst, int src, PPLayout lay, void *ws) {
-    if (threadIdx.x == 0) WS(int, off_scal)[dst] = WS(int, off_scal)[src];
+__global__ void k_copy_scalar(int dst, int src, int zero_slot, PPLayout lay, void *ws) {
+    if (threadIdx.x == 0) {
+        WS(int, off_scal)[dst] = WS(int, off_scal)[src];
+        if (zero_slot >= 0) WS(int, off_scal)[zero_slot] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -483,7 +513,8 @@ struct LabStatsLds {
     int vmax;
 };
 template <typename T, bool REC>
-__device__ __forceinline__ void lab_stats_pass(const T *__restrict__ m, int limit, LabStatsLds &L, const PPLayout &lay, void *ws) {
+__device__ __forceinline__ void lab_stats_pass(const T *__restrict__ m, int limit, LabStatsLds &L, const PPLayout &lay, void *ws,
+                                               int32_t *copy_to = nullptr) {
     const int i = threadIdx.x;
     L.key[i] = 0; L.ymin[i] = 0x7FFFFFFF; L.xmin[i] = 0x7FFFFFFF; L.ymax[i] = -1; L.xmax[i] = -1; L.cnt[i] = 0;
     L.first[i] = 0x7FFFFFFF; L.sy[i] = 0; L.sx[i] = 0;
@@ -509,7 +540,7 @@ __device__ __forceinline__ void lab_stats_pass(const T *__restrict__ m, int limi
             if (REC) atomicMin(&first[lab], idx);
         }
         vmax = max(vmax, lab);
-    });
+    }, copy_to);
     if (REC && vmax > 0) atomicMax(&L.vmax, vmax);
     __syncthreads();
     const int lab = L.key[i];
@@ -522,9 +553,11 @@ __device__ __forceinline__ void lab_stats_pass(const T *__restrict__ m, int limi
     }
     if (REC && i == 0 && L.vmax > 0) atomicMax(&scal[SC_VMAX], L.vmax);
 }
-__global__ void k_lab_stats(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+// copy_to_tmp: also copy the map into the per-tile scratch plane the hole fill reads (was a kernel of its own)
+__global__ void k_lab_stats(const int32_t *__restrict__ masks, int copy_to_tmp, PPLayout lay, void *ws) {
     __shared__ LabStatsLds L;
-    lab_stats_pass<int32_t, false>(masks + (size_t)blockIdx.y * lay.HW, 0x7FFFFFFF, L, lay, ws);
+    lab_stats_pass<int32_t, false>(masks + (size_t)blockIdx.y * lay.HW, 0x7FFFFFFF, L, lay, ws,
+                                   copy_to_tmp ? WS(int32_t, off_tmp) : nullptr);
 }
 
 __global__ void k_init_stats(PPLayout lay, void *ws) {
@@ -598,6 +631,15 @@ __global__ void k_center_d2(const int32_t *__restrict__ masks, PPLayout lay, voi
     key[threadIdx.x] = 0; vmin[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull;
     __syncthreads();
     const int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
+    {   // per label (the grid has more threads than labels): n_iter = 2 * max(bbox extent sum), largest occupied label
+        const int v = blockIdx.x * NTHR + threadIdx.x + 1;
+        if (v < lay.L && cnt[v] > 0) {
+            const int *bb = bbox + 4 * v;
+            const int ext = (bb[2] - bb[0] + 1) + (bb[3] - bb[1] + 1) + 2;
+            atomicMax(&WS(int, off_scal)[SC_NITER], 2 * ext);
+            atomicMax(&WS(int, off_scal)[SC_VMAX], v);
+        }
+    }
     const unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
     unsigned long long *d2min = WS(unsigned long long, off_d2);
     for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
@@ -627,16 +669,6 @@ __global__ void k_center_pick(const int32_t *__restrict__ masks, PPLayout lay, v
         atomicMin(&WS(int, off_center)[lab], idx);
 }
 
-__global__ void k_niter(PPLayout lay, void *ws) {
-    int v = blockIdx.x * NTHR + threadIdx.x + 1;
-    if (v >= lay.L) return;
-    if (WS(int, off_cnt)[v] <= 0) return;
-    const int *bb = WS(int, off_bbox) + 4 * v;
-    int ext = (bb[2] - bb[0] + 1) + (bb[3] - bb[1] + 1) + 2;
-    atomicMax(&WS(int, off_scal)[SC_NITER], 2 * ext);
-    atomicMax(&WS(int, off_scal)[SC_VMAX], v);
-}
-
 // heat diffusion from the centre inside one label (fp64 Jacobi, 9-neighbour mean
 // summed in neighbour order 0..8 then / 9).  One workgroup per (label, tile).
 #define DIFF_LDS_CELLS 3584     // (bh+2)*(bw+2) <= this -> T ping-pong in LDS (56 KB) + flags
@@ -657,7 +689,7 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
     __shared__ double sT[2 * DIFF_LDS_CELLS];
     __shared__ unsigned short sIdx[DIFF_LDS_CELLS];
     __shared__ int sN;
-    // persistent over labels: a fixed grid of workgroups strides through 1..vmax (k_niter left the largest
+    // persistent over labels: a fixed grid of workgroups strides through 1..vmax (k_center_d2 left the largest
     // occupied label in SC_VMAX) instead of one 60 KB-LDS workgroup per POSSIBLE label (L-1 = H*W/11 of them,
     // ~99 % of which exited at once but still had to be dispatched and kept the GEMM workgroups off their CUs)
     const int vmax = min(WS(int, off_scal)[SC_VMAX], lay.L - 1);
@@ -1055,12 +1087,6 @@ __global__ void __launch_bounds__(NTHR) k_fill_serial(int32_t *__restrict__ mask
     }
 }
 
-__global__ void k_copy_to_tmp(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    WS(int32_t, off_tmp)[idx] = masks[(size_t)blockIdx.y * lay.HW + idx];
-}
-
 // ---------------------------------------------------------------------------
 // a15  class vote     a16  border removal     records
 // ---------------------------------------------------------------------------
@@ -1099,12 +1125,13 @@ __global__ void k_class_pick(int ncls, PPLayout lay, void *ws) {
 }
 
 __global__ void k_class_write(const int32_t *__restrict__ masks, uint8_t *__restrict__ cm,
-                              PPLayout lay, void *ws) {
+                              uint16_t *__restrict__ masks_u16, PPLayout lay, void *ws) {
     int idx = blockIdx.x * NTHR + threadIdx.x;
     if (idx >= lay.HW) return;
     size_t t = blockIdx.y;
     int lab = masks[t * lay.HW + idx];
     cm[t * lay.HW + idx] = lab > 0 ? (uint8_t)WS(int, off_remap)[lab] : 0;
+    if (masks_u16) masks_u16[t * lay.HW + idx] = (uint16_t)lab;      // the uint16 id map of cpx_compute_masks, same pass
 }
 
 __global__ void k_border_flag(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
@@ -1196,13 +1223,16 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
 }
 
 // zero labels flagged? no: shared tail "renumber by first appearance"
-static int pp_renumber(int32_t *masks, int nT, const PPLayout &lay, void *ws, hipStream_t s,
-                       bool first_already) {
+// mode 0: `first` is already final and SC_NLAB already cleared (get_masks: k_big_first + k_copy_scalar);
+// mode 1: plain k_first; mode 2: k_first that also zeroes the labels flagged by the size filter.
+// nlabels_out (nullable) receives the label count of every tile.
+static int pp_renumber(int32_t *masks, int nT, const PPLayout &lay, void *ws, hipStream_t s, int mode,
+                       int32_t *nlabels_out) {
     // (`first` was set to INT_MAX by the stage's PPI_STATS init and nothing has written it since)
-    if (!first_already) hipLaunchKernelGGL(k_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    pp_init(PPI_NLAB, nT, lay, ws, s);
+    if (mode == 1) hipLaunchKernelGGL(k_first<false>, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    else if (mode == 2) hipLaunchKernelGGL(k_first<true>, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_renumber_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, SC_VMAX, lay, ws);
-    hipLaunchKernelGGL(k_relabel, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_relabel, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, nlabels_out, lay, ws);
     return CPX_OK;
 }
 
@@ -1222,9 +1252,8 @@ extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, doubl
     double big = (double)((long long)H * W) * max_size_fraction;
     hipLaunchKernelGGL(k_big_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
     // labels here are seed ranks 1..nseeds
-    hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_VMAX, SC_NSEEDS, lay, ws);
-    pp_renumber(masks, nT, lay, ws, s, true);
-    if (nlabels) hipLaunchKernelGGL(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
+    hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_VMAX, SC_NSEEDS, SC_NLAB, lay, ws);
+    pp_renumber(masks, nT, lay, ws, s, 0, nlabels);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -1238,10 +1267,9 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     pp_init(PPI_SCAL | PPI_STATS | PPI_T, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 0, lay, ws);
     hipLaunchKernelGGL(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_niter, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_flow_err_pix, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, dP, lay, ws);
     hipLaunchKernelGGL(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, threshold, flow_errors, lay, ws);
@@ -1251,55 +1279,63 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
 }
 
 static void pp_size_filter(int32_t *masks, int nT, int min_size, const PPLayout &lay, void *ws,
-                           hipStream_t s) {
-    pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
+                           hipStream_t s, unsigned extra_init, int32_t *nlabels_out) {
+    pp_init(PPI_SCAL | PPI_STATS | extra_init, nT, lay, ws, s);
     hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
-    hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    pp_renumber(masks, nT, lay, ws, s, false);
+    pp_renumber(masks, nT, lay, ws, s, 2, nlabels_out);        // k_first<true> removes the flagged labels on the way
 }
 
-extern "C" int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int H, int W,
-                                                     int min_size, int32_t *nlabels, void *ws,
-                                                     void *stream) {
+// extra_init: PPI_* bits of the NEXT stage folded into this stage's last initialisation launch (cpx_compute_masks)
+static int fill_holes_impl(int32_t *masks, int nT, int H, int W, int min_size, int32_t *nlabels, void *ws,
+                           void *stream, unsigned extra_init) {
     int rc = pp_check(nT, H, W); if (rc) return rc;
     CPX_REQUIRE(masks && ws);
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s);
+    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s, 0, nullptr);
     else {   // labels may be non-contiguous: bbox loop below handles absent labels (slc None)
         pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
         hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-        hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, lay, ws);
+        hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, -1, lay, ws);
     }
     // find_objects(masks): bbox per label, then fill
     int nlab_saved_slot = SC_NLAB;
     (void)nlab_saved_slot;
     pp_init(PPI_STATS, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_copy_to_tmp, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 1, lay, ws);
     hipLaunchKernelGGL(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_fill_serial, dim3(1, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s);
-    if (nlabels) hipLaunchKernelGGL(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
+    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s, extra_init, nlabels);
+    else if (nlabels) hipLaunchKernelGGL(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
 
-extern "C" int cpx_compute_class_masks(const int32_t *masks, const float *logits, int nT, int ncls,
-                                       int H, int W, uint8_t *class_masks, void *ws, void *stream) {
+extern "C" int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int H, int W,
+                                                     int min_size, int32_t *nlabels, void *ws,
+                                                     void *stream) {
+    return fill_holes_impl(masks, nT, H, W, min_size, nlabels, ws, stream, 0);
+}
+
+static int class_masks_impl(const int32_t *masks, const float *logits, int nT, int ncls, int H, int W,
+                            uint8_t *class_masks, uint16_t *masks_u16, bool init, void *ws, void *stream) {
     int rc = pp_check(nT, H, W); if (rc) return rc;
     CPX_REQUIRE(masks && logits && class_masks && ws && ncls >= 1 && ncls <= PP_MAXCLS);
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    pp_init(PPI_CLS, nT, lay, ws, s);
+    if (init) pp_init(PPI_CLS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_class_count, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, logits, ncls, lay, ws);
     hipLaunchKernelGGL(k_class_pick, GRID_LAB(lay, nT), dim3(NTHR), 0, s, ncls, lay, ws);
-    hipLaunchKernelGGL(k_class_write, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
+    hipLaunchKernelGGL(k_class_write, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
+}
+extern "C" int cpx_compute_class_masks(const int32_t *masks, const float *logits, int nT, int ncls,
+                                       int H, int W, uint8_t *class_masks, void *ws, void *stream) {
+    return class_masks_impl(masks, logits, nT, ncls, H, W, class_masks, nullptr, true, ws, stream);
 }
 
 extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks, int nT, int H,
@@ -1336,17 +1372,17 @@ extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const f
         rc = cpx_remove_bad_flow_masks(masks, dP, nT, H, W, flow_threshold, nullptr, ws, stream);
         if (rc) return rc;
     }
-    rc = cpx_fill_holes_and_remove_small_masks(masks, nT, H, W, min_size, nlabels, ws, stream);
+    const bool vote = class_masks && logits && ncls > 1;
+    // the class-vote table is cleared by the size filter's last initialisation launch (one launch fewer)
+    rc = fill_holes_impl(masks, nT, H, W, min_size, nlabels, ws, stream, vote ? PPI_CLS : 0);
     if (rc) return rc;
-    if (class_masks) {
-        if (logits && ncls > 1) {
-            rc = cpx_compute_class_masks(masks, logits, nT, ncls, H, W, class_masks, ws, stream);
-            if (rc) return rc;
-        } else {
-            CPX_HIP(hipMemsetAsync(class_masks, 0, n, s));
-        }
+    if (vote) {       // k_class_write also emits the uint16 id map
+        rc = class_masks_impl(masks, logits, nT, ncls, H, W, class_masks, masks_u16, false, ws, stream);
+        if (rc) return rc;
+    } else {
+        if (class_masks) CPX_HIP(hipMemsetAsync(class_masks, 0, n, s));
+        hipLaunchKernelGGL(k_to_u16, dim3(cpx_cdiv((long long)n, NTHR)), dim3(NTHR), 0, s, masks, masks_u16, n);
     }
-    hipLaunchKernelGGL(k_to_u16, dim3(cpx_cdiv((long long)n, NTHR)), dim3(NTHR), 0, s, masks, masks_u16, n);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
