@@ -229,22 +229,8 @@ __global__ void k_seeds(PPLayout lay, void *ws) {
     }
 }
 
-// rank = position in the stable ascending sort by (count, raster index)
-__global__ void k_seed_rank(PPLayout lay, void *ws) {
-    int n = min(WS(int, off_scal)[SC_NSEEDS], lay.L);
-    int k = blockIdx.x * NTHR + threadIdx.x;
-    if (k >= n) return;
-    const int *pos = WS(int, off_seed_pos);
-    const int *cnt = WS(int, off_seed_cnt);
-    int c = cnt[k], p = pos[k], r = 0;
-    for (int j = 0; j < n; ++j) {
-        int cj = cnt[j], pj = pos[j];
-        r += (cj < c) || (cj == c && pj < p);
-    }
-    WS(int, off_rank)[k] = r;
-}
-
-// 11x11 window, 5 x (3x3 dilation & (h > 2)); label = rank+1, later (larger) wins.
+// 11x11 window, 5 x (3x3 dilation & (h > 2)); label = rank+1, later (larger) wins; rank = the seed's position in the
+// stable ascending sort by (count, raster index), counted by the wave over all seeds (was a kernel of its own).
 // One WAVE per seed: the lanes fetch the 121 window counts two each, two ballots give the 11 "allowed" row masks to
 // every lane (the five dilations are then wave-uniform bit operations), and lane l writes window positions l and l + 64
 // (one thread per seed read its 121 counts one after the other: 35-40 us for ~650 seeds per batch).
@@ -256,7 +242,17 @@ __global__ void __launch_bounds__(NTHR) k_seed_grow(PPLayout lay, void *ws) {
     int *M1 = WS(int, off_M1);
     for (int k = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6); k < n; k += gridDim.x * (NTHR / 64)) {
         const int p = WS(int, off_seed_pos)[k];
-        const int label = WS(int, off_rank)[k] + 1;
+        int label = 1;
+        {
+            const int *pos = WS(int, off_seed_pos), *cnt = WS(int, off_seed_cnt);
+            const int c = cnt[k];
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                bool before = false;
+                if (j < n) { const int cj = cnt[j], pj = pos[j]; before = (cj < c) || (cj == c && pj < p); }
+                label += (int)__popcll(__ballot(before));
+            }
+        }
         const int sy = p / lay.Wp, sx = p - sy * lay.Wp;
         bool a0 = false, a1 = false;
         {
@@ -411,6 +407,10 @@ __global__ void k_big_first(int32_t *__restrict__ masks, double big, PPLayout la
     __shared__ int key[LH_SLOTS], vmin[LH_SLOTS];
     key[threadIdx.x] = 0; vmin[threadIdx.x] = 0x7FFFFFFF;
     __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {       // labels are seed ranks 1..nseeds; clear the count for the rank kernel
+        WS(int, off_scal)[SC_VMAX] = WS(int, off_scal)[SC_NSEEDS];
+        WS(int, off_scal)[SC_NLAB] = 0;
+    }
     const int *cnt = WS(int, off_cnt);
     int *first = WS(int, off_first);
     int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
@@ -792,40 +792,17 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
   }
 }
 
-// per-pixel squared error between mask-derived unit flows and network flows / 5
-__global__ void k_flow_err_pix(const int32_t *__restrict__ masks, const float *__restrict__ dP,
-                               PPLayout lay, void *ws) {
-    int idx = blockIdx.x * NTHR + threadIdx.x;
-    if (idx >= lay.HW) return;
-    size_t t = blockIdx.y;
-    int lab = masks[t * lay.HW + idx];
-    if (lab <= 0) return;
-    int y = idx / lay.W, x = idx - y * lay.W;
-    const double *T = WS(double, off_T);
-    int c = (y + 1) * lay.TW + (x + 1);
-    double dy = T[c + lay.TW] - T[c - lay.TW];
-    double dx = T[c + 1] - T[c - 1];
-    double a = dy * dy;
-    double b = dx * dx;
-    double den = 1e-60 + sqrt(a + b);
-    double muy = dy / den, mux = dx / den;
-    double vy = (double)__fdiv_rn(dP[(t * 2 + 0) * lay.HW + idx], 5.0f);
-    double vx = (double)__fdiv_rn(dP[(t * 2 + 1) * lay.HW + idx], 5.0f);
-    double ey = muy - vy, ex = mux - vx;
-    double *e = WS(double, off_e);
-    e[idx] = ey * ey;
-    e[lay.HW + idx] = ex * ex;
-}
-
 // scipy.ndimage.mean: per-label sums accumulated in raster order (np.bincount), / count
-// One WAVE per label: the lanes fetch 64 bbox pixels at a time (coalesced) and park (e_y, e_x) -- or (0, 0) for pixels
-// of other labels: the errors are squares, and s + 0.0 == s exactly -- in the wave's LDS slab; then every lane runs
+// The per-pixel errors are the squared differences between the unit flows derived from the diffusion result T (central
+// differences, / (1e-60 + norm)) and the network flows / 5.
+// One WAVE per label: the lanes take 64 bbox pixels at a time (coalesced), compute (e_y, e_x) -- or (0, 0) for pixels
+// of other labels: the errors are squares, and s + 0.0 == s exactly -- into the wave's LDS slab; then every lane runs
 // np.bincount's sequential float64 summation over the slab (all lanes read the same address: a broadcast, and the two
 // dependent add chains are the only cost).  History: one thread per label chasing three dependent global loads per
 // pixel 148 us; lane-by-lane v_readlane broadcast 21 us.
 #define FE_SLAB 512                                         // pixels per wave slab (16 B each)
-__global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restrict__ masks, double thr,
-                                                         double *__restrict__ errs_out, PPLayout lay, void *ws) {
+__global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restrict__ masks, const float *__restrict__ dP,
+                                                         double thr, double *__restrict__ errs_out, PPLayout lay, void *ws) {
     __shared__ double2 slab[NTHR / 64][FE_SLAB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int v = (blockIdx.x * NTHR + threadIdx.x) / 64 + 1;          // wave-uniform label
@@ -835,7 +812,8 @@ __global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restri
     const int *bb = WS(int, off_bbox) + 4 * v;
     const int y0 = bb[0], x0 = bb[1], bw = bb[3] - x0 + 1, npx = (bb[2] - y0 + 1) * bw;
     const int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
-    const double *e = WS(double, off_e);
+    const double *T = WS(double, off_T);
+    const size_t t = blockIdx.y;
     double2 *sl = slab[wv];
     double sy = 0.0, sx = 0.0;
     for (int q0 = 0; q0 < npx; q0 += FE_SLAB) {
@@ -843,7 +821,19 @@ __global__ void __launch_bounds__(NTHR) k_flow_err_label(const int32_t *__restri
         for (int j = lane; j < cnt; j += 64) {
             const int q = q0 + j, ly = q / bw, p = (y0 + ly) * lay.W + x0 + (q - ly * bw);
             double2 val = make_double2(0.0, 0.0);
-            if (m[p] == v) val = make_double2(e[p], e[lay.HW + p]);
+            if (m[p] == v) {
+                const int c = (y0 + ly + 1) * lay.TW + (x0 + (q - ly * bw) + 1);
+                const double dy = T[c + lay.TW] - T[c - lay.TW];
+                const double dx = T[c + 1] - T[c - 1];
+                const double a = dy * dy;
+                const double b = dx * dx;
+                const double den = 1e-60 + sqrt(a + b);
+                const double muy = dy / den, mux = dx / den;
+                const double vy = (double)__fdiv_rn(dP[(t * 2 + 0) * lay.HW + p], 5.0f);
+                const double vx = (double)__fdiv_rn(dP[(t * 2 + 1) * lay.HW + p], 5.0f);
+                const double ey = muy - vy, ex = mux - vx;
+                val = make_double2(ey * ey, ex * ex);
+            }
             sl[j] = val;
         }
         __builtin_amdgcn_wave_barrier();
@@ -882,19 +872,38 @@ __global__ void k_zero_f64(size_t off, int n, PPLayout lay, void *ws) {
 // ---------------------------------------------------------------------------
 // a14  fill_holes_and_remove_small_masks
 // ---------------------------------------------------------------------------
-__global__ void k_count_labels(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+// err_thr_on: labels whose flow error (off_err, written by k_flow_err_label) exceeds err_thr are removed from the map on
+// the way -- the flow-error filter's removal pass when cpx_compute_masks chains the stages (one launch fewer).
+__global__ void k_count_labels(int32_t *__restrict__ masks, int err_thr_on, double err_thr, PPLayout lay, void *ws) {
     __shared__ int key[LH_SLOTS], vadd[LH_SLOTS], s_max, s_bg;
     key[threadIdx.x] = 0; vadd[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_max = 0; s_bg = 0; }
     __syncthreads();
     int *cnt = WS(int, off_cnt), *scal = WS(int, off_scal);
+    int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
     int vmax = 0;
-    const bool bg = for_label_runs(masks + (size_t)blockIdx.y * lay.HW, lay.HW, lay.W, 0x7FFFFFFF,
-                                   [&](int lab, int, int n, int, int) {
-                                       const int s = lh_slot(key, lab);
-                                       if (s >= 0) atomicAdd(&vadd[s], n); else atomicAdd(&cnt[lab], n);
-                                       vmax = max(vmax, lab);
-                                   });
+    bool bg = false;
+    if (base < lay.HW) {
+        int lab[RUN_PX];
+        bool changed = false;
+        const double *err = WS(double, off_err);
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) {
+            lab[i] = base + i < lay.HW ? m[base + i] : 0;
+            if (err_thr_on && lab[i] > 0 && err[lab[i]] > err_thr) { lab[i] = 0; changed = true; }
+        }
+        if (changed) {
+#pragma unroll
+            for (int i = 0; i < RUN_PX; ++i)
+                if (base + i < lay.HW) m[base + i] = lab[i];
+        }
+        bg = label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int, int n, int, int) {
+            const int s = lh_slot(key, l);
+            if (s >= 0) atomicAdd(&vadd[s], n); else atomicAdd(&cnt[l], n);
+            vmax = max(vmax, l);
+        });
+    }
     if (vmax > 0) atomicMax(&s_max, vmax);
     if (bg) s_bg = 1;
     __syncthreads();
@@ -1164,8 +1173,9 @@ __global__ void k_to_u16(const int32_t *__restrict__ masks, uint16_t *__restrict
     if (idx < n) out[idx] = (uint16_t)masks[idx];
 }
 
-__global__ void k_rec_stats(const uint16_t *__restrict__ masks, PPLayout lay, void *ws) {
+__global__ void k_rec_stats(const uint16_t *__restrict__ masks, int32_t *__restrict__ counts, PPLayout lay, void *ws) {
     __shared__ LabStatsLds L;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[blockIdx.y] = 0;      // k_rec_write raises it with atomicMax
     lab_stats_pass<uint16_t, true>(masks + (size_t)blockIdx.y * lay.HW, lay.L, L, lay, ws);
 }
 
@@ -1246,21 +1256,18 @@ extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, doubl
     pp_init(PPI_PAD | PPI_SCAL | PPI_STATS, nT, lay, ws, s);
     hipLaunchKernelGGL(k_hist, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, lay, ws);
     hipLaunchKernelGGL(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_seed_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_seed_grow, dim3(SEED_WGS, nT), dim3(NTHR), 0, s, lay, ws);
     hipLaunchKernelGGL(k_gather, GRID_RUN(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
     double big = (double)((long long)H * W) * max_size_fraction;
     hipLaunchKernelGGL(k_big_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
-    // labels here are seed ranks 1..nseeds
-    hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_VMAX, SC_NSEEDS, SC_NLAB, lay, ws);
     pp_renumber(masks, nT, lay, ws, s, 0, nlabels);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
 
-extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT, int H, int W,
-                                         double threshold, double *flow_errors, void *ws,
-                                         void *stream) {
+// defer_zero: leave the flagged labels in the map; the caller's next pass (k_count_labels with apply_flags) removes them
+static int bad_flow_impl(int32_t *masks, const float *dP, int nT, int H, int W, double threshold,
+                         double *flow_errors, void *ws, void *stream, bool defer_zero) {
     int rc = pp_check(nT, H, W); if (rc) return rc;
     CPX_REQUIRE(masks && dP && ws);
     hipStream_t s = (hipStream_t)stream;
@@ -1271,33 +1278,38 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
     hipLaunchKernelGGL(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_flow_err_pix, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, dP, lay, ws);
-    hipLaunchKernelGGL(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, threshold, flow_errors, lay, ws);
-    hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, dP, threshold, flow_errors, lay, ws);
+    if (!defer_zero) hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
+extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT, int H, int W,
+                                         double threshold, double *flow_errors, void *ws,
+                                         void *stream) {
+    return bad_flow_impl(masks, dP, nT, H, W, threshold, flow_errors, ws, stream, false);
+}
 
 static void pp_size_filter(int32_t *masks, int nT, int min_size, const PPLayout &lay, void *ws,
-                           hipStream_t s, unsigned extra_init, int32_t *nlabels_out) {
+                           hipStream_t s, unsigned extra_init, int32_t *nlabels_out, double err_thr = 0.0) {
     pp_init(PPI_SCAL | PPI_STATS | extra_init, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, err_thr > 0 ? 1 : 0, err_thr, lay, ws);
     hipLaunchKernelGGL(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
     pp_renumber(masks, nT, lay, ws, s, 2, nlabels_out);        // k_first<true> removes the flagged labels on the way
 }
 
 // extra_init: PPI_* bits of the NEXT stage folded into this stage's last initialisation launch (cpx_compute_masks)
+// pending_err_thr > 0: the flow-error filter left its flagged labels in the map (bad_flow_impl, defer_zero)
 static int fill_holes_impl(int32_t *masks, int nT, int H, int W, int min_size, int32_t *nlabels, void *ws,
-                           void *stream, unsigned extra_init) {
+                           void *stream, unsigned extra_init, double pending_err_thr) {
     int rc = pp_check(nT, H, W); if (rc) return rc;
     CPX_REQUIRE(masks && ws);
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s, 0, nullptr);
+    if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s, 0, nullptr, pending_err_thr);
     else {   // labels may be non-contiguous: bbox loop below handles absent labels (slc None)
         pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
-        hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+        hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, pending_err_thr > 0 ? 1 : 0, pending_err_thr, lay, ws);
         hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, -1, lay, ws);
     }
     // find_objects(masks): bbox per label, then fill
@@ -1316,7 +1328,7 @@ static int fill_holes_impl(int32_t *masks, int nT, int H, int W, int min_size, i
 extern "C" int cpx_fill_holes_and_remove_small_masks(int32_t *masks, int nT, int H, int W,
                                                      int min_size, int32_t *nlabels, void *ws,
                                                      void *stream) {
-    return fill_holes_impl(masks, nT, H, W, min_size, nlabels, ws, stream, 0);
+    return fill_holes_impl(masks, nT, H, W, min_size, nlabels, ws, stream, 0, 0.0);
 }
 
 static int class_masks_impl(const int32_t *masks, const float *logits, int nT, int ncls, int H, int W,
@@ -1368,13 +1380,13 @@ extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const f
     if (rc) return rc;
     rc = cpx_get_masks(p_final, nT, H, W, max_size_fraction, masks, nullptr, ws, stream);
     if (rc) return rc;
-    if (flow_threshold > 0) {
-        rc = cpx_remove_bad_flow_masks(masks, dP, nT, H, W, flow_threshold, nullptr, ws, stream);
+    if (flow_threshold > 0) {      // the flagged labels are removed by the size filter's counting pass below
+        rc = bad_flow_impl(masks, dP, nT, H, W, flow_threshold, nullptr, ws, stream, true);
         if (rc) return rc;
     }
     const bool vote = class_masks && logits && ncls > 1;
     // the class-vote table is cleared by the size filter's last initialisation launch (one launch fewer)
-    rc = fill_holes_impl(masks, nT, H, W, min_size, nlabels, ws, stream, vote ? PPI_CLS : 0);
+    rc = fill_holes_impl(masks, nT, H, W, min_size, nlabels, ws, stream, vote ? PPI_CLS : 0, flow_threshold > 0 ? flow_threshold : 0.0);
     if (rc) return rc;
     if (vote) {       // k_class_write also emits the uint16 id map
         rc = class_masks_impl(masks, logits, nT, ncls, H, W, class_masks, masks_u16, false, ws, stream);
@@ -1395,9 +1407,8 @@ extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *cl
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    CPX_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * nT, s));
     pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_rec_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks_u16, lay, ws);
+    hipLaunchKernelGGL(k_rec_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks_u16, counts, lay, ws);
     hipLaunchKernelGGL(k_rec_write, GRID_LAB(lay, nT), dim3(NTHR), 0, s, class_masks, max_rec, records, counts, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
