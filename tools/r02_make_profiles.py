@@ -16,7 +16,8 @@ gemm_bytes = lambda n, k, extra=0: 2.0 * (M * k + n * k + M * n) + extra
 # kernel-name prefix -> (what, algorithmic flops per launch, algorithmic bytes per launch)
 KERNELS = [
     ("void k_gemm256p<1, false, 1>", "mlp.lin1 (fc1, GELU + folded LayerNorm)", gemm_flops(HID, C), gemm_bytes(HID, C)),
-    ("void k_gemm256<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm)", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
+    ("void k_gemm256p<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), persistent with the balanced tile list", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
+    ("void k_gemm256<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), one workgroup per tile", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
     ("void k_gemm256p<2, false, 2>", "attn.proj and mlp.lin2 (residual + row statistics), average of both",
      (gemm_flops(C, C) + gemm_flops(C, HID)) / 2, (gemm_bytes(C, C, 2 * M * C) + gemm_bytes(C, HID, 2 * M * C)) / 2),
     ("void k_attention4p<false>", "rel-pos flash attention (4-wave, LDS-DMA ring; production variant 2)",
