@@ -97,6 +97,7 @@ SIGNATURES = {
     "cpx_layernorm": (_i, [_i, _p, _p, _p, _i, _i, _f, _p, _p]),
     "cpx_attention": (_i, [_i, _p, _p, _p, _i, _p, _p, _p]),
     "cpx_gemm_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "cpx_conv3x3": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p]),
     "cpx_gemm_ln": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_row_stats": (_i, [_p, _i, _p, _p]),
     "cpx_layernorm_bf16": (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),

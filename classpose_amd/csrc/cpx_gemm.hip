@@ -1203,6 +1203,11 @@ int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C
     return CPX_OK;
 }
 
+extern "C" int cpx_conv3x3(int dtype, const void *x, const void *Wt, int M, int N, int C, int epilogue, const float *bias,
+                           void *out, int ld_out, void *stream) {
+    return cpx_conv3_half(dtype, x, Wt, M, N, C, epilogue, bias, out, ld_out, stream);
+}
+
 extern "C" int cpx_gemm_ln(const void *A, const void *Wt, int M, int N, int K, int epilogue,
                            const float *bias, const void *aux, void *out, int ld_out,
                            const float *ln_stats, const float *ln_colsum, float *stats_out, void *stream) {

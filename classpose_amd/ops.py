@@ -247,6 +247,17 @@ def gemm(A: torch.Tensor, Wt: torch.Tensor, epilogue: str = "bf16", bias=None, a
 _DT = {torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16, torch.float32: _lib.DT_F32}
 
 
+def conv3x3(x: torch.Tensor, Wt: torch.Tensor, epilogue: str = "bf16", bias=None):
+    """3x3 / padding-1 convolution over 32 x 32-token images as an implicit GEMM: x (S*1024, C) token-major,
+    Wt (N, 9*C) with k = (3 ky + kx) * C + c (``weight.permute(0, 2, 3, 1).reshape(N, 9 * C)`` of a Conv2d)."""
+    M, Cc = x.shape
+    N = Wt.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cpx_conv3x3(_DT[x.dtype], ptr(x), ptr(Wt), M, N, Cc, EPI[epilogue], ptr(bias), ptr(out), N,
+                                 _stream(x.device)), "conv3x3")
+    return out
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6):
     out = torch.empty_like(x)
     check(_lib.lib().cpx_layernorm(_DT[x.dtype], ptr(x), ptr(w), ptr(b), x.shape[0], x.shape[1], eps, ptr(out),

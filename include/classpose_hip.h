@@ -252,6 +252,15 @@ int cpx_gemm_bf16(const void *A, const void *Wt, int M, int N, int K, int epilog
  * QKV epilogue is the plain one: the f32 attention reads V from the qkv rows), K % 16 == 0.  */
 int cpx_gemm(int dtype, const void *A, const void *Wt, int M, int N, int K, int epilogue,
              const float *bias, const void *resid_or_pos, void *out, int ld_out, void *stream);
+
+/* 3x3 convolution, padding 1, over 32 x 32-token images as an IMPLICIT GEMM (the neck's Conv2d(256, 256, 3, padding=1,
+ * bias=False) of the SAM image encoder; cellpose vit_sam.Transformer): x [M = S*1024][C] token-major
+ * (token = 32 y + x), Wt [N][9*C] with k = (3 ky + kx) * C + c, out [M][ld_out] bf16 / fp16.  No im2col buffer: the
+ * LDS-DMA of every K tile reads the shifted token's chunk, or a zero chunk outside the image; the accumulation order is
+ * that of cpx_gemm on the materialised [M][9*C] operand (bitwise equal).  M % 1024 == 0, N % 128 == 0, C % 64 == 0,
+ * epilogue CPX_EPI_BF16 or CPX_EPI_RELU_BF16, dtype CPX_DT_BF16 / CPX_DT_F16.                                      */
+int cpx_conv3x3(int dtype, const void *x, const void *Wt, int M, int N, int C, int epilogue, const float *bias,
+                void *out, int ld_out, void *stream);
 int cpx_gemm_uses_big_tile(int M, int N, int K, int epilogue);
 /* Same with a LayerNorm over the K = 1024 input row folded in (consumer) and/or partial row
  * statistics of the output emitted (producer, RESID epilogue, N = 1024, 256^2-tile shapes):

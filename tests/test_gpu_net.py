@@ -514,3 +514,29 @@ def test_attention_variants_repeatable_and_agree(cuda, variant):
     bias = (torch.einsum("nhwc,hkc->nhwk", qhw, R)[..., :, None] + torch.einsum("nhwc,wkc->nhwk", qhw, R)[..., None, :]).reshape(16, 1024, 1024)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125 + bias, -1) @ v).transpose(0, 1).reshape(1024, 1024)
     assert _rel(first[:1024].double(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv3x3_implicit_gemm(cuda, dtype):
+    """cpx_conv3x3 (the neck's 3x3 conv without an im2col buffer): bitwise equal to cpx_gemm on the materialised
+    [M][9 C] operand (same K order, same accumulation) and within half-precision rounding of torch's conv2d."""
+    g = torch.Generator().manual_seed(5)
+    S, Cc, N = 3, 256, 256
+    x = torch.randn(S * 1024, Cc, generator=g).to(dtype).to(cuda)
+    w4 = (torch.randn(N, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5).to(dtype)
+    Wt = w4.permute(0, 2, 3, 1).reshape(N, 9 * Cc).contiguous().to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    for epi, b in (("bf16", None), ("relu", bias)):
+        got = ops.conv3x3(x, Wt, epi, b)
+        img = x.view(S, 32, 32, Cc)
+        pad = torch.zeros((S, 34, 34, Cc), dtype=dtype, device=cuda)
+        pad[:, 1:33, 1:33] = img
+        col = torch.cat([pad[:, ky:ky + 32, kx:kx + 32] for ky in range(3) for kx in range(3)], -1).reshape(S * 1024, 9 * Cc).contiguous()
+        want = ops.gemm(col, Wt, epi, b)
+        assert torch.equal(got, want)
+        ref = torch.nn.functional.conv2d(img.permute(0, 3, 1, 2).float(), w4.float().to(cuda), b, padding=1)
+        if epi == "relu":
+            ref = ref.relu()
+        ref = ref.permute(0, 2, 3, 1).reshape(S * 1024, N)
+        err = (got.float() - ref).abs().max().item()
+        assert err < (3e-2 if dtype == torch.bfloat16 else 4e-3), err
