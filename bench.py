@@ -315,7 +315,7 @@ def main():
                                "timed region, flow-injection dynamics" % (args.depth, bt),
                    "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * eng.n_sub,
                    "tiles_per_step": bt, "distinct_batches": n_distinct, "records_gathered": int(allrec.shape[0])},
-        "roofline": {"bound": "mfma", "kernel": "k_gemm256<GELU> (mlp.lin1 %dx4096x1024)" % M,
+        "roofline": {"bound": "mfma", "kernel": "k_gemm256p<GELU> = void k_gemm256p<1, false, 1>(GemmArgs) (mlp.lin1 %dx4096x1024)" % M,
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % traffic_src,
