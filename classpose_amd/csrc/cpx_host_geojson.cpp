@@ -5,7 +5,7 @@
 // (:1336-1374) -- byte for byte what CPython's json encoder emits (", " / ": " separators, float.__repr__ numbers),
 // apart from the random uuid4 ids.  The reference builds ~2 M dicts and dumps them in one call; at 40k x 40k this file
 // pair is 2.6 GB and the Python loop that streamed it was the serial tail of the CLI (28 s against a 12 s tile loop
-// on 8 GPUs).  Here the kept cells are split into chunks, worker threads format chunks into memory, and the chunks are
+// on 8 GPUs).  Here the kept cells are split into chunks of 4 096, worker threads format chunks into memory, and the chunks are
 // written in order.  Pure host code: no HIP calls; ctypes releases the GIL around it.
 #include <atomic>
 #include <charconv>
@@ -184,7 +184,7 @@ extern "C" int cpx_write_geojson(const char *contours_path, const char *centroid
               std::fwrite(head, 1, sizeof head - 1, f2) == sizeof head - 1;
     Job job{(const Row *)cells, centroids_xy, xy_pool, offsets, keep, class_json, n_class_json,
             bounds_x, bounds_y, bounds_x != 0 || bounds_y != 0};
-    const int64_t CH = 8192;
+    const int64_t CH = 4096;                   // cells per chunk (~4 MB of contour text)
     const int64_t n_chunks = (n_keep + CH - 1) / CH;
     int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
@@ -192,7 +192,7 @@ extern "C" int cpx_write_geojson(const char *contours_path, const char *centroid
     if ((int64_t)nt > n_chunks) nt = (int)(n_chunks > 0 ? n_chunks : 1);
     // workers take chunks in order and hand their text to the writer (this thread) through a bounded window,
     // so at most `window` chunks are in memory whatever the size of the slide
-    const int64_t window = 4 * nt;
+    const int64_t window = 2 * nt + 2;         // <= 34 chunks in flight: bounded memory when the disk is the slow side
     std::vector<std::string> out1((size_t)window), out2((size_t)window);
     std::vector<char> ready((size_t)window, 0);
     std::mutex mu;

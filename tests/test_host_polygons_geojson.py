@@ -195,7 +195,7 @@ def test_native_writer_is_bytewise_json_dump(tmp_path):
 
 
 def test_native_writer_many_chunks(tmp_path):
-    """more cells than one 8192-cell chunk and more chunks than the in-memory window: order and separators hold"""
+    """more cells than one chunk and more chunks than the in-memory window: order and separators hold"""
     import json
     from classpose_amd.entrypoints.predict_wsi import CELL_ROW
     n = 8192 * 9 + 17
