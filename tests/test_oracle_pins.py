@@ -169,3 +169,38 @@ def test_net_oracle_shapes_and_dtype():
     outb = net.class_transformer_forward(sdb, x, torch.bfloat16)
     rel = (outb - out).norm() / out.norm()
     assert rel < 3e-2
+
+
+def test_host_logic_matches_reference_goldens():
+    """a1 / a5 host logic against outputs of the reference's own functions (tests/golden/make_golden_host.py):
+    get_slide_resolution (utils.py:285-331) incl. its error messages, infer_structure (predict_wsi.py:1377-1419) on
+    the key layouts of synthetic checkpoints the reference itself loaded, resolve_precision (models.py:37-69)."""
+    import json
+    import os
+    import types
+
+    import torch
+
+    from classpose_amd import engine, models, wsi
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    for c in g["get_slide_resolution"]:
+        slide = types.SimpleNamespace(properties=c["properties"])
+        if "error" in c:
+            with pytest.raises(ValueError) as e:
+                wsi.get_slide_resolution(slide)
+            assert c["error"] == "ValueError" and str(e.value) == c["message"]
+        else:
+            assert list(wsi.get_slide_resolution(slide)) == c["mpp"]           # same float operations, same bits
+    for c in g["infer_structure"]:
+        sd = {k: torch.empty(shape, device="meta") for k, shape in c["keys"].items()}
+        fts, ncls, depth = engine.NetWeights.infer_structure(sd)
+        assert (fts, ncls, depth) == (c["fts"], c["n_classes"], 1)
+    names = {"torch.float32": "fp32", "torch.float16": "fp16", "torch.bfloat16": "bf16"}
+    for c in g["resolve_precision"]:
+        if "error" in c:
+            with pytest.raises(ValueError) as e:
+                models.resolve_precision(c["precision"], torch.device("cpu"))
+            assert str(e.value) == c["message"]
+        else:
+            assert models.resolve_precision(c["precision"], torch.device("cpu")) == names[c["dtype"]]
