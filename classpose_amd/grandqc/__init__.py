@@ -623,6 +623,22 @@ def artefact_class_map(image: np.ndarray, tissue_mask_art: np.ndarray, net: QcNe
     return out
 
 
+def create_geojson_feature(contour_points: np.ndarray, scaling_factors, classification_name: str,
+                           classification_color: list[int]):
+    """wsi_qc_helpers.create_geojson_feature (:49-88): contour x scale -> closed ring -> QuPath annotation feature;
+    None for fewer than 4 points."""
+    scaled = np.asarray(contour_points) * np.asarray(scaling_factors)
+    if len(scaled) < 4:
+        return None
+    pts = scaled.tolist()
+    if pts[0] != pts[-1]:
+        pts.append(pts[0])
+    return {"type": "Feature", "id": str(uuid.uuid4()),
+            "geometry": {"type": "Polygon", "coordinates": [pts]},
+            "properties": {"objectType": "annotation", "isLocked": False,
+                           "classification": {"name": classification_name, "color": classification_color}}}
+
+
 def artefact_contours(artefact_mask: np.ndarray, scaling):
     """per-class RETR_CCOMP contours (:252-325): GeoJSON features for classes 1-6, filter polygons
     (``artefact_cnts``) for classes 2-6 with area > 10 px"""
@@ -640,14 +656,8 @@ def artefact_contours(artefact_mask: np.ndarray, scaling):
             if cv >= 2 and contour_area(cnt) <= 10:
                 n_small += 1
                 continue
-            pts = (cnt * scaling).tolist()
-            if pts[0] != pts[-1]:
-                pts.append(pts[0])
-            geojson["features"].append({"type": "Feature", "id": str(uuid.uuid4()),
-                                        "geometry": {"type": "Polygon", "coordinates": [pts]},
-                                        "properties": {"objectType": "annotation", "isLocked": False,
-                                                       "classification": {"name": ARTIFACT_CLASS_MAPPING.get(cv, "Unknown"),
-                                                                          "color": ARTIFACT_COLORS[cv]}}})
+            geojson["features"].append(create_geojson_feature(cnt, scaling, ARTIFACT_CLASS_MAPPING.get(cv, "Unknown"),
+                                                              ARTIFACT_COLORS[cv]))
             if 2 <= cv <= 6 and parent[i] == -1:
                 c = cnt * scaling
                 artefact_cnts[f"{cv}_{i}"] = {"contour": np.concatenate([c, c[0:1]], 0), "holes": []}

@@ -61,9 +61,36 @@ def main():
         except Exception as e:
             prec_cases.append({"precision": p, "error": type(e).__name__, "message": str(e)})
 
+    # a20 host helpers (grandqc/wsi_qc_helpers.py:26-150)
+    import numpy as np
+    from classpose.grandqc import wsi_qc_helpers as qh
+    rng = np.random.default_rng(2)
+    info_cases = []
+    for dims, props, mpp_model in (((40000, 30000), {"openslide.mpp-x": "0.25", "openslide.mpp-y": "0.25"}, 1.0),
+                                   ((98304, 65537), {"openslide.mpp-x": "0.2521", "openslide.mpp-y": "0.2521"}, 1.5),
+                                   ((1000, 700), {"tiff.XResolution": "20000", "tiff.YResolution": "20000", "tiff.ResolutionUnit": "centimeter"}, 10.0)):
+        slide = types.SimpleNamespace(level_dimensions=[dims], properties=props)
+        w, h, mpp, td = qh.extract_slide_info(slide, mpp_model)
+        info_cases.append({"dims": list(dims), "properties": props, "mpp_model": mpp_model,
+                           "out": [w, h, mpp, list(td)]})
+    feat_cases = []
+    for n, closed in ((3, False), (4, False), (7, False), (6, True)):
+        cnt = rng.integers(0, 500, (n, 2))
+        if closed:
+            cnt[-1] = cnt[0]
+        scaling = np.array([3.9672, 4.0125])
+        f = qh.create_geojson_feature(cnt, scaling, "Fold", [255, 99, 71])
+        if f is not None:
+            f["id"] = "uuid"
+        feat_cases.append({"contour": cnt.tolist(), "scaling": scaling.tolist(), "feature": f})
+    mask = rng.integers(0, 7, (9, 13))
+    colors = [[int(v) for v in rng.integers(0, 256, 3)] for _ in range(7)]
+    cmap_case = {"mask": mask.tolist(), "colors": colors, "rgb": qh.make_class_map(mask, colors).tolist()}
+
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
-        json.dump({"get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases}, f, indent=1)
-    print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases))
+        json.dump({"get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
+                   "extract_slide_info": info_cases, "create_geojson_feature": feat_cases, "make_class_map": cmap_case}, f, indent=1)
+    print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases), len(info_cases), len(feat_cases))
 
 
 if __name__ == "__main__":

@@ -204,3 +204,28 @@ def test_host_logic_matches_reference_goldens():
             assert str(e.value) == c["message"]
         else:
             assert models.resolve_precision(c["precision"], torch.device("cpu")) == names[c["dtype"]]
+
+
+def test_grandqc_host_helpers_match_reference_goldens():
+    """a20 host helpers against the reference's wsi_qc_helpers (extract_slide_info :26-46, create_geojson_feature
+    :49-88, make_class_map :123-150), goldens from tests/golden/make_golden_host.py."""
+    import json
+    import os
+    import types
+
+    from classpose_amd import grandqc
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    for c in g["extract_slide_info"]:
+        slide = types.SimpleNamespace(level_dimensions=[tuple(c["dims"])], properties=c["properties"])
+        w, h, mpp, td = grandqc.extract_slide_info(slide, c["mpp_model"])
+        assert [w, h, mpp, list(td)] == c["out"]
+    for c in g["create_geojson_feature"]:
+        f = grandqc.create_geojson_feature(np.array(c["contour"]), np.array(c["scaling"]), "Fold", [255, 99, 71])
+        if c["feature"] is None:
+            assert f is None
+        else:
+            f = dict(f, id="uuid")
+            assert json.loads(json.dumps(f)) == c["feature"]
+    c = g["make_class_map"]
+    assert grandqc.make_class_map(np.array(c["mask"]), c["colors"]).tolist() == c["rgb"]
