@@ -87,8 +87,23 @@ def main():
     colors = [[int(v) for v in rng.integers(0, 256, 3)] for _ in range(7)]
     cmap_case = {"mask": mask.tolist(), "colors": colors, "rgb": qh.make_class_map(mask, colors).tolist()}
 
+    # (b) drop-in boundary helpers: output file names and --device parsing (utils.py:29-148)
+    from classpose import utils as ru
+    name_cases = []
+    for kind, base in (("cell_contours", "slide_1"), ("cell_centroids", "a.b"), ("tissue_contours", "x"),
+                       ("artefact_contours", "x y"), ("roi", "r"), ("nonsense", "x")):
+        try:
+            name_cases.append({"kind": kind, "base": base, "name": ru.get_geojson_output_filename(kind, base)})
+        except Exception as e:
+            name_cases.append({"kind": kind, "base": base, "error": type(e).__name__, "message": str(e)})
+    prefix_cases = [{"prefix": p_, "kind": k, "path": str(ru.get_geojson_output_path_from_prefix(p_, k))}
+                    for p_, k in (("/out/dir/slide_1", "tissue_contours"), ("rel/s.v2", "artefact_contours"), ("plain", "roi"))]
+    device_cases = [{"device": d, "devices": [str(x) for x in ru.get_device(d)]}
+                    for d in ("cuda:0", "cuda:0,1,2,3", "cuda:3", "cpu", "cuda")]
+
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
-        json.dump({"get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
+        json.dump({"output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
+                   "get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
                    "extract_slide_info": info_cases, "create_geojson_feature": feat_cases, "make_class_map": cmap_case}, f, indent=1)
     print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases), len(info_cases), len(feat_cases))
 

@@ -229,3 +229,26 @@ def test_grandqc_host_helpers_match_reference_goldens():
             assert json.loads(json.dumps(f)) == c["feature"]
     c = g["make_class_map"]
     assert grandqc.make_class_map(np.array(c["mask"]), c["colors"]).tolist() == c["rgb"]
+
+
+def test_boundary_helpers_match_reference_goldens():
+    """(b) drop-in boundary: output file names (utils.py:29-93, incl. the error text) and --device parsing
+    (utils.py:118-148) against outputs of the reference's own functions."""
+    import json
+    import os
+
+    from classpose_amd.entrypoints import predict_wsi as pw
+    from classpose_amd.grandqc import wsi_tissue_detection as td
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    for c in g["output_filename"]:
+        if "error" in c:
+            with pytest.raises(ValueError) as e:
+                pw.get_geojson_output_filename(c["kind"], c["base"])
+            assert str(e.value) == c["message"]
+        else:
+            assert pw.get_geojson_output_filename(c["kind"], c["base"]) == c["name"]
+    for c in g["output_path_from_prefix"]:
+        assert str(td.get_geojson_output_path_from_prefix(c["prefix"], c["kind"])) == c["path"]
+    for c in g["get_device"]:
+        assert [str(d) for d in pw.get_device(c["device"])] == c["devices"]
