@@ -101,8 +101,22 @@ def main():
     device_cases = [{"device": d, "devices": [str(x) for x in ru.get_device(d)]}
                     for d in ("cuda:0", "cuda:0,1,2,3", "cuda:3", "cpu", "cuda")]
 
+    # --model_config surface (model_configs.py:20-148): the default table (paths relative to the model directory) and
+    # the YAML schema
+    import classpose.model_configs as rmc
+    root = str(rmc.ROOT_MODEL_DIR)
+    table = {k: dict(v, path=os.path.relpath(v["path"], root)) for k, v in rmc.DEFAULT_MODEL_CONFIGS.items()}
+    yaml_cases = []
+    for text in ("path: /w/my.pt\nmpp: 0.33\ncell_types: [A, B, C]\n",
+                 "path: /w/my.pt\nmpp: 1\nurl: https://example.org/w.pt\nhf:\n  repo_id: org/repo\n  filename: w.pt\ncell_types:\n  - X\n"):
+        with tempfile.TemporaryDirectory() as d:
+            yp = os.path.join(d, "c.yaml")
+            with open(yp, "w") as f:
+                f.write(text)
+            yaml_cases.append({"yaml": text, "config": rmc.ModelConfig.load_from_yaml(yp).model_dump()})
+
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
-        json.dump({"output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
+        json.dump({"default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
                    "get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
                    "extract_slide_info": info_cases, "create_geojson_feature": feat_cases, "make_class_map": cmap_case}, f, indent=1)
     print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases), len(info_cases), len(feat_cases))

@@ -252,3 +252,19 @@ def test_boundary_helpers_match_reference_goldens():
         assert str(td.get_geojson_output_path_from_prefix(c["prefix"], c["kind"])) == c["path"]
     for c in g["get_device"]:
         assert [str(d) for d in pw.get_device(c["device"])] == c["devices"]
+
+
+def test_model_configs_match_reference_goldens(tmp_path):
+    """--model_config surface against the reference's own table and YAML loader (model_configs.py:20-148)."""
+    import json
+    import os
+
+    from classpose_amd import model_configs as mc
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    ours = {k: dict(v, path=os.path.relpath(v["path"], str(mc.ROOT_MODEL_DIR))) for k, v in mc.DEFAULT_MODEL_CONFIGS.items()}
+    assert ours == g["default_model_configs"]
+    for c in g["model_config_yaml"]:
+        yp = tmp_path / "c.yaml"
+        yp.write_text(c["yaml"])
+        assert mc.ModelConfig.load_from_yaml(str(yp)).model_dump() == c["config"]
