@@ -115,8 +115,47 @@ def main():
                 f.write(text)
             yaml_cases.append({"yaml": text, "config": rmc.ModelConfig.load_from_yaml(yp).model_dump()})
 
+    # the command line itself (predict_wsi.py:1891-2021): what argparse hands to main() for a given argv
+    cli_cases = []
+    captured = []
+    real_main, real_argv = pw.main, sys.argv
+    pw.main = lambda a: captured.append(dict(vars(a)))
+    try:
+        for argv in (
+            ["--model_config", "conic", "--slide_path", "s.svs", "--output_folder", "out"],
+            ["--model_config", "cfg.yaml", "--slide_path", "/a/b.ndpi", "--output_folder", "/o", "--tta", "--filter_artefacts",
+             "--tissue_detection_model_path", "t.pth", "--artefact_detection_model_path", "a.pth", "--roi_geojson", "r.geojson",
+             "--roi_class_priority", "Tumour", "Stroma", "--min_area", "5000", "--batch_size", "32", "--device", "cuda:0,1",
+             "--precision", "fp16", "--tile_size", "512", "--overlap", "96", "--output_type", "csv", "spatialdata",
+             "--inference_threads", "3"],
+            ["--model_config", "puma", "--slide_path", "s", "--output_folder", "o", "--no-tta", "--no-filter_artefacts",
+             "--precision", "fp32"],
+        ):
+            sys.argv = ["classpose-predict-wsi"] + argv
+            pw.main_with_args()
+            cli_cases.append({"argv": argv, "args": captured[-1]})
+    finally:
+        pw.main, sys.argv = real_main, real_argv
+    # the class-less sibling (predict_wsi_cpsam.py:677-812)
+    import classpose.entrypoints.predict_wsi_cpsam as pc
+    cpsam_cases = []
+    real_main, real_argv = pc.main, sys.argv
+    pc.main = lambda a: captured.append(dict(vars(a)))
+    try:
+        for argv in (
+            ["--slide_path", "s.svs", "--output_folder", "out"],
+            ["--model_path", "/w/cpsam_ft.pt", "--slide_path", "s", "--output_folder", "o", "--train_mpp", "0.25", "--tta",
+             "--batch_size", "16", "--device", "cuda:1", "--tile_size", "512", "--precision", "fp32", "--overlap", "32",
+             "--output_type", "csv", "--min_area", "100", "--roi_class_priority", "A"],
+        ):
+            sys.argv = ["classpose-predict-wsi-cpsam"] + argv
+            pc.main_with_args()
+            cpsam_cases.append({"argv": argv, "args": captured[-1]})
+    finally:
+        pc.main, sys.argv = real_main, real_argv
+
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
-        json.dump({"default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
+        json.dump({"cli": cli_cases, "cli_cpsam": cpsam_cases, "default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
                    "get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
                    "extract_slide_info": info_cases, "create_geojson_feature": feat_cases, "make_class_map": cmap_case}, f, indent=1)
     print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases), len(info_cases), len(feat_cases))

@@ -268,3 +268,20 @@ def test_model_configs_match_reference_goldens(tmp_path):
         yp = tmp_path / "c.yaml"
         yp.write_text(c["yaml"])
         assert mc.ModelConfig.load_from_yaml(str(yp)).model_dump() == c["config"]
+
+
+def test_cli_arguments_match_reference_goldens():
+    """(b) the console script's argument surface: for the same argv, our parser hands run the same namespace as the
+    reference's main_with_args hands its main() (predict_wsi.py:1891-2021): names, defaults, types, list arguments,
+    --tta / --no-tta style switches."""
+    import json
+    import os
+
+    from classpose_amd.entrypoints import predict_wsi as pw
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    for c in g["cli"]:
+        assert vars(pw.build_parser().parse_args(c["argv"])) == c["args"]
+    from classpose_amd.entrypoints import predict_wsi_cpsam as pc            # predict_wsi_cpsam.py:677-812
+    for c in g["cli_cpsam"]:
+        assert vars(pc.build_parser().parse_args(c["argv"])) == c["args"]
