@@ -241,3 +241,30 @@ def test_compute_masks_repeatable_under_load(cuda):
     torch.cuda.synchronize()
     want = dynamics.compute_masks(f[3][0], f[3][1])
     assert np.array_equal(ops.masks_to_numpy(first[0][3]), want.astype(np.uint16))
+
+
+def test_compute_masks_equals_reference_eval_golden(cuda):
+    """The HIP dynamics + class vote on the network fields of the reference's own ``ClassposeModel.eval`` run
+    (tests/golden/reference_eval.npz, minted by make_golden_eval.py; the fields are regenerated with the oracle's
+    normalize_img / run_net, which tests/test_oracle_network_pins.py shows bit-identical to the reference's): the id map
+    and the class map equal what the reference returned, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_eval as mge
+    from oracle import tiling
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_eval.npz"))
+    for k in range(int(g["ev_n"])):
+        seed, tta, bs = (int(v) for v in g[f"ev_{k}_cfg"])
+        x = tiling.normalize_img(mge.eval_tile(seed)[None])
+
+        def fw(img):
+            o = mge.decode_net(torch.from_numpy(np.ascontiguousarray(img)), mge.NCLS).numpy()
+            return o[:, mge.NCLS:], o[:, :mge.NCLS]
+        dP, cp, yc = tiling.run_net(fw, x, batch_size=bs, augment=bool(tta), tile_overlap=0.1, bsize=256)
+        assert np.array_equal(dP[:, ::4, ::4], g[f"ev_{k}_dP"])
+        m, cm, nl = ops.compute_masks(torch.from_numpy(dP[None]).to(cuda), torch.from_numpy(cp[None]).to(cuda),
+                                      torch.from_numpy(yc[None]).to(cuda))
+        assert np.array_equal(ops.masks_to_numpy(m)[0], g[f"ev_{k}_masks"])
+        assert np.array_equal(cm[0].cpu().numpy(), g[f"ev_{k}_class_masks"])
+        assert int(nl[0]) == int(g[f"ev_{k}_masks"].max())

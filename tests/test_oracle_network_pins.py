@@ -56,3 +56,41 @@ def test_oracle_run_net_equals_reference_run_net(gold):
         assert np.array_equal(yf[::5, ::5], gold[f"rn_{k}_yf"]), k
         assert np.array_equal(yc.transpose(1, 2, 0)[::5, ::5], gold[f"rn_{k}_ycf"]), k
         assert np.array_equal(yf[H // 2], gold[f"rn_{k}_yf_row"]), k
+
+
+def test_oracle_tile_pipeline_equals_reference_eval():
+    """The per-tile orchestration: ``ClassposeModel.eval([tile], batch_size, augment, bsize=256, compute_masks=True)`` as
+    the WSI worker calls it (predict_wsi.py:751-757), run by the reference itself on an elementwise stand-in network
+    (tests/golden/make_golden_eval.py), against the composition the GPU tests use as their oracle: normalize_img ->
+    run_net -> compute_masks -> compute_class_masks with the default arguments.  Bit for bit, and the arguments the
+    reference hands across the cellpose boundary are the ones the oracle / the engine hard-code."""
+    import json
+    import make_golden_eval as mge
+    from oracle import classmask, dynamics
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_eval.npz"))
+    for k in range(int(g["ev_n"])):
+        seed, tta, bs = (int(v) for v in g[f"ev_{k}_cfg"])
+        tile = mge.eval_tile(seed)
+        assert int(tile.astype(np.int64).sum()) == int(g[f"ev_{k}_tilesum"])        # RNG drift guard
+        x = tiling.normalize_img(tile[None])
+
+        def fw(img):
+            o = mge.decode_net(torch.from_numpy(np.ascontiguousarray(img)), mge.NCLS).numpy()
+            return o[:, mge.NCLS:], o[:, :mge.NCLS]
+        dP, cp, yc = tiling.run_net(fw, x, batch_size=bs, augment=bool(tta), tile_overlap=0.1, bsize=256)
+        assert np.array_equal(dP[:, ::4, ::4], g[f"ev_{k}_dP"]) and np.array_equal(cp[::4, ::4], g[f"ev_{k}_cellprob"])
+        assert np.array_equal(yc[:, ::4, ::4], g[f"ev_{k}_yclass"])
+        masks = dynamics.compute_masks(dP, cp)                                        # niter 200, 0.0 / 0.4, min_size 15, 0.4
+        assert masks.max() > 50
+        assert np.array_equal(masks.astype(np.uint16), g[f"ev_{k}_masks"])
+        cm, _ = classmask.compute_class_masks(masks, yc)
+        assert np.array_equal(cm.astype(np.uint8), g[f"ev_{k}_class_masks"])
+        log = json.loads(str(g[f"ev_{k}_log"]))
+        assert log["resize_and_compute_masks"] == {"cellprob_threshold": 0.0, "flow_threshold": 0.4, "max_size_fraction": 0.4,
+                                                   "min_size": 15, "niter": 200, "resize": None, "dP_shape": [2, 256, 256],
+                                                   "device": "device(type='cpu')"}
+        n = log["normalize_img"]
+        assert n["normalize"] is True and n["invert"] is False and n["percentile"] is None and n["lowhigh"] is None
+        assert n["sharpen_radius"] == 0 and n["smooth_radius"] == 0 and n["tile_norm_blocksize"] == 0
+        assert log["convert_image"]["shape"] == [256, 256, 3] and log["convert_image"]["do_3D"] is False
+        assert list(g[f"ev_{k}_shape_x"]) == [1, 256, 256, 3] and int(g[f"ev_{k}_n_flows"]) == 5
