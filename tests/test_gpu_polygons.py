@@ -103,3 +103,54 @@ def test_device_polygons_multi_component_and_tiny(cuda):
         assert np.array_equal(xy[c["offset"]: c["offset"] + c["n_pts"]], exp), lab
         assert bool(c["valid"]) == opoly.polygon_metrics(exp)["valid"], lab
 
+
+
+def test_device_records_and_polygons_equal_reference_postprocessor(cuda):
+    """cpx_instance_records + cpx_polygonize_device on the id / class maps of the reference's own ``eval`` run against the
+    cells the reference's own ``PostProcessor.__call__`` produced from them (tests/golden/reference_postprocessor.npz):
+    vertices, area, perimeter, rounded centroid, class -- per valid cell, in label order."""
+    import ctypes as C
+    import os
+    from classpose_amd import _lib
+    from classpose_amd._lib import ptr
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, ev = np.load(os.path.join(gd, "reference_postprocessor.npz")), np.load(os.path.join(gd, "reference_eval.npz"))
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(int(g["pp_n"])):
+        case, cx, cy, labelled = (int(v) for v in g[f"pp_{k}_cfg"])
+        scale = float(g[f"pp_{k}_scale"])
+        m = ev[f"ev_{case}_masks"].astype(np.uint16).copy()
+        cmh = ev[f"ev_{case}_class_masks"].astype(np.uint8).copy()
+        if int(g[f"pp_{k}_extra"]):
+            n = int(m.max())
+            m[0, 0] = n + 1; m[5, 250:252] = n + 2
+            cmh[0, 0] = 1; cmh[5, 250:252] = 2
+        H, W = m.shape
+        masks = torch.from_numpy(m.view(np.int16)).to(cuda)[None]
+        cm = torch.from_numpy(cmh).to(cuda)[None]
+        max_rec = 256
+        recs = torch.zeros(max_rec * C.sizeof(_lib.CpxRecord), dtype=torch.uint8, device=cuda)
+        cnt = torch.zeros(1, dtype=torch.int32, device=cuda)
+        ws = torch.empty(L.cpx_postproc_workspace_bytes(1, H, W), dtype=torch.uint8, device=cuda)
+        _lib.check(L.cpx_instance_records(ptr(masks), ptr(cm), 1, H, W, max_rec, ptr(recs), ptr(cnt), ptr(ws), st))
+        cells = torch.zeros(max_rec * C.sizeof(_lib.CpxCell), dtype=torch.uint8, device=cuda)
+        pool = torch.zeros((16384, 2), dtype=torch.float64, device=cuda)
+        tot = torch.zeros(1, dtype=torch.int32, device=cuda)
+        org = torch.tensor([[float(cx), float(cy)]], dtype=torch.float64, device=cuda)
+        pws = torch.empty(L.cpx_polygonize_workspace_bytes(1, H, W, max_rec), dtype=torch.uint8, device=cuda)
+        _lib.check(L.cpx_polygonize_device(ptr(masks), ptr(recs), ptr(cnt), 1, H, W, max_rec, scale, ptr(org), ptr(pool), 16384,
+                                           ptr(cells), ptr(tot), ptr(pws), st))
+        n = int(cnt.item())
+        dc = cells.cpu().numpy().view(engine.CELL_DTYPE)[:n]
+        xy = pool.cpu().numpy()
+        dv = dc[dc["valid"] == 1]
+        offs = np.concatenate([[0], np.cumsum(g[f"pp_{k}_n_pts"])])
+        assert len(dv) == len(offs) - 1 and n - len(dv) == int(g[f"pp_{k}_n_invalid"])
+        for i, c in enumerate(dv):
+            want = g[f"pp_{k}_coords"][offs[i]: offs[i + 1]]
+            assert np.array_equal(xy[c["offset"]: c["offset"] + c["n_pts"]], want[:-1])
+            assert c["area"] == g[f"pp_{k}_area"][i] and abs(c["perimeter"] - g[f"pp_{k}_perimeter"][i]) <= 1e-12 * c["perimeter"]
+            assert np.round([c["cx"], c["cy"]], 2).tolist() == g[f"pp_{k}_centroid"][i].tolist()
+            if labelled:
+                assert c["cls"] - 1 == int(g[f"pp_{k}_class_int"][i])

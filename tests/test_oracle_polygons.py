@@ -11,12 +11,14 @@ from classpose_amd.engine import RECORD_DTYPE
 from oracle import polygons as opoly
 
 
-def _records(m):
+def _records(m, cm=None):
+    """what cpx_instance_records emits; the class is the class map at the instance's first raster pixel when cm is given"""
     labs = [l for l in np.unique(m) if l]
     recs = np.zeros(len(labs), RECORD_DTYPE)
     for i, l in enumerate(labs):
         ys, xs = np.nonzero(m == l)
-        recs[i] = (0, l, 1 + int(l) % 6, len(ys), ys.min(), xs.min(), ys.max() + 1, xs.max() + 1, ys.sum(), xs.sum())
+        cls = 1 + int(l) % 6 if cm is None else int(cm[ys[0], xs[0]])
+        recs[i] = (0, l, cls, len(ys), ys.min(), xs.min(), ys.max() + 1, xs.max() + 1, ys.sum(), xs.sum())
     return recs
 
 
@@ -135,3 +137,55 @@ def test_host_polygonizer_equals_oracle_random_blobs(seed, thr):
         cm[m == r["label"]] = r["cls"]
     cells, xy = postprocess.polygonize_tile(m, recs, 1.0, (7, 9))
     assert _compare_with_oracle(m, cm, 1.0, (7, 9), cells, xy) > 5
+
+
+# ---- the reference's own PostProcessor loop (tests/golden/make_golden_postprocessor.py) ---------------------------------
+def _pp_case(g, ev, k):
+    case, cx, cy, labelled = (int(v) for v in g[f"pp_{k}_cfg"])
+    masks = ev[f"ev_{case}_masks"].astype(np.uint16)
+    cm = ev[f"ev_{case}_class_masks"].astype(np.uint8)
+    if int(g[f"pp_{k}_extra"]):
+        masks = masks.copy(); cm = cm.copy()
+        n = int(masks.max())
+        masks[0, 0] = n + 1; masks[5, 250:252] = n + 2
+        cm[0, 0] = 1; cm[5, 250:252] = 2
+    return masks, cm, (cx, cy), float(g[f"pp_{k}_scale"]), bool(labelled)
+
+
+def test_oracle_and_host_polygonizer_equal_reference_postprocessor():
+    """``PostProcessor.__call__`` (predict_wsi.py:578-656) run by the reference itself on the id / class maps its own
+    ``eval`` produced: the oracle's restatement of the loop and the product's host polygoniser + cell dict give the same
+    cells -- vertices, area, perimeter, rounded centroid, class, label, colour, dict keys, rejection count."""
+    import json
+    import os
+    from classpose_amd import geojson
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, ev = np.load(os.path.join(gd, "reference_postprocessor.npz")), np.load(os.path.join(gd, "reference_eval.npz"))
+    labels = ["Alpha", "Beta", "Gamma"]
+    for k in range(int(g["pp_n"])):
+        masks, cm, coords, scale, labelled = _pp_case(g, ev, k)
+        offs = np.concatenate([[0], np.cumsum(g[f"pp_{k}_n_pts"])])
+        want_xy = [g[f"pp_{k}_coords"][offs[i]: offs[i + 1]] for i in range(len(offs) - 1)]
+        # the oracle's loop
+        ref = opoly.post_process_tile(masks, cm if labelled else None, coords, scale)
+        assert len(ref) == len(want_xy)
+        assert int(g[f"pp_{k}_n_invalid"]) == len(np.unique(masks)) - 1 - len(ref)
+        for r, xy, a, p, c, ci in zip(ref, want_xy, g[f"pp_{k}_area"], g[f"pp_{k}_perimeter"], g[f"pp_{k}_centroid"], g[f"pp_{k}_class_int"]):
+            assert np.array_equal(r["coords"], xy[:-1]) and np.array_equal(xy[-1], xy[0])      # the reference closes the ring
+            assert r["area"] == a and r["perimeter"] == p and r["centroid"] == c.tolist()
+            assert r["class_int"] == (ci if labelled else 0)
+        # the product's host polygoniser + cell dict
+        recs = _records(masks, cm)
+        cells, pool = postprocess.polygonize_tile(masks, recs, scale, coords)
+        valid = cells[cells["valid"] == 1]
+        assert len(valid) == len(want_xy)
+        names, colors = json.loads(str(g[f"pp_{k}_label"])), g[f"pp_{k}_color"]
+        for i, c in enumerate(valid):
+            ring = pool[c["offset"]: c["offset"] + c["n_pts"]]
+            assert np.array_equal(ring, want_xy[i][:-1])
+            assert c["area"] == g[f"pp_{k}_area"][i] and c["perimeter"] == pytest.approx(g[f"pp_{k}_perimeter"][i], rel=1e-14)
+            d = geojson.cell_dict(ring.tolist(), int(c["cls"]) if labelled else 0, labels if labelled else None, c["area"],
+                                  c["perimeter"], np.round([c["cx"], c["cy"]], 2).tolist())
+            assert sorted(d.keys()) == json.loads(str(g[f"pp_{k}_keys"]))
+            assert d["coords"] == want_xy[i].tolist() and d["centroid"] == g[f"pp_{k}_centroid"][i].tolist()
+            assert d["label"] == names[i] and d["color"] == colors[i].tolist() and d["class_int"] == int(g[f"pp_{k}_class_int"][i])
