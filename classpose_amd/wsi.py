@@ -89,7 +89,9 @@ def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePl
     mpp = get_slide_resolution(slide)
     bx = slide.properties.get("openslide.bounds-x")
     by = slide.properties.get("openslide.bounds-y")
-    bounds = (float(bx) if bx is not None else 0.0, float(by) if by is not None else 0.0)
+    # (also manager.Value("f") slots in the reference, predict_wsi.py:187-188,226-229: the offset later subtracted from
+    # every coordinate is the float32-rounded one)
+    bounds = (float(np.float32(float(bx))) if bx is not None else 0.0, float(np.float32(float(by))) if by is not None else 0.0)
     scale = min(train_mpp / mpp[0], train_mpp / mpp[1])
     level = slide.get_best_level_for_downsample(scale)
     dim = tuple(slide.level_dimensions[level])

@@ -115,6 +115,51 @@ def main():
                 f.write(text)
             yaml_cases.append({"yaml": text, "config": rmc.ModelConfig.load_from_yaml(yp).model_dump()})
 
+    # a1: SlideLoader._init_slide (predict_wsi.py:220-278) run unbound on a fake self whose shared values are C floats like
+    # manager.Value("f") and whose reader is a fabricated multi-level slide (OpenSlide's level-selection rule)
+    import ctypes
+    init_cases = []
+    for spec in (
+        dict(dims=[(40000, 30000), (10000, 7500), (2500, 1875)], down=[1.0, 4.0, 16.0], props={"openslide.mpp-x": "0.25", "openslide.mpp-y": "0.25"},
+             tile=1024, overlap=64, train_mpp=0.5),
+        dict(dims=[(98304, 65536), (49152, 32768), (24573, 16382)], down=[1.0, 2.0, 4.000407], props={"openslide.mpp-x": "0.1213", "openslide.mpp-y": "0.1213"},
+             tile=256, overlap=32, train_mpp=0.5),
+        dict(dims=[(20000, 20000)], down=[1.0], props={"openslide.mpp-x": "0.2521", "openslide.mpp-y": "0.2498", "openslide.bounds-x": "15360.7", "openslide.bounds-y": "208.5"},
+             tile=512, overlap=96, train_mpp=0.22),
+        dict(dims=[(10000, 10000)], down=[1.0], props={"openslide.mpp-x": "0.5", "openslide.mpp-y": "0.5"}, tile=256, overlap=32, train_mpp=0.5),
+        dict(dims=[(12000, 9000), (3000, 2250)], down=[1.0, 4.0], props={"tiff.XResolution": "20000", "tiff.YResolution": "20000", "tiff.ResolutionUnit": "centimeter"},
+             tile=1024, overlap=64, train_mpp=0.25),
+    ):
+        class FakeSlide:
+            properties = spec["props"]
+            level_dimensions = [tuple(d) for d in spec["dims"]]
+            level_downsamples = list(spec["down"])
+
+            def get_best_level_for_downsample(self, ds):        # OpenSlide: the largest level whose downsample is <= ds
+                best = 0
+                for i, d in enumerate(self.level_downsamples):
+                    if d <= ds:
+                        best = i
+                return best
+        fv = lambda: ctypes.c_float(0.0)
+        me = types.SimpleNamespace(slide_path="fake", tile_size=spec["tile"], overlap=spec["overlap"], train_mpp=spec["train_mpp"],
+                                   roi_tree=None, mpp_x=fv(), mpp_y=fv(), bounds_x=fv(), bounds_y=fv(), ts=fv(), resize_factor=fv(),
+                                   real_slide_path="fake")
+        me.get_real_slide_path = lambda: "fake"
+        me._get_coords = types.MethodType(pw.SlideLoader._get_coords, me)
+        real_reader = pw.WSIReader
+        pw.WSIReader = lambda path: FakeSlide()
+        try:
+            pw.SlideLoader._init_slide(me)
+        finally:
+            pw.WSIReader = real_reader
+        init_cases.append({**spec, "mpp": list(me.mpp), "mpp_x": me.mpp_x.value, "mpp_y": me.mpp_y.value,
+                           "bounds": [me.bounds_x.value, me.bounds_y.value], "level": me.level, "slide_dim": list(me.slide_dim),
+                           "ts": me.ts.value, "resize_factor": me.resize_factor.value, "n_coords": len(me.coords),
+                           "coords_head": [[list(map(int, c[0])), int(c[1])] for c in me.coords[:3]],
+                           "coords_tail": [[list(map(int, c[0])), int(c[1])] for c in me.coords[-2:]],
+                           "coords_sum": [int(sum(c[0][0] for c in me.coords)), int(sum(c[0][1] for c in me.coords))]})
+
     # the command line itself (predict_wsi.py:1891-2021): what argparse hands to main() for a given argv
     cli_cases = []
     captured = []
@@ -155,7 +200,7 @@ def main():
         pc.main, sys.argv = real_main, real_argv
 
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
-        json.dump({"cli": cli_cases, "cli_cpsam": cpsam_cases, "default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
+        json.dump({"init_slide": init_cases, "cli": cli_cases, "cli_cpsam": cpsam_cases, "default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
                    "get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
                    "extract_slide_info": info_cases, "create_geojson_feature": feat_cases, "make_class_map": cmap_case}, f, indent=1)
     print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases), len(info_cases), len(feat_cases))

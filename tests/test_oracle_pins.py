@@ -285,3 +285,36 @@ def test_cli_arguments_match_reference_goldens():
     from classpose_amd.entrypoints import predict_wsi_cpsam as pc            # predict_wsi_cpsam.py:677-812
     for c in g["cli_cpsam"]:
         assert vars(pc.build_parser().parse_args(c["argv"])) == c["args"]
+
+
+def test_plan_slide_matches_reference_init_slide():
+    """a1 / a2: ``SlideLoader._init_slide`` (predict_wsi.py:220-278) run by the reference itself on fabricated multi-level
+    slides -- mpp, bounds, level choice, the float32 ``ts`` / ``resize_factor`` of its manager.Value("f") slots, the
+    read-tile geometry and the whole tile grid -- against ``wsi.plan_slide``."""
+    import json
+    import os
+
+    from classpose_amd import wsi
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    for c in g["init_slide"]:
+        class FakeSlide:
+            properties = c["props"]
+            level_dimensions = [tuple(d) for d in c["dims"]]
+            level_downsamples = list(c["down"])
+
+            def get_best_level_for_downsample(self, ds):
+                best = 0
+                for i, d in enumerate(self.level_downsamples):
+                    if d <= ds:
+                        best = i
+                return best
+        p = wsi.plan_slide(FakeSlide(), c["tile"], c["overlap"], c["train_mpp"])
+        assert list(p.mpp) == c["mpp"]
+        assert list(p.bounds) == c["bounds"]
+        assert p.level == c["level"] and list(p.slide_dim) == c["slide_dim"]
+        assert p.ts == c["ts"] and p.resize_factor == c["resize_factor"]                  # float32 values, exactly
+        assert len(p.coords) == c["n_coords"]
+        as_list = lambda cs: [[list(map(int, x[0])), int(x[1])] for x in cs]
+        assert as_list(p.coords[:3]) == c["coords_head"] and as_list(p.coords[-2:]) == c["coords_tail"]
+        assert [sum(x[0][0] for x in p.coords), sum(x[0][1] for x in p.coords)] == c["coords_sum"]
