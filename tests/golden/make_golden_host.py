@@ -160,6 +160,20 @@ def main():
                            "coords_tail": [[list(map(int, c[0])), int(c[1])] for c in me.coords[-2:]],
                            "coords_sum": [int(sum(c[0][0] for c in me.coords)), int(sum(c[0][1] for c in me.coords))]})
 
+    # a3: the output size of resize_tile_to_target_mpp (predict_wsi.py:102-123; Python's round-half-even on h * factor),
+    # observed through a recording stand-in for cv2.resize
+    import numpy as np
+    seen = []
+    pw.cv2.resize = lambda tile, size, interpolation=None: seen.append((size, interpolation)) or np.zeros((size[1], size[0], 3), np.uint8)
+    pw.cv2.INTER_LINEAR = "LINEAR"
+    resize_cases = []
+    for h, w, rf in ((447, 447, 1.145909070968628), (251, 253, 0.5), (250, 255, 0.5), (264, 264, 0.97049880027771), (1, 3, 0.2),
+                     (2048, 2048, 0.5), (512, 300, 2.0), (333, 777, 1.5), (256, 256, 1.0), (5, 5, 0.1)):
+        seen.clear()
+        out_tile = pw.resize_tile_to_target_mpp(np.zeros((h, w, 3), np.uint8), rf)
+        resize_cases.append({"h": h, "w": w, "factor": rf, "out_hw": [int(out_tile.shape[0]), int(out_tile.shape[1])],
+                             "called_resize": bool(seen), "interpolation": seen[0][1] if seen else None})
+
     # the command line itself (predict_wsi.py:1891-2021): what argparse hands to main() for a given argv
     cli_cases = []
     captured = []
@@ -200,7 +214,7 @@ def main():
         pc.main, sys.argv = real_main, real_argv
 
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
-        json.dump({"init_slide": init_cases, "cli": cli_cases, "cli_cpsam": cpsam_cases, "default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
+        json.dump({"resize_shape": resize_cases, "init_slide": init_cases, "cli": cli_cases, "cli_cpsam": cpsam_cases, "default_model_configs": table, "model_config_yaml": yaml_cases, "output_filename": name_cases, "output_path_from_prefix": prefix_cases, "get_device": device_cases,
                    "get_slide_resolution": res_cases, "infer_structure": struct_cases, "resolve_precision": prec_cases,
                    "extract_slide_info": info_cases, "create_geojson_feature": feat_cases, "make_class_map": cmap_case}, f, indent=1)
     print("wrote reference_host.json:", len(res_cases), len(struct_cases), len(prec_cases), len(info_cases), len(feat_cases))

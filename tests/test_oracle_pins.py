@@ -318,3 +318,17 @@ def test_plan_slide_matches_reference_init_slide():
         as_list = lambda cs: [[list(map(int, x[0])), int(x[1])] for x in cs]
         assert as_list(p.coords[:3]) == c["coords_head"] and as_list(p.coords[-2:]) == c["coords_tail"]
         assert [sum(x[0][0] for x in p.coords), sum(x[0][1] for x in p.coords)] == c["coords_sum"]
+
+
+def test_resized_shape_matches_reference():
+    """a3: the output size of ``resize_tile_to_target_mpp`` (predict_wsi.py:102-123, Python's round-half-even) as observed
+    from the reference through a recording stand-in for cv2.resize."""
+    import json
+    import os
+
+    from classpose_amd import ops
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")) as f:
+        g = json.load(f)
+    for c in g["resize_shape"]:
+        assert list(ops.resized_shape(c["h"], c["w"], c["factor"])) == c["out_hw"]
+        assert c["called_resize"] == (c["factor"] != 1.0)
