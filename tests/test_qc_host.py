@@ -224,3 +224,108 @@ def test_pickle_loader_allow_list_blocks_getattr_chain(tmp_path):
     assert issubclass(up.find_class("torch.nn.modules.conv", "Conv2d"), grandqc._Stub)
     with pytest.raises(pickle.UnpicklingError):
         up.find_class("os", "system")
+
+
+def test_tissue_pipeline_equals_reference_detect_tissue_wsi():
+    """a20 host orchestration: ``detect_tissue_wsi`` (grandqc/wsi_tissue_detection.py:32-329) run by the reference itself
+    on fabricated slides with an elementwise stand-in network (tests/golden/make_golden_qc.py) against the product's
+    ``tissue_class_map`` -> ``tissue_contours`` -> ``_cnts_to_geojson`` (-> ``_shift_outputs``) with the same stand-in:
+    the stitched class map's tissue mask, every contour and hole in level-0 coordinates, the GeoJSON features."""
+    import json
+    import os
+    import sys
+    import types
+
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_qc as mq
+    from classpose_amd import grandqc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_qc.npz"))
+
+    class FakeNet:                                      # QcNet's interface: uint8 (n, 512, 512, 3) -> int8 class maps
+        device = torch.device("cpu")
+
+        def forward(self, patches):
+            out = []
+            for p in patches.numpy():
+                x = mq.preprocessing_fn(p).transpose(2, 0, 1).astype("float32")          # get_preprocessing + to_tensor_x
+                out.append(np.argmax(mq.fake_logits(x), axis=0).astype("int8"))
+            return torch.from_numpy(np.stack(out))
+
+    for k in range(int(g["td_n"])):
+        w0, h0, min_area, shift, seed, tw, th = (int(v) for v in g[f"td_{k}_cfg"])
+        props = json.loads(str(g[f"td_{k}_props"]))
+        slide = types.SimpleNamespace(properties=props, level_dimensions=[(w0, h0)])
+        assert grandqc.extract_slide_info(slide, 10)[3] == (tw, th)
+        image = mq.thumbnail(seed, tw, th)
+        class_map = grandqc.tissue_class_map(image, FakeNet(), 512)
+        filtered, cnts = grandqc.tissue_contours(class_map, 10, min_area, (w0 / tw, h0 / th))
+        want_mask = np.unpackbits(g[f"td_{k}_mask"])[: th * tw].reshape(th, tw)
+        assert np.array_equal(filtered, want_mask)
+        gj = grandqc._cnts_to_geojson(cnts, "tissue", [0, 0, 0])
+        if shift:
+            grandqc._shift_outputs(cnts, gj, float(props["openslide.bounds-x"]), float(props["openslide.bounds-y"]))
+        assert sorted(cnts.keys()) == g[f"td_{k}_keys"].tolist()
+        for i, key in enumerate(sorted(cnts.keys())):
+            assert np.array_equal(cnts[key]["contour"], g[f"td_{k}_c{i}"])
+            assert len(cnts[key]["holes"]) == int(g[f"td_{k}_c{i}_nh"])
+            for j, hct in enumerate(cnts[key]["holes"]):
+                assert np.array_equal(hct, g[f"td_{k}_c{i}_h{j}"])
+        for f in gj["features"]:
+            f["id"] = "uuid"
+        assert json.loads(json.dumps(gj)) == json.loads(str(g[f"td_{k}_geojson"]))
+
+
+def test_artefact_pipeline_equals_reference_detect_artefacts_wsi():
+    """a20 host orchestration, artefact half: ``detect_artefacts_wsi`` (grandqc/wsi_artefact_detection.py:56-348) run by
+    the reference itself (tissue step stood in by a given mask, 7-class elementwise stand-in network) against the product's
+    ``resize_nearest`` -> ``artefact_class_map`` -> ``artefact_contours`` (-> ``_shift_outputs``) and the LANCZOS overview
+    map: the tissue-gated, padded class mask, the filter polygons with their holes, every GeoJSON feature, the class
+    names and colours."""
+    import json
+    import os
+    import sys
+
+    import torch
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_qc as mq
+    from classpose_amd import grandqc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_qc.npz"))
+    assert json.loads(str(g["ad_colors"])) == [list(c) for c in grandqc.ARTIFACT_COLORS]
+    assert {int(k): v for k, v in json.loads(str(g["ad_names"])).items()} == dict(grandqc.ARTIFACT_CLASS_MAPPING)
+
+    class FakeNet7:
+        device = torch.device("cpu")
+
+        def forward(self, patches):
+            out = []
+            for p in patches.numpy():
+                x = mq.preprocessing_fn(p).transpose(2, 0, 1).astype("float32")
+                out.append(np.argmax(mq.fake_logits7(x), axis=0).astype("int8"))
+            return torch.from_numpy(np.stack(out))
+
+    for k in range(int(g["ad_n"])):
+        w0, h0, shift, seed, tw, th, mw, mh = (int(v) for v in g[f"ad_{k}_cfg"])
+        props = json.loads(str(g[f"ad_{k}_props"]))
+        image = mq.artefact_thumbnail(seed, tw, th)
+        tmask = mq.tissue_mask_10(seed, mw, mh)
+        tissue_art = grandqc.resize_nearest(tmask, tw, th)
+        amask = grandqc.artefact_class_map(image, tissue_art, FakeNet7(), 512)
+        assert np.array_equal(amask.astype(np.uint8), g[f"ad_{k}_mask"])
+        cnts, gj = grandqc.artefact_contours(amask, (w0 / tw, h0 / th))
+        if shift:
+            grandqc._shift_outputs(cnts, gj, float(props["openslide.bounds-x"]), float(props["openslide.bounds-y"]))
+        keys = json.loads(str(g[f"ad_{k}_keys"]))
+        assert sorted(cnts.keys()) == keys
+        for i, key in enumerate(keys):
+            assert np.array_equal(cnts[key]["contour"], g[f"ad_{k}_c{i}"])
+            assert len(cnts[key]["holes"]) == int(g[f"ad_{k}_c{i}_nh"])
+            for j, hct in enumerate(cnts[key]["holes"]):
+                assert np.array_equal(hct, g[f"ad_{k}_c{i}_h{j}"])
+        for f in gj["features"]:
+            f["id"] = "uuid"
+        assert json.loads(json.dumps(gj)) == json.loads(str(g[f"ad_{k}_geojson"]))
+        amap = Image.fromarray(grandqc.make_class_map(amask, grandqc.ARTIFACT_COLORS)).resize(
+            (int(tw * 50 / 512), int(th * 50 / 512)), Image.Resampling.LANCZOS)
+        assert np.array_equal(np.array(amap), g[f"ad_{k}_map"])
