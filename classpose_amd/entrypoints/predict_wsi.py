@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import queue
 import sys
@@ -237,9 +238,12 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     for R, idxs in by_size.items():                              # R: pixels read per tile side
         H, W = ops.resized_shape(R, R, plan.resize_factor)       # what the network sees
         n_sub = engine.make_tiling(H, W, 256, args.tta).ny ** 2
-        # sub-tiles per launch: 96 keeps the 256-row GEMM grid a near-multiple of the 256 CUs for the 9- and
-        # 25-sub-tile geometries too (+7..9 % over 32, tools/bench_variants.py); --batch_size can raise it
+        # sub-tiles per launch: >= 96 (+7..9 % over 32), and a multiple of 8 so that the 256-row GEMM grids keep their
+        # 8 x 4 super-tile order (tools/bench_variants.py: 9-sub-tile geometries 10 -> 16 tiles per launch +3..5 %,
+        # the 25-sub-tile one 3 -> 8 tiles +4.5 %); --batch_size can raise it
         nT = max(1, max(args.batch_size, 96) // n_sub)
+        step = 8 // math.gcd(n_sub, 8)
+        nT = -(-nT // step) * step
         eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
         extra = None
         provider = hooks.field_provider(slide, plan, n_classes) if hooks.field_provider else None
