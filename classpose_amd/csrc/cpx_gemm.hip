@@ -701,13 +701,21 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / nxcd;
         int tile_m, tile_n;
         if (EPI == CPX_EPI_QKV_BF16 && g.l2_block == 3) {
-            // balanced list for the qkv projection (launcher: 256 workgroups, tiles_m % 128 == 0, 12 column tiles): the
+            // balanced list for the qkv projection (launcher: 256 workgroups, tiles_m % 64 == 0, 12 column tiles): the
             // V^T tiles cost more (their transposed image needs the whole LDS, so nothing is prefetched under their
             // epilogue), hence every workgroup gets the same mix -- four q|k tiles, then two V^T tiles, per round -- and the
             // 32 workgroups of an XCD still cover one 8 x 4 super-tile at a time
-            // (rounds of 6: four q|k super-tiles and the two V^T super-tiles of the same 16 row tiles)
-            const int x = v & 7, slot = (v >> 3) & 31, i = v >> 8, rx = tiles_m >> 3, rnd = i / 6, j = i - rnd * 6;
-            const int rg = 2 * rnd + (j < 4 ? j >> 1 : j - 4), cg = j < 4 ? j & 1 : 2;
+            // (rounds of 6: four q|k super-tiles and the two V^T super-tiles of the same 16 row tiles; when the XCD's row
+            // count is an odd multiple of 8, a last half round of 3: two q|k super-tiles and one V^T of the last 8 rows)
+            const int x = v & 7, slot = (v >> 3) & 31, i = v >> 8, rx = tiles_m >> 3, full = rx >> 4;
+            int rg, cg;
+            if (i < 6 * full) {
+                const int rnd = i / 6, j = i - rnd * 6;
+                rg = 2 * rnd + (j < 4 ? j >> 1 : j - 4); cg = j < 4 ? j & 1 : 2;
+            } else {
+                const int j = i - 6 * full;
+                rg = 2 * full; cg = j < 2 ? j : 2;
+            }
             tile_m = x * rx + rg * 8 + (slot >> 2);
             tile_n = cg * 4 + (slot & 3);
         } else if (g.l2_block && (tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
@@ -1034,7 +1042,7 @@ template <int EPI, bool F16, int FLAGS>
 static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
     // the qkv projection keeps one workgroup per tile: a third of its tiles (the V^T ones) cannot overlap their
     // epilogue with the next prefetch and cost more, and a static tile list cannot balance that (measured +3 %)
-    const bool qkv_balanced = EPI == CPX_EPI_QKV_BF16 && g_gemm_persist_qkv && (a.n_blocks / a.tiles_n) % 128 == 0 && a.tiles_n == 12;
+    const bool qkv_balanced = EPI == CPX_EPI_QKV_BF16 && g_gemm_persist_qkv && (a.n_blocks / a.tiles_n) % 64 == 0 && a.tiles_n == 12;
     if (g_gemm_persist && (EPI != CPX_EPI_QKV_BF16 || qkv_balanced)) {
         static CpxOncePerDevice once_p;
         static int n_cu = 0;

@@ -1,6 +1,6 @@
 """A/B of the qkv projection: one workgroup per tile (k_gemm256) against the persistent kernel with the balanced
 q|k / V^T tile list (cpx_gemm_set_persistent_qkv), folded LayerNorm + V^T epilogue as in production; interleaved
-rounds in one process + bitwise comparison, for 32 and 96 sub-tiles."""
+rounds in one process + bitwise comparison, for 32, 96, 144 (a half round at the end) and 16 sub-tiles."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,7 @@ dev = torch.device("cuda:0"); L = _lib.lib()
 g = torch.Generator().manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 N, K = 3072, 1024
-for M in (32768, 98304):
+for M in (32768, 98304, 147456, 16384):
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
     b = torch.randn(N, generator=g).to(dev)
