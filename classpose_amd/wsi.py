@@ -80,6 +80,10 @@ class SlidePlan:
     read_tile_size: int
     read_overlap: int
     coords: list
+    # what main() reads back from the loader's manager.Value("f") slots (predict_wsi.py:1517-1524, 1793-1794): the mpp
+    # rounded to C floats, and the level-0-pixels-per-prediction-pixel scale of the polygons derived from THOSE
+    mpp_shared: tuple = (0.0, 0.0)
+    polygon_scale: float = 1.0
     rois: list | None = None
     tissue_cnts: list | None = None
     roi_class_dict: dict | None = None
@@ -101,8 +105,10 @@ def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePl
     resize_factor = float(np.float32(ts / scale))
     read_tile = max(1, round(tile_size / resize_factor))
     read_ov = max(0, round(overlap / resize_factor))
+    mpp_shared = (float(np.float32(mpp[0])), float(np.float32(mpp[1])))
     return SlidePlan(mpp, bounds, scale, level, dim, ts, resize_factor, read_tile, read_ov,
-                     get_coords(read_tile, read_ov, dim, ts))
+                     get_coords(read_tile, read_ov, dim, ts), mpp_shared=mpp_shared,
+                     polygon_scale=min(train_mpp / mpp_shared[0], train_mpp / mpp_shared[1]))
 
 
 def read_tile(slide, plan: SlidePlan, coords) -> np.ndarray:

@@ -314,6 +314,10 @@ def test_plan_slide_matches_reference_init_slide():
         assert list(p.bounds) == c["bounds"]
         assert p.level == c["level"] and list(p.slide_dim) == c["slide_dim"]
         assert p.ts == c["ts"] and p.resize_factor == c["resize_factor"]                  # float32 values, exactly
+        # main() reads mpp_x / mpp_y back from the loader's C-float slots and derives the polygon scale from THOSE
+        # (predict_wsi.py:1517-1524); the golden holds the slot values
+        assert list(p.mpp_shared) == [c["mpp_x"], c["mpp_y"]]
+        assert p.polygon_scale == min(c["train_mpp"] / c["mpp_x"], c["train_mpp"] / c["mpp_y"])
         assert len(p.coords) == c["n_coords"]
         as_list = lambda cs: [[list(map(int, x[0])), int(x[1])] for x in cs]
         assert as_list(p.coords[:3]) == c["coords_head"] and as_list(p.coords[-2:]) == c["coords_tail"]
