@@ -540,3 +540,52 @@ def test_conv3x3_implicit_gemm(cuda, dtype):
         ref = ref.permute(0, 2, 3, 1).reshape(S * 1024, N)
         err = (got.float() - ref).abs().max().item()
         assert err < (3e-2 if dtype == torch.bfloat16 else 4e-3), err
+
+
+def test_benched_path_all_subtiles_vs_reference_style_torch_on_gpu(cuda):
+    """The benched configuration against the reference's op sequence (F.linear / layer_norm / SDPA with the materialised
+    rel-pos bias / gelu: ``oracle.net.class_transformer_forward``) executed by PyTorch-ROCm ON THE SAME GPU: all 32
+    sub-tiles against the float32 run (the CPU oracle can afford three), and, for scale, how the hand-written network
+    compares with that eager path in the same precision -- error against float32 and time per 32-sub-tile batch."""
+    import ctypes as C
+    import time
+    L = _lib.lib()
+    nS, depth = 32, 24
+    sd = synth.make_state_dict(7, None, depth=depth, seed=3)
+    w = engine.NetWeights.from_state_dict(sd, "bf16", cuda, fuse_ln=True)
+    x = np.random.default_rng(0).random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5) \
+        .reshape(nS * 1024, 192).to(torch.bfloat16).to(cuda)
+    head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+    ws = torch.empty(L.cpx_net_workspace_bytes(nS, w.c.dtype), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def ours_forward():
+        _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    ours_forward()
+    out = head[:, :640].reshape(nS, 32, 32, 10, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(nS, 10, 256, 256)
+    ours = torch.cat([out[:, 3:], out[:, :3]], 1).clone()
+    xg = torch.from_numpy(x).to(cuda)
+    sd32 = {k: v.to(cuda) for k, v in sd.items()}
+    sdh = {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in sd32.items()}
+    with torch.no_grad():
+        ref32 = torch.cat([onet.class_transformer_forward(sd32, xg[i:i + 8]) for i in range(0, nS, 8)])
+        refh = onet.class_transformer_forward(sdh, xg, torch.bfloat16)
+    e_ours = [_rel(ours[i].cpu(), ref32[i].cpu()) for i in range(nS)]
+    e_torch = _rel(refh.cpu(), ref32.cpu())
+
+    def t(fn, reps):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    with torch.no_grad():
+        ms_torch = t(lambda: onet.class_transformer_forward(sdh, xg, torch.bfloat16), 3)
+    ms_ours = t(ours_forward, 10)
+    print(f"32 sub-tiles, depth 24, bf16 on one MI355X: hand-written network {ms_ours:.2f} ms, rel-L2 vs torch-GPU fp32 "
+          f"max {max(e_ours):.4f} / mean {np.mean(e_ours):.4f}; PyTorch-ROCm eager (reference op sequence) {ms_torch:.2f} ms, "
+          f"rel-L2 {e_torch:.4f}; speed-up {ms_torch / ms_ours:.2f}x")
+    assert max(e_ours) < 2e-2
+    assert np.mean(e_ours) < 1.5 * e_torch + 2e-3
