@@ -232,7 +232,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
     futures = []
     cells_all, xy_all, n_invalid = [], [], 0
-    scale = plan.polygon_scale        # from the float32 mpp, like the reference's main() (predict_wsi.py:1517-1524)
+    scale = plan.polygon_scale        # min(train_mpp / mpp_x, train_mpp / mpp_y) from the shared slots, predict_wsi.py:1517-1524
     t0 = time.time()
     n_done = 0
     for R, idxs in by_size.items():                              # R: pixels read per tile side
@@ -428,10 +428,10 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
                 # artefact area inside each ROI class: sum of polygon intersection areas (predict_wsi.py:1818-1828)
                 {k: sum(roi.intersection_area(a, p) for a in art_shown for p in v) if args.artefact_detection_model_path else 0
                  for k, v in plan.roi_class_dict.items()},
-                plan.mpp_shared[0], plan.mpp_shared[1], dens_labels)
+                plan.mpp[0], plan.mpp[1], dens_labels)
         else:
             df = outputs.densities_from_counts("tissue", {l: int((names == l).sum()) for l in dens_labels},
-                                               total_tissue_area, total_artefact_area, plan.mpp_shared[0], plan.mpp_shared[1],
+                                               total_tissue_area, total_artefact_area, plan.mpp[0], plan.mpp[1],
                                                dens_labels)
         df.to_csv(out / f"{base}_cell_densities.csv", index=False)
         logger.info(f"Saving cellular densities to {out}/{base}_cell_densities.csv")

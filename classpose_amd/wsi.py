@@ -80,9 +80,10 @@ class SlidePlan:
     read_tile_size: int
     read_overlap: int
     coords: list
-    # what main() reads back from the loader's manager.Value("f") slots (predict_wsi.py:1517-1524, 1793-1794): the mpp
-    # rounded to C floats, and the level-0-pixels-per-prediction-pixel scale of the polygons derived from THOSE
-    mpp_shared: tuple = (0.0, 0.0)
+    # level-0 pixels per prediction pixel, as main() derives it from the loader's shared mpp slots (predict_wsi.py:1517-1524,
+    # 1793-1794).  Those slots are ``tmproc.Manager().Value("f", ...)`` = multiprocessing.managers.Value, which stores the
+    # Python float as is (the typecode is ignored; only sharedctypes.Value would round to a C float) -- so mpp, bounds, ts and
+    # resize_factor are all read back as full doubles and this equals prediction_to_slide_scale.
     polygon_scale: float = 1.0
     rois: list | None = None
     tissue_cnts: list | None = None
@@ -93,22 +94,16 @@ def plan_slide(slide, tile_size: int, overlap: int, train_mpp: float) -> SlidePl
     mpp = get_slide_resolution(slide)
     bx = slide.properties.get("openslide.bounds-x")
     by = slide.properties.get("openslide.bounds-y")
-    # (also manager.Value("f") slots in the reference, predict_wsi.py:187-188,226-229: the offset later subtracted from
-    # every coordinate is the float32-rounded one)
-    bounds = (float(np.float32(float(bx))) if bx is not None else 0.0, float(np.float32(float(by))) if by is not None else 0.0)
+    bounds = (float(bx) if bx is not None else 0.0, float(by) if by is not None else 0.0)
     scale = min(train_mpp / mpp[0], train_mpp / mpp[1])
     level = slide.get_best_level_for_downsample(scale)
     dim = tuple(slide.level_dimensions[level])
-    # the reference keeps both in manager.Value("f", ...) slots, i.e. C floats
-    # (predict_wsi.py:184,191,245-246): every later use sees the float32-rounded value
-    ts = float(np.float32(slide.level_downsamples[level]))
-    resize_factor = float(np.float32(ts / scale))
+    ts = slide.level_downsamples[level]
+    resize_factor = ts / scale
     read_tile = max(1, round(tile_size / resize_factor))
     read_ov = max(0, round(overlap / resize_factor))
-    mpp_shared = (float(np.float32(mpp[0])), float(np.float32(mpp[1])))
     return SlidePlan(mpp, bounds, scale, level, dim, ts, resize_factor, read_tile, read_ov,
-                     get_coords(read_tile, read_ov, dim, ts), mpp_shared=mpp_shared,
-                     polygon_scale=min(train_mpp / mpp_shared[0], train_mpp / mpp_shared[1]))
+                     get_coords(read_tile, read_ov, dim, ts), polygon_scale=min(train_mpp / mpp[0], train_mpp / mpp[1]))
 
 
 def read_tile(slide, plan: SlidePlan, coords) -> np.ndarray:

@@ -115,9 +115,13 @@ def main():
                 f.write(text)
             yaml_cases.append({"yaml": text, "config": rmc.ModelConfig.load_from_yaml(yp).model_dump()})
 
-    # a1: SlideLoader._init_slide (predict_wsi.py:220-278) run unbound on a fake self whose shared values are C floats like
-    # manager.Value("f") and whose reader is a fabricated multi-level slide (OpenSlide's level-selection rule)
-    import ctypes
+    # a1: SlideLoader._init_slide (predict_wsi.py:220-278) run unbound on a fake self whose shared values are REAL
+    # multiprocessing.Manager().Value("f", ...) proxies -- what tmproc.Manager() hands the reference (predict_wsi.py:180-191):
+    # managers.Value stores the Python object as is (the typecode is ignored; only sharedctypes.Value rounds to a C float),
+    # so every slot reads back the full double -- and whose reader is a fabricated multi-level slide (OpenSlide's
+    # level-selection rule)
+    import multiprocessing
+    manager = multiprocessing.Manager()
     init_cases = []
     for spec in (
         dict(dims=[(40000, 30000), (10000, 7500), (2500, 1875)], down=[1.0, 4.0, 16.0], props={"openslide.mpp-x": "0.25", "openslide.mpp-y": "0.25"},
@@ -141,7 +145,7 @@ def main():
                     if d <= ds:
                         best = i
                 return best
-        fv = lambda: ctypes.c_float(0.0)
+        fv = lambda: manager.Value("f", 0)
         me = types.SimpleNamespace(slide_path="fake", tile_size=spec["tile"], overlap=spec["overlap"], train_mpp=spec["train_mpp"],
                                    roi_tree=None, mpp_x=fv(), mpp_y=fv(), bounds_x=fv(), bounds_y=fv(), ts=fv(), resize_factor=fv(),
                                    real_slide_path="fake")
@@ -159,6 +163,8 @@ def main():
                            "coords_head": [[list(map(int, c[0])), int(c[1])] for c in me.coords[:3]],
                            "coords_tail": [[list(map(int, c[0])), int(c[1])] for c in me.coords[-2:]],
                            "coords_sum": [int(sum(c[0][0] for c in me.coords)), int(sum(c[0][1] for c in me.coords))]})
+
+    manager.shutdown()
 
     # a3: the output size of resize_tile_to_target_mpp (predict_wsi.py:102-123; Python's round-half-even on h * factor),
     # observed through a recording stand-in for cv2.resize

@@ -119,11 +119,11 @@ def test_oracle_resize_linear_properties():
 
 
 def test_plan_slide_rescaled():
-    """_init_slide arithmetic with slide mpp != model mpp (float32 shared values)"""
+    """_init_slide arithmetic with slide mpp != model mpp (the shared manager.Value slots keep doubles)"""
     from classpose_amd import wsi
     plan = wsi.plan_slide(wsi.WSIReader("synthetic://9000x7000?mpp=0.2431"), 1024, 64, 0.5)
     scale = 0.5 / 0.2431
-    rf = float(np.float32(1.0 / scale))
+    rf = 1.0 / scale
     assert plan.resize_factor == rf and plan.read_tile_size == round(1024 / rf) == 2106
     assert plan.read_overlap == round(64 / rf)
     assert max(1, int(round(plan.read_tile_size * rf))) == 1024

@@ -289,7 +289,7 @@ def test_cli_arguments_match_reference_goldens():
 
 def test_plan_slide_matches_reference_init_slide():
     """a1 / a2: ``SlideLoader._init_slide`` (predict_wsi.py:220-278) run by the reference itself on fabricated multi-level
-    slides -- mpp, bounds, level choice, the float32 ``ts`` / ``resize_factor`` of its manager.Value("f") slots, the
+    slides -- mpp, bounds, level choice, ``ts`` / ``resize_factor`` as its manager.Value("f") slots return them (full doubles: a real Manager is used), the
     read-tile geometry and the whole tile grid -- against ``wsi.plan_slide``."""
     import json
     import os
@@ -313,10 +313,10 @@ def test_plan_slide_matches_reference_init_slide():
         assert list(p.mpp) == c["mpp"]
         assert list(p.bounds) == c["bounds"]
         assert p.level == c["level"] and list(p.slide_dim) == c["slide_dim"]
-        assert p.ts == c["ts"] and p.resize_factor == c["resize_factor"]                  # float32 values, exactly
-        # main() reads mpp_x / mpp_y back from the loader's C-float slots and derives the polygon scale from THOSE
-        # (predict_wsi.py:1517-1524); the golden holds the slot values
-        assert list(p.mpp_shared) == [c["mpp_x"], c["mpp_y"]]
+        assert p.ts == c["ts"] and p.resize_factor == c["resize_factor"]                  # exactly
+        # main() reads mpp_x / mpp_y back from the loader's shared slots and derives the polygon scale from THOSE
+        # (predict_wsi.py:1517-1524); the golden holds the slot values (doubles)
+        assert list(p.mpp) == [c["mpp_x"], c["mpp_y"]]
         assert p.polygon_scale == min(c["train_mpp"] / c["mpp_x"], c["train_mpp"] / c["mpp_y"])
         assert len(p.coords) == c["n_coords"]
         as_list = lambda cs: [[list(map(int, x[0])), int(x[1])] for x in cs]
