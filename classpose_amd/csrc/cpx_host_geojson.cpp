@@ -134,10 +134,10 @@ void format_chunk(const Job &j, int64_t lo, int64_t hi, bool first_chunk, Rng &r
         double cx = j.cen[2 * i], cy = j.cen[2 * i + 1];
         if (j.shift) { cx -= j.bx; cy -= j.by; }
         meas.clear();
-        meas += "[{\"name\": \"area\", \"value\": "; put_double(meas, c.area, false);
-        meas += "}, {\"name\": \"perimeter\", \"value\": "; put_double(meas, c.perimeter, false);
-        meas += "}, {\"name\": \"centroidX\", \"value\": "; put_double(meas, cx, false);
-        meas += "}, {\"name\": \"centroidY\", \"value\": "; put_double(meas, cy, false);
+        meas += "[{\"name\": \"area\", \"value\": "; put_double(meas, c.area, true);
+        meas += "}, {\"name\": \"perimeter\", \"value\": "; put_double(meas, c.perimeter, true);
+        meas += "}, {\"name\": \"centroidX\", \"value\": "; put_double(meas, cx, true);
+        meas += "}, {\"name\": \"centroidY\", \"value\": "; put_double(meas, cy, true);
         meas += "}]";
         const char *sep = (first_chunk && k == lo) ? "" : ", ";
         // polygon
@@ -157,7 +157,7 @@ void format_chunk(const Job &j, int64_t lo, int64_t hi, bool first_chunk, Rng &r
         // centroid
         fp += sep; fp += "{\"type\": \"Feature\", \"id\": \""; put_uuid4(fp, rng);
         fp += "\", \"geometry\": {\"type\": \"Point\", \"coordinates\": [";
-        put_double(fp, cx, false); fp += ", "; put_double(fp, cy, false);
+        put_double(fp, cx, true); fp += ", "; put_double(fp, cy, true);
         fp += "]}, \"properties\": {\"objectType\": \"annotation\", \"isLocked\": false, \"classification\": ";
         fp += cls; fp += ", \"measurements\": "; fp += meas; fp += "}}";
     }

@@ -90,6 +90,7 @@ class TileStream:
         # optional gate: batches >= gate_at are not read (nor copied) before release() -- bench.py times a region that
         # starts with a warm reader thread but with none of its tiles read ahead
         self.gate_at, self.gate = gate_at, threading.Event()
+        self._stop = threading.Event()
         n_workers = max(2, min(32, (os.cpu_count() or 4) // 2))
         self.ahead = max(depth, -(-n_workers // max(nT, 1)))        # batches being decoded at once
         self.q: queue.Queue = queue.Queue(maxsize=depth)
@@ -104,6 +105,23 @@ class TileStream:
 
     def release(self):
         self.gate.set()
+
+    def close(self):
+        """stop reading: wakes a reader parked at the gate (a consumer that failed before ``release()`` would otherwise
+        leave the thread, its pool and the pinned buffers waiting until process exit) and lets ``_run`` wind down"""
+        self._stop.set()
+        self.gate.set()
+        while True:                                  # unblock a producer parked on the full queue
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                break
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def start(self):
         """begin reading / copying (``autostart=False``: buffers and threads exist, nothing has been read yet)"""
@@ -127,14 +145,19 @@ class TileStream:
             n_batches = -(-len(self.idxs) // self.nT)
             pending = []
             nxt = 0
-            while nxt < n_batches or pending:
+            while (nxt < n_batches or pending) and not self._stop.is_set():
                 while nxt < n_batches and len(pending) < self.ahead:
                     if self.gate_at is not None and nxt >= self.gate_at and not self.gate.is_set():
                         if pending:
                             break                        # hand over what was read before the gate first
-                        self.gate.wait()
+                        while not self.gate.wait(0.5):
+                            pass
+                        if self._stop.is_set():
+                            break
                     pending.append(self._submit(nxt))
                     nxt += 1
+                if self._stop.is_set() or not pending:
+                    break
                 chunk, slot, futs = pending.pop(0)
                 extras = [f.result() for f in futs]
                 with torch.cuda.stream(self.copy_stream):
@@ -142,8 +165,14 @@ class TileStream:
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 self.copied[slot] = ev
-                self.q.put((chunk, dev, ev, extras))
-            self.q.put(None)
+                while not self._stop.is_set():
+                    try:
+                        self.q.put((chunk, dev, ev, extras), timeout=0.5)
+                        break
+                    except queue.Full:
+                        pass
+            if not self._stop.is_set():
+                self.q.put(None)
         except BaseException as e:      # surface reader errors in the consumer
             self.q.put(e)
         finally:
@@ -339,14 +368,34 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
         return None
     cen = geojson.rounded_centroids(cells)
     t_dd = time.time()
-    if os.getenv("CLASSPOSE_DEDUP_BACKEND", "device") == "scipy" or device is None:
-        # scipy's KDTree + the loop over ITS set: the reference's exact tie-breaking in >= 3-cell clusters
-        keep = np.asarray(geojson.dedup_indices(cen, cells["area"]), dtype=np.int64)
-        logger.info(f"De-duplication (scipy KDTree): {time.time() - t_dd:.2f} s")
-    else:
-        pairs = ops.dedup_pairs(cen, 15 / 2, device)                        # radius search on the device (f2)
-        keep = geojson.dedup_from_pairs(len(cells), cells["area"], pairs)   # the reference's set-order grouping
-        logger.info(f"De-duplication: {len(pairs)} neighbour pairs, {time.time() - t_dd:.2f} s")
+    # Identity with the reference first: the default walks scipy's own pair set in ITS order (geojson.dedup_exact).  The
+    # device radius search (f2) finds the identical pair set ~10x faster but cannot know that set's iteration order, which
+    # decides who survives in clusters of >= 3 cells -- so it is opt-in (CLASSPOSE_DEDUP_BACKEND=device) and says how many
+    # cells it may have decided differently.
+    backend = os.getenv("CLASSPOSE_DEDUP_BACKEND", "exact")
+    keep = None
+    if backend == "device" and device is not None:
+        try:
+            pairs = ops.dedup_pairs(cen, 15 / 2, device)
+            keep = geojson.dedup_from_pairs(len(cells), cells["area"], pairs)
+            n_od = geojson.count_order_dependent(len(cells), pairs)
+            logger.info(f"De-duplication (device pair search, CLASSPOSE_DEDUP_BACKEND=device): {len(pairs)} neighbour pairs, "
+                        f"{time.time() - t_dd:.2f} s")
+            if n_od:
+                logger.warning(f"{n_od} cells sit in clusters of >= 3 neighbours, where the reference's result depends on the "
+                               "iteration order of its Python set: the fast path models that order (hash slots) and a "
+                               "fraction of a percent of THESE cells can differ from the reference; unset "
+                               "CLASSPOSE_DEDUP_BACKEND for the exact path")
+        except Exception as e:          # e.g. the dense 8-px grid of a huge sparse slide does not fit: the exact path always works
+            logger.warning(f"device de-duplication failed ({e}); falling back to the exact host path")
+            keep = None
+    elif backend not in ("exact", "scipy", "device"):
+        raise ValueError(f"CLASSPOSE_DEDUP_BACKEND={backend!r}: expected 'exact' (default) or 'device'")
+    if keep is None:
+        st: dict = {}
+        keep = geojson.dedup_exact(cen, cells["area"], stats=st)
+        logger.info(f"De-duplication (scipy KDTree pair set, the reference's own order): {st.get('n_pairs', 0)} neighbour pairs, "
+                    f"{st.get('n_order_dependent', 0)} cells in order-dependent clusters (>= 3 neighbours), {time.time() - t_dd:.2f} s")
     logger.info(f"Number of cells after de-duplication: {len(keep)}")
 
     def filter_within(keep, polys):          # STRtree.query(points, "within"): one hit per containing polygon
@@ -469,6 +518,12 @@ def _spawn_entry(local_rank: int, world: int, port: int, arg_dict: dict, dev_ids
 
 def main(args, spawned: bool = False, parser_factory=None):
     _check_unsupported(args)
+    if getattr(args, "inference_threads", None) is not None and not spawned:
+        # the reference starts N Python threads per device that each call model.eval on one tile (predict_wsi.py:728-798);
+        # here ONE host thread per GPU batches tiles across the whole slide into every launch, which is what those
+        # threads were approximating -- the flag is accepted for drop-in compatibility and has no effect
+        logger.info(f"--inference_threads {args.inference_threads} is superseded: this engine batches tiles across the slide "
+                    "into each launch from one host thread per GPU (cross-tile batching replaces the per-tile eval threads)")
     devices = get_device(args.device)
     env_world = int(os.environ.get("WORLD_SIZE", 1))
     if len(devices) > 1 and env_world == 1 and not spawned:

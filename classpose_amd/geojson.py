@@ -141,55 +141,109 @@ def _fast_set_table_mask(n: int) -> int:
         mask = size - 1
 
 
-def dedup_from_pairs(n: int, sizes, pairs: np.ndarray) -> np.ndarray:
-    """Indices kept by ``deduplicate`` (predict_wsi.py:929-965) given the neighbour pairs (i < j) that
-    ``tree.query_pairs`` returns -- here the device radius search (``ops.dedup_pairs``).
+def _group_pairs_in_order(ordered, sizes, keep) -> None:
+    """The reference's grouping loop (predict_wsi.py:929-960) over pairs visited in the given order; clears ``keep``
+    for every cell it removes."""
+    groups: dict[int, list] = {}
+    member_to_group: dict[int, int] = {}
+    for pair in ordered:
+        if pair[0] not in member_to_group and pair[1] not in member_to_group:
+            gi = len(groups)
+            groups[gi] = []
+            member_to_group[pair[0]] = gi
+            member_to_group[pair[1]] = gi
+        else:
+            gi = member_to_group[pair[0]] if pair[0] in member_to_group else member_to_group[pair[1]]
+        if pair[0] not in groups[gi]:
+            groups[gi].append(pair[0])
+        if pair[1] not in groups[gi]:
+            groups[gi].append(pair[1])
+    szl = sizes.tolist() if hasattr(sizes, "tolist") else list(sizes)
+    for group in groups.values():
+        if len(group) > 1:
+            largest = group[int(np.argmax([szl[i] for i in group]))]
+            for i in group:
+                if i != largest:
+                    keep[i] = False
 
-    The reference walks ``neighbours`` -- a Python ``set`` of tuples -- in set order and groups greedily, so its
-    result depends on that order whenever a connected component of the pair graph has three or more cells
-    (and on the list order inside a group for equal areas).  Components of exactly two cells -- the bulk: one
-    cell seen by two overlapping tiles -- do not depend on any order (group [i, j], ``argmax`` keeps i on equal
-    areas) and are resolved vectorised.  The pairs of the larger components go through the reference's loop
-    verbatim, visited in the order of their slot in the hash table the reference's set would have
-    (``hash((i, j)) & mask`` with the mask of a set holding ALL pairs): that IS the set's iteration order except
-    for entries displaced by hash collisions, whose position also depends on scipy's insertion order (a property
-    of the reference's set that no pair list can carry)."""
-    sizes = np.asarray(sizes)
-    keep = np.ones(n, bool)
-    if len(pairs) == 0:
-        return np.flatnonzero(keep)
-    pi, pj = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+
+def _split_simple(n: int, sizes, pi, pj, keep):
+    """Resolves the connected components of exactly two cells (the bulk: one cell seen by two overlapping tiles) --
+    they do not depend on any visiting order: group [i, j] with i < j, ``np.argmax`` keeps i on equal areas -- and
+    returns the mask of the pairs that belong to larger components."""
     deg = np.bincount(pi, minlength=n) + np.bincount(pj, minlength=n)
     simple = (deg[pi] == 1) & (deg[pj] == 1)
     si, sj = pi[simple], pj[simple]
     drop_j = sizes[si] >= sizes[sj]                      # np.argmax([s_i, s_j]) == 0 unless s_j is strictly larger
     keep[np.where(drop_j, sj, si)] = False
-    if not simple.all():
-        ci, cj = pi[~simple], pj[~simple]
+    return ~simple
+
+
+def count_order_dependent(n: int, pairs: np.ndarray) -> int:
+    """Number of cells that sit in connected components of three or more cells of the neighbour graph: the cells whose
+    fate in the reference's ``deduplicate`` depends on the iteration order of its Python set of pairs."""
+    if len(pairs) == 0:
+        return 0
+    pi, pj = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    deg = np.bincount(pi, minlength=n) + np.bincount(pj, minlength=n)
+    cx = ~((deg[pi] == 1) & (deg[pj] == 1))
+    return int(len(np.unique(np.concatenate([pi[cx], pj[cx]]))))
+
+
+def dedup_exact(centers, sizes, max_dist: float = 15 / 2, stats: dict | None = None) -> np.ndarray:
+    """Indices kept by the reference's ``deduplicate`` (predict_wsi.py:896-965), result-identical to it, at array speed.
+
+    The neighbour pairs come from the same call as in the reference -- ``KDTree(centers).query_pairs(max_dist)``, a
+    Python ``set`` of (i, j) tuples with i < j -- and are visited in THAT set's iteration order, which is what decides
+    the outcome inside connected components of three or more cells (4x corner overlaps, chains).  Components never
+    interact in the reference's loop (a pair only ever joins the group of one of its own two cells), and components
+    of exactly two cells do not depend on the order at all, so those are resolved vectorised and only the pairs of the
+    larger components run through the loop, in their relative set order.  ``tests/test_dedup.py`` checks equality
+    with the verbatim loop (``dedup_indices``)."""
+    n = len(centers)
+    keep = np.ones(n, bool)
+    if n == 0:
+        return np.flatnonzero(keep)
+    sizes = np.asarray(sizes)
+    neighbours = KDTree(np.asarray(centers, dtype=np.float64)).query_pairs(max_dist)
+    if stats is not None:
+        stats["n_pairs"] = len(neighbours)
+        stats["n_order_dependent"] = 0
+    if not neighbours:
+        return np.flatnonzero(keep)
+    from itertools import chain
+    arr = np.fromiter(chain.from_iterable(neighbours), np.int64, 2 * len(neighbours)).reshape(-1, 2)   # set order kept
+    pi, pj = arr[:, 0], arr[:, 1]
+    cx = _split_simple(n, sizes, pi, pj, keep)
+    if cx.any():
+        if stats is not None:
+            stats["n_order_dependent"] = int(len(np.unique(np.concatenate([pi[cx], pj[cx]]))))
+        _group_pairs_in_order(zip(pi[cx].tolist(), pj[cx].tolist()), sizes, keep)
+    return np.flatnonzero(keep)
+
+
+def dedup_from_pairs(n: int, sizes, pairs: np.ndarray) -> np.ndarray:
+    """FAST, APPROXIMATE-IN-CLUSTERS variant of ``deduplicate`` (predict_wsi.py:929-965) given the neighbour pairs
+    (i < j) from the device radius search (``ops.dedup_pairs``; opt-in: ``CLASSPOSE_DEDUP_BACKEND=device``).
+
+    The pair SET is exact.  The reference walks its Python ``set`` of pairs in set order, so inside connected components
+    of three or more cells its result depends on that order.  Components of exactly two cells are order-free and are
+    resolved vectorised; the pairs of the larger components are visited in the order of their slot in the hash table
+    the reference's set would have (``hash((i, j)) & mask`` with the mask of a set holding ALL pairs): that IS the
+    set's iteration order except for entries displaced by hash collisions, whose position also depends on scipy's
+    insertion order (which no pair list carries) -- a fraction of a percent of the cells of such clusters can differ
+    from the reference.  ``dedup_exact`` is the default and has no such caveat."""
+    sizes = np.asarray(sizes)
+    keep = np.ones(n, bool)
+    if len(pairs) == 0:
+        return np.flatnonzero(keep)
+    pi, pj = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    cx = _split_simple(n, sizes, pi, pj, keep)
+    if cx.any():
+        ci, cj = pi[cx], pj[cx]
         slot = _tuple2_hash(ci, cj) & np.uint64(_fast_set_table_mask(len(pairs)))
         order = np.argsort(slot, kind="stable")
-        ordered = list(zip(ci[order].tolist(), cj[order].tolist()))
-        groups: dict[int, list] = {}
-        member_to_group: dict[int, int] = {}
-        for pair in ordered:
-            if pair[0] not in member_to_group and pair[1] not in member_to_group:
-                gi = len(groups)
-                groups[gi] = []
-                member_to_group[pair[0]] = gi
-                member_to_group[pair[1]] = gi
-            else:
-                gi = member_to_group[pair[0]] if pair[0] in member_to_group else member_to_group[pair[1]]
-            if pair[0] not in groups[gi]:
-                groups[gi].append(pair[0])
-            if pair[1] not in groups[gi]:
-                groups[gi].append(pair[1])
-        szl = sizes.tolist() if hasattr(sizes, "tolist") else list(sizes)
-        for group in groups.values():
-            if len(group) > 1:
-                largest = group[int(np.argmax([szl[i] for i in group]))]
-                for i in group:
-                    if i != largest:
-                        keep[i] = False
+        _group_pairs_in_order(zip(ci[order].tolist(), cj[order].tolist()), sizes, keep)
     return np.flatnonzero(keep)
 
 

@@ -16,6 +16,12 @@ import os
 import torch
 import torch.distributed as dist
 
+# The pool's host driver only supports dmabuf IPC: without this setting RCCL's intra-node transport (and any sharing of
+# device tensors across processes) fails with ``hipIpcGetMemHandle: invalid argument``.  It has to be in the environment
+# before the HIP runtime initialises, so it is set when this module is imported (every multi-process entry point --
+# bench.py, the CLI's per-GPU children, the tests -- imports it first); an explicit value in the environment wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def env_rank_world() -> tuple[int, int, int]:
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),

@@ -1,5 +1,7 @@
-"""f2: de-duplication split into the device radius search (cpx_dedup_pairs) and the reference's set-order
-greedy grouping on the host (geojson.dedup_from_pairs); predict_wsi.py:896-965."""
+"""a18 / f2: de-duplication (predict_wsi.py:896-965).  Default = ``geojson.dedup_exact``: scipy's own pair set walked in
+ITS order, result-identical to the reference (equality tests below).  Opt-in fast path = the device radius search
+(cpx_dedup_pairs, exact pair set) + ``geojson.dedup_from_pairs`` (models the set order; documented tolerance inside
+clusters of >= 3 cells only)."""
 import numpy as np
 import pytest
 from scipy.spatial import KDTree
@@ -35,6 +37,35 @@ def test_dedup_from_pairs_equals_reference_loop_golden(golden):
     pts = np.array(js["geojson"]["points"])
     pairs = _scipy_pairs(pts[:, :2])
     assert geojson.dedup_from_pairs(len(pts), pts[:, 2], pairs).tolist() == js["geojson"]["kept_ids"]
+
+
+def test_dedup_exact_equals_reference_golden(golden):
+    """the default path against the kept ids of the reference's own deduplicate (incl. the A-B-C chain)"""
+    _, js = golden
+    pts = np.array(js["geojson"]["points"])
+    st = {}
+    assert geojson.dedup_exact(pts[:, :2], pts[:, 2], stats=st).tolist() == js["geojson"]["kept_ids"]
+    assert st["n_pairs"] == len(_scipy_pairs(pts[:, :2])) and st["n_order_dependent"] >= 3
+
+
+@pytest.mark.parametrize("seed,n_cells", [(0, 3000), (1, 3000), (2, 3000), (3, 60000)])
+def test_dedup_exact_equals_verbatim_loop(seed, n_cells):
+    """EQUALITY (no tolerance) of the default path with the reference's loop run verbatim over scipy's own set
+    (geojson.dedup_indices, golden-pinned), on cell tables full of >= 3-cell clusters, equal areas and chains"""
+    c, a = _clustered(np.random.default_rng(seed), n_cells, 4000.0 * (n_cells / 3000) ** 0.5)
+    st = {}
+    got = geojson.dedup_exact(c, a, stats=st).tolist()
+    ref = geojson.dedup_indices(c.tolist(), a.tolist())
+    assert got == ref
+    assert st["n_order_dependent"] > 0.1 * n_cells                       # the order-dependent case is what is being tested
+    assert st["n_order_dependent"] == geojson.count_order_dependent(len(c), _scipy_pairs(c))
+
+
+def test_dedup_exact_trivial_inputs():
+    assert geojson.dedup_exact(np.zeros((0, 2)), np.zeros(0)).tolist() == []
+    assert geojson.dedup_exact(np.array([[0.0, 0.0], [100.0, 0.0]]), np.ones(2)).tolist() == [0, 1]
+    assert geojson.dedup_exact(np.array([[0.0, 0.0], [3.0, 0.0]]), np.array([5.0, 5.0])).tolist() == [0]      # tie keeps i
+    assert geojson.dedup_exact(np.array([[0.0, 0.0], [3.0, 0.0]]), np.array([5.0, 6.0])).tolist() == [1]
 
 
 def _reference_loop(n, sizes, neighbours):
@@ -78,8 +109,8 @@ def _assert_same_up_to_ambiguous_clusters(n, pairs, got, ref, max_frac):
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_dedup_from_pairs_equals_reference_loop_random(seed):
-    """the hybrid (vectorised 2-cell components + the reference's loop over the remaining pairs in hash-slot
-    order) against (1) the reference's loop run verbatim over a Python set of the same pairs and (2) the loop
+    """the OPT-IN fast path (vectorised 2-cell components + the reference's loop over the remaining pairs in hash-slot
+    order; CLASSPOSE_DEDUP_BACKEND=device) against (1) the reference's loop run verbatim over a Python set of the same pairs and (2) the loop
     over scipy's own set (geojson.dedup_indices, golden-pinned): identical outside >= 3-cell clusters, and
     inside them up to the collision-displacement ambiguity of the reference's set order, ties and chains included"""
     c, a = _clustered(np.random.default_rng(seed), 3000, 4000.0)

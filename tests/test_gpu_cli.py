@@ -435,3 +435,83 @@ def test_predict_wsi_cli_roi_class_densities_with_artefacts(cuda, tmp_path, monk
         assert len(got_eff) > 0
         # the artefact contour follows 1.5 um/px thumbnail pixels (3 level-0 px): a few 1e-3 of the ROI area
         assert np.allclose(got_eff, eff, rtol=0.01), (name, float(got_eff.iloc[0]), eff)
+
+
+@pytest.mark.parametrize("props_kind", ["openslide-mpp+bounds", "tiff-resolution"])
+def test_predict_wsi_cli_openslide_protocol_reader_at_level_1(cuda, tmp_path, monkeypatch, props_kind):
+    """f4: an OpenSlide-PROTOCOL reader through the tile loop (predict_wsi.py:220-278, 446-451, 463-482; reader switch
+    src/classpose/__init__.py:6-41): ``WSI_READER=openslide`` imports ``openslide.OpenSlide`` (tests/fake_openslide.py
+    installed as that module), a 3-level pyramid, mpp from ``openslide.mpp-*`` or from ``tiff.*Resolution``, a level > 0
+    chosen by ``get_best_level_for_downsample``, ``read_region`` in level-0 coordinates returning RGBA ``PIL.Image``s, a
+    residual rescale (0.8) on the device, and ``openslide.bounds-*`` subtracted from the outputs.  The raw cells of the
+    tile loop equal those of the ``synthetic://`` run of the same pixels under the exact level-1 -> level-0 map (x2), and the
+    files of the full CLI run are those cells after the reference's de-duplication and bounds shift."""
+    import sys
+    import fake_openslide as fo
+    from classpose_amd import geojson, hooks, wsi
+    from classpose_amd.entrypoints import predict_wsi
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "fake_openslide")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    monkeypatch.setenv("WSI_READER", "openslide")
+    monkeypatch.setitem(sys.modules, "openslide", fo)
+    W1, H1, seed = 1000, 700, 9
+    if props_kind == "tiff-resolution":
+        props, bounds = {"tiff.XResolution": "50000", "tiff.YResolution": "50000", "tiff.ResolutionUnit": "centimeter"}, (0.0, 0.0)
+    else:
+        props, bounds = {"openslide.mpp-x": "0.2", "openslide.mpp-y": "0.2", "openslide.bounds-x": "100", "openslide.bounds-y": "60.5"}, (100.0, 60.5)
+    path = str(tmp_path / "fake_slide.svs")
+    fo.SLIDES[path] = dict(seed=seed, base_level=1, base_dims=(W1, H1), downsamples=[1.0, 2.0, 8.0], properties=props)
+    fo.READS.clear()
+    out_f, out_s = tmp_path / "fake", tmp_path / "synth"
+    common = ["--model_config", "conic", "--tile_size", "256", "--overlap", "32", "--device", "cuda:0"]
+    args_f = predict_wsi.build_parser().parse_args(common + ["--slide_path", path, "--output_folder", str(out_f)])
+    args_s = predict_wsi.build_parser().parse_args(common + ["--slide_path", f"synthetic://{W1}x{H1}?mpp=0.4&seed={seed}",
+                                                             "--output_folder", str(out_s)])
+    # ---- slide planning: level 1 (downsample 2 <= 0.5 / 0.2 = 2.5), 320-px reads, residual factor 0.8
+    slide = wsi.WSIReader(path)
+    assert isinstance(slide, fo.OpenSlide) and slide.level_dimensions == ((2000, 1400), (1000, 700), (250, 175))
+    plan = wsi.plan_slide(slide, 256, 32, 0.5)
+    assert plan.level == 1 and plan.ts == 2.0 and plan.resize_factor == 0.8 and plan.read_tile_size == 320
+    assert plan.mpp == (0.2, 0.2) and plan.bounds == bounds and plan.polygon_scale == 2.5
+    assert len(plan.coords) == 6 and plan.coords[1] == ((0, 560), 320) and plan.coords[-1] == ((1120, 560), 320)
+    # ---- the tile loop on both readers
+    cells_f, xy_f, labels, _ = predict_wsi.run_rank(args_f, 0, 1, cuda)
+    assert len(fo.READS) == 6 and all(r[2] == 1 and r[3] == (320, 320) for r in fo.READS)         # every read at level 1
+    assert sorted(r[1] for r in fo.READS) == sorted(c[0] for c in plan.coords)                   # origins in level-0 pixels
+    hooks.reset()
+    cells_s, xy_s, _, plan_s = predict_wsi.run_rank(args_s, 0, 1, cuda)
+    assert plan_s.level == 0 and plan_s.resize_factor == 0.8 and plan_s.polygon_scale == 1.25
+    assert len(cells_f) == len(cells_s) > 150
+    assert np.array_equal(xy_f, 2.0 * xy_s)                                    # same contours, level-1 -> level-0 pixels
+    assert np.array_equal(cells_f["area"], 4.0 * cells_s["area"]) and np.array_equal(cells_f["perimeter"], 2.0 * cells_s["perimeter"])
+    assert np.array_equal(cells_f["cx"], 2.0 * cells_s["cx"]) and np.array_equal(cells_f["cy"], 2.0 * cells_s["cy"])
+    assert np.array_equal(cells_f["cls"], cells_s["cls"]) and np.array_equal(cells_f["n_pts"], cells_s["n_pts"])
+    # every nucleus well inside the covered area is found, at 2x its level-1 position
+    cx, cy, r, _ = synth.nuclei_in_region(seed, 0, 0, 880, 600)
+    inner = (cx - r > 15) & (cx + r < 880 - 15) & (cy - r > 15) & (cy + r < 600 - 15)
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(np.stack([cells_f["cx"], cells_f["cy"]], 1)).query(2.0 * np.stack([cx[inner], cy[inner]], 1))
+    assert (d < 4.0).mean() > 0.99
+    # ---- the whole CLI on the fake reader: files == those cells through the reference-shaped (golden-pinned) functions
+    hooks.reset()
+    fo.READS.clear()
+    predict_wsi.main(args_f)
+    assert len(fo.READS) == 6
+    offs = np.concatenate([[0], np.cumsum(cells_f["n_pts"])])
+    feats = []
+    for i, c in enumerate(cells_f):
+        centroid = np.round([c["cx"], c["cy"]], 2).tolist()
+        feats.append(geojson.to_geojson_polygon(geojson.cell_dict(xy_f[offs[i]:offs[i + 1]].tolist(), int(c["cls"]), labels,
+                                                                  c["area"], c["perimeter"], centroid)))
+    feats = [geojson.apply_bounds_offset_to_feature(f, *bounds) for f in geojson.deduplicate(feats)]
+    cont = json.load(open(next(out_f.glob("*contours.geojson"))))["features"]
+    cent = json.load(open(next(out_f.glob("*centroids.geojson"))))["features"]
+    assert 100 < len(cont) == len(feats) == len(cent) < len(cells_f)
+    strip = lambda fs: [{k: v for k, v in f.items() if k != "id"} for f in fs]
+    assert strip(cont) == strip(json.loads(json.dumps(feats)))
+    assert strip(cent) == strip(json.loads(json.dumps(geojson.polygons_to_centroids(feats))))
+    if bounds != (0.0, 0.0):
+        xs = np.concatenate([np.asarray(f["geometry"]["coordinates"][0])[:, 0] for f in cont])
+        assert xs.min() < 0                                   # cells left of the bounds origin come out negative, as in the reference

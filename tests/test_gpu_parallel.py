@@ -21,8 +21,9 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    from classpose_amd import engine, parallel, synth
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from classpose_amd import engine, parallel, synth          # parallel sets HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL needs dmabuf IPC here)
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
     r, w, local = parallel.init_distributed("nccl")
     dev = torch.device("cuda", local)
     # one engine step on this rank's shard of a 3 x 3 tile grid, then the path's only collective

@@ -128,3 +128,32 @@ def test_plan_slide_rescaled():
     assert plan.read_overlap == round(64 / rf)
     assert max(1, int(round(plan.read_tile_size * rf))) == 1024
     assert plan.coords[0] == ((0, 0), 2106) and plan.coords[1][0] == (0, 2106 - plan.read_overlap)
+
+
+def test_wsi_reader_switch_imports_openslide(monkeypatch):
+    """src/classpose/__init__.py:6-41: WSI_READER (default "openslide") picks the class; an OpenSlide-protocol object --
+    RGBA PIL regions, string properties, several levels -- plans and reads like the reference's fill_queue
+    (predict_wsi.py:220-278, 446-451); unknown reader names raise the reference's ValueError"""
+    import sys
+    import fake_openslide as fo
+    from classpose_amd import wsi
+    monkeypatch.setitem(sys.modules, "openslide", fo)
+    monkeypatch.delenv("WSI_READER", raising=False)
+    fo.SLIDES["/x/s.ndpi"] = dict(seed=3, base_level=2, base_dims=(600, 500), downsamples=[1.0, 4.0, 16.0],
+                                  properties={"tiff.XResolution": "100000", "tiff.YResolution": "100000", "tiff.ResolutionUnit": "centimeter"})
+    s = wsi.WSIReader("/x/s.ndpi")                                 # default reader = openslide
+    assert isinstance(s, fo.OpenSlide) and s.level_dimensions[0] == (9600, 8000)
+    plan = wsi.plan_slide(s, 512, 64, 2.0)                         # mpp 0.1 -> scale 20 -> level 2 (16x), residual 0.8
+    assert plan.mpp == (0.1, 0.1) and plan.level == 2 and plan.ts == 16.0 and plan.resize_factor == 16.0 / 20.0
+    assert plan.read_tile_size == 640 and plan.slide_dim == (600, 500) and plan.coords == []      # nothing fits: dropped like the reference
+    plan = wsi.plan_slide(s, 256, 32, 2.0)
+    assert plan.read_tile_size == 320 and [c[0] for c in plan.coords] == [(0, 0), (int(280 * 16.0), 0)]
+    fo.READS.clear()
+    t = wsi.read_tile(s, plan, plan.coords[1])
+    assert t.shape == (320, 320, 3) and t.dtype == np.uint8 and t.flags["C_CONTIGUOUS"]
+    assert fo.READS == [("/x/s.ndpi", (4480, 0), 2, (320, 320))]
+    from classpose_amd import synth
+    assert np.array_equal(t, synth.render_region(3, 280, 0, 320, 320))
+    monkeypatch.setenv("WSI_READER", "bioformats")
+    with pytest.raises(ValueError, match="not supported"):
+        wsi.WSIReader("/x/s.ndpi")

@@ -153,13 +153,15 @@ def test_streaming_writer_equals_dict_pipeline(tmp_path):
 def test_native_writer_is_bytewise_json_dump(tmp_path):
     """cpx_write_geojson against json.dumps of the reference-shaped feature dicts, byte for byte (ids masked),
     on values that exercise every branch of float.__repr__: integers, exponents on both sides of the
-    fixed / scientific switch (1e-4, 1e16), 17-digit values, negative zero, and a bounds offset."""
+    fixed / scientific switch (1e-4, 1e16), 17-digit values, negative zero, NaN / +-Infinity (json.dump's spelling, in
+    the measurements, the Point coordinates and the ring alike), and a bounds offset."""
     import json
     import re
     from classpose_amd.entrypoints.predict_wsi import CELL_ROW
     rng = np.random.default_rng(11)
     special = np.array([0.0, -0.0, 1.0, 1e15, 1e16, 1.5e16, 1e-4, 9.999e-5, 1e-5, 123456789012345.6, 2.0 / 3, 0.1 + 0.2,
-                        1e22, 5e-324, 1.7976931348623157e308, 4.35, 100.0, 65536.5, 1234567.891, -3.25, 1e-7, 12345678.9])
+                        1e22, 5e-324, 1.7976931348623157e308, 4.35, 100.0, 65536.5, 1234567.891, -3.25, 1e-7, 12345678.9,
+                        np.nan, np.inf, -np.inf])
     n = 64
     cells = np.zeros(n, CELL_ROW)
     cells["n_pts"] = rng.integers(3, 7, n)
@@ -168,12 +170,13 @@ def test_native_writer_is_bytewise_json_dump(tmp_path):
     cells["perimeter"] = np.resize(special[::-1], n)
     cells["cx"] = rng.uniform(0, 1e5, n)
     cells["cy"] = rng.uniform(0, 1e5, n)
+    cells["cx"][:3] = [np.nan, np.inf, -np.inf]                                 # non-finite centroids -> Point coordinates too
     tot = int(cells["n_pts"].sum())
     xy = np.stack([np.resize(special, tot), rng.uniform(-10, 1e5, tot)], 1)
     xy[5:40] = rng.integers(0, 40000, (35, 2)).astype(np.float64) * 0.5        # what tile contours look like
     offs = np.concatenate([[0], np.cumsum(cells["n_pts"])])
     labels = ['a "quoted" name', "b", "ünï"]                                    # json.dumps escapes both
-    keep = [int(k) for k in rng.permutation(n)[:50]] + [3, 3]
+    keep = [int(k) for k in rng.permutation(n)[:50]] + [3, 3, 0, 1, 2]
     for bounds in [(0.0, 0.0), (12.5, -7.25)]:
         feats = []
         for i in keep:
