@@ -19,7 +19,13 @@ streamed pixels.
 
     python bench.py                                   # 1 GPU, the whole 10k x 10k slide
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --slide 40000 --steps 200         # the north-star slide (31 684 tiles; ranks walk disjoint shards)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Besides the headline the line carries ``roofline`` (dominant kernel + per-stage table; the post-processing stage is timed
+repetition by repetition with device AND host clocks), ``cpu_baseline`` (P oracle processes x 32 torch threads over all
+physical host cores) and, at N = 1, ``side_lines``: the same pipeline with ``--precision fp32`` and with the network's own
+(random-weight) fields driving the dynamics instead of the injected ones (SURVEY 8d asks for both modes).
 """
 from __future__ import annotations
 
@@ -40,15 +46,17 @@ sys.path.insert(0, ROOT)
 from classpose_amd import _lib, engine, parallel, synth, wsi  # noqa: E402
 from classpose_amd.entrypoints.predict_wsi import TileStream  # noqa: E402
 
-SLIDE = 10000
 TILE, OVERLAP, NCLS = 256, 32, 7
+N_TILES = {10000: 1936, 40000: 31684, 80000: 127449}          # SlideLoader._get_coords golden counts (tests/golden)
+MAX_DISTINCT_BATCHES = 256                                    # rendered tiles + injected fields kept resident: 2.6 MB of fields per tile
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0              # HBM3E peak (same guide)
 SEED = 1234
-# algorithmic work per launch at M = 32768 tokens: GEMMs 2 M N K, attention 4 T^2 hd heads + rel-pos
+# algorithmic work per launch at M = 32768 tokens: GEMMs 2 M N K; attention 4 T^2 hd heads + the decomposed
+# rel-pos bias 4 heads T sqrt(T) hd = 4.43 GFLOP per sub-tile (the kernel's 64-row padded tables are NOT counted)
 FLOPS = {"fc1": lambda M: 2.0 * M * 4096 * 1024, "fc2": lambda M: 2.0 * M * 4096 * 1024,
          "qkv": lambda M: 2.0 * M * 3072 * 1024, "proj": lambda M: 2.0 * M * 1024 * 1024,
-         "attention": lambda M: (M / 1024) * (4.0 * 1024 * 1024 * 64 * 16 + 4.0 * 16 * 1024 * 64 * 64)}
+         "attention": lambda M: (M / 1024) * (4.0 * 1024 * 1024 * 64 * 16 + 4.0 * 16 * 1024 * 32 * 64)}
 POST_BYTES_PER_TILE = 524288 + 262144 + NCLS * 262144 + 131072 + 65536      # dP + cellprob + logits in, ids + classes out
 
 
@@ -68,56 +76,70 @@ class CachedSlide:
         return self._tiles[(int(location[0]), int(location[1]))]
 
 
-def cpu_baseline(sd, coords, n_tiles=16, warm=2, budget_s=75.0):
-    """Reference-shaped CPU path (the oracle, kind 'port'), one tile per eval like
-    predict_wsi.worker: normalize -> run_net (4 sub-tiles in one forward, torch-CPU fp32) ->
-    compute_masks on the same injected fields -> class vote -> records."""
-    from oracle import classmask, dynamics, net, tiling
-    # torch-CPU scales to ~16-32 threads on this ViT-L and collapses beyond (measured on the
-    # 256-core GPU-box host: 5.1 s/tile at 32 threads, 151 s/tile at 256)
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    fw = net.make_forward(sd, torch.float32)
-    n, cells, dt = 0, 0, 0.0
-    stage = {"normalise": 0.0, "network": 0.0, "dynamics": 0.0, "class_vote_records": 0.0}
-    for k in range(warm + n_tiles):
-        (x0, y0), _ = coords[k]
-        tile = synth.render_region(SEED, x0, y0, TILE, TILE)           # rendering is not timed
-        dP, cp, lg, _ = synth.analytic_fields(SEED, x0, y0, TILE, TILE, NCLS)
-        t1 = time.perf_counter()
-        x = tiling.normalize_img(tile[None])
-        t2 = time.perf_counter()
-        tiling.run_net(fw, x, batch_size=8, bsize=256)
-        t3 = time.perf_counter()
-        m = dynamics.compute_masks(dP, cp)
-        t4 = time.perf_counter()
-        cm, _ = classmask.compute_class_masks(m, lg)
-        classmask.instance_records(m, cm)
-        t5 = time.perf_counter()
-        if k < warm:
-            continue
-        dt += t5 - t1
-        for key, v in zip(stage, (t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-            stage[key] += v
-        cells += int(m.max())
-        n += 1
-        if dt > budget_s and n >= 8:
-            break
-    return dict(value=n / dt, unit="tiles/s", cores=cores, kind="port",
-                cells_per_s=cells / dt, stage_ms_per_tile={k: round(v / n * 1e3, 2) for k, v in stage.items()},
-                sample=f"{n} tiles of the same workload after {warm} warm-up tiles, one tile per eval (4 sub-tiles, "
-                       f"fp32 torch-CPU ViT-L on {cores} threads + oracle dynamics on the injected fields), {dt:.1f} s")
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return max(1, len(os.sched_getaffinity(0)))
+
+
+def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
+    """Reference-shaped CPU path (the oracle, kind 'port'; oracle/cpu_baseline.py) on ALL physical host cores:
+    P child processes x 32 torch threads over disjoint tiles of the same workload (one torch-CPU process stops scaling
+    at ~32 threads on this ViT-L), >= 64 tiles after 4 warm-up tiles unless the wall budget ends a worker earlier.
+    The children never touch the GPU; they are started as ordinary child processes (no exec from this process)."""
+    import subprocess
+    phys = physical_cores()
+    threads = min(32, phys)
+    P = max(1, phys // threads)
+    per = -(-n_tiles // P)
+    warm = max(1, -(-warm_total // P))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--slide", str(slide_px), "--first", str(i),
+                               "--stride", str(P), "--tiles", str(per), "--warm", str(warm), "--threads", str(threads),
+                               "--budget", str(budget_s), "--depth", str(depth)],
+                              cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(P)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=budget_s * 4 + 600)
+        for ln in out.splitlines():
+            if ln.startswith("CPU_BASELINE "):
+                res.append(json.loads(ln[len("CPU_BASELINE "):]))
+    if not res:
+        return dict(value=None, unit="tiles/s", cores=phys, kind="port", sample="no worker finished")
+    tiles = sum(r["tiles"] for r in res)
+    cells = sum(r["cells"] for r in res)
+    rate = sum(r["tiles"] / (r["t_end"] - r["t_start"]) for r in res)            # the workers' windows overlap: rates add
+    span = max(r["t_end"] for r in res) - min(r["t_start"] for r in res)
+    stage = {k: round(sum(r["stage_s"][k] for r in res) / tiles * 1e3, 2) for k in res[0]["stage_s"]}
+    return dict(value=rate, unit="tiles/s", cores=len(res) * threads, kind="port", cells_per_s=cells / tiles * rate,
+                processes=len(res), threads_per_process=threads, physical_cores=phys, stage_ms_per_tile=stage,
+                sample=f"{tiles} tiles of the same workload ({len(res)} processes x {threads} torch threads on disjoint tiles, "
+                       f"{warm} warm-up tile(s) each = {warm * len(res)} in all), one tile per eval (4 sub-tiles, fp32 torch-CPU "
+                       f"ViT-L + oracle dynamics on the injected fields); all windows within {span:.1f} s; the literal "
+                       f"reference cannot run here (cellpose / cv2 / openslide wheels absent)")
+
+
+def _mmm(v):
+    v = sorted(v)
+    return {"min": round(v[0], 4), "median": round(v[len(v) // 2], 4), "max": round(v[-1], 4)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="0 = this rank's whole shard of the slide (242 steps on 1 GPU)")
+    ap.add_argument("--steps", type=int, default=0, help="0 = this rank's whole shard of the slide (242 steps on 1 GPU at --slide 10000)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-tiles", type=int, default=8)
     ap.add_argument("--depth", type=int, default=24)
+    ap.add_argument("--slide", type=int, default=10000, help="side of the synthetic slide in pixels (10000 = configs[1]; 40000 = the north-star slide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--no-side-lines", action="store_true")
     args = ap.parse_args()
 
     rank, world, local = parallel.init_distributed()
@@ -131,14 +153,16 @@ def main():
     w = engine.NetWeights.from_state_dict(sd, "bf16", dev)
     bt = args.batch_tiles
     eng = engine.Engine(w, TILE, batch_tiles=bt)
-    slide = synth.SyntheticSlide(SLIDE, SLIDE, mpp=0.5, seed=SEED)
+    S = args.slide
+    slide = synth.SyntheticSlide(S, S, mpp=0.5, seed=SEED)
     plan = wsi.plan_slide(slide, TILE, OVERLAP, 0.5)
     coords = plan.coords
-    assert len(coords) == 1936
-    mine = list(parallel.shard_indices(len(coords), rank, world))      # tile k -> rank k % world
+    assert len(coords) == N_TILES.get(S, len(coords)), (S, len(coords))
+    mine = list(parallel.shard_indices(len(coords), rank, world))      # tile k -> rank k % world: disjoint shards
     shard_steps = len(mine) // bt
     steps = args.steps if args.steps > 0 else shard_steps
-    n_distinct = min(steps + args.warmup, shard_steps)                 # distinct batches; longer runs wrap around the shard
+    # distinct batches kept resident (rendered tiles in host memory, injected fields in HBM); longer runs wrap around them
+    n_distinct = min(steps + args.warmup, shard_steps, MAX_DISTINCT_BATCHES)
     use = mine[: n_distinct * bt]
 
     # ---- before the timed region: rendered slide tiles in host memory, analytic fields in HBM
@@ -159,12 +183,11 @@ def main():
     max_cells = 256                                                    # >> the ~81 cells of a 256 px tile of this slide
     pinned = torch.empty((bt, max_cells, rec_bytes), dtype=torch.uint8).pin_memory()
     pinned_cnt = torch.empty(bt, dtype=torch.int32).pin_memory()
-    cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
     rec_keep = []
 
-    def collect(sid, keep=False):
-        out = eng.result(sid)                                          # current stream waits for the post stream
-        recs = out.records.view(bt, eng.max_rec, rec_bytes)[:, :max_cells]
+    def collect(e, sid, cells_acc, keep=False):
+        out = e.result(sid)                                            # current stream waits for the post stream
+        recs = out.records.view(bt, e.max_rec, rec_bytes)[:, :max_cells]
         pinned.copy_(recs, non_blocking=True)                          # records leave the device
         pinned_cnt.copy_(out.rec_counts, non_blocking=True)
         cells_acc.add_(out.nlabels.sum())
@@ -176,7 +199,7 @@ def main():
         idxs = [use[((first_batch + i) % n_distinct) * bt + k] for i in range(n) for k in range(bt)]
         return TileStream(cached, plan, idxs, bt, TILE, TILE, dev, autostart=False, gate_at=gate_at)
 
-    def run_steps(it, n, keep_last=False):
+    def run_steps(e, it, n, cells_acc, inject=True, keep_last=False):
         """n steps from the batch iterator `it`: TileStream (reader threads -> pinned batches -> hipMemcpyAsync on its
         copy stream) feeds the 2-stream engine pipeline; the network of step i+1 overlaps the post-processing of step i."""
         prev = None
@@ -184,27 +207,50 @@ def main():
         for _ in range(n):
             chunk, tiles_dev, ev, _x = next(it)
             torch.cuda.current_stream(dev).wait_event(ev)
-            sid = eng.submit(tiles_dev, inject=fields[batch_of[tuple(chunk)]], records=True)
+            sid = e.submit(tiles_dev, inject=fields[batch_of[tuple(chunk)]] if inject else None, records=True)
             if prev is not None:
-                collect(prev)
+                collect(e, prev, cells_acc)
             prev = sid
             if dbg_t is not None:
                 dbg_t.append(time.perf_counter())
         if prev is not None:
-            collect(prev, keep=keep_last)
+            collect(e, prev, cells_acc, keep=keep_last)
         if dbg_t is not None:
             torch.cuda.synchronize(dev)
             dbg_t.append(time.perf_counter())
             print("BENCH_DEBUG host ms between loop iterations:", [round((b - a) * 1e3, 1) for a, b in zip(dbg_t, dbg_t[1:])], file=sys.stderr)
 
-    # ONE TileStream over warm-up + timed batches (its reader / copy threads pay their one-off HIP thread start-up
-    # during the warm-up); a gate keeps it from reading or copying any timed batch before the clock starts
-    ts = make_stream(args.warmup + steps, 0, gate_at=args.warmup)
-    ts.start()
-    it = iter(ts)
-    run_steps(it, args.warmup)
-    torch.cuda.synchronize(dev)
-    cells_acc.zero_()
+    def timed_run(e, n_steps, n_warm, inject=True, prof=None, collective=False):
+        """ONE TileStream over warm-up + timed batches (its reader / copy threads pay their one-off HIP thread start-up
+        during the warm-up); a gate keeps it from reading or copying any timed batch before the clock starts."""
+        cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+        with make_stream(n_warm + n_steps, 0, gate_at=n_warm) as ts:
+            ts.start()
+            it = iter(ts)
+            run_steps(e, it, n_warm, cells_acc, inject)
+            torch.cuda.synchronize(dev)
+            cells_acc.zero_()
+            if prof is not None:
+                e.w.c.prof = prof
+            if collective:
+                parallel.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ts.release()                                                   # first read / H2D copy of a timed batch happens from here on
+            run_steps(e, it, n_steps, cells_acc, inject, keep_last=collective)
+            allrec = None
+            if collective:
+                # the path's one exchange: per-cell records of this rank's shard -> every rank (RCCL)
+                rec = rec_keep[-1].reshape(-1, rec_bytes)
+                allrec = parallel.all_gather_records(rec)
+            torch.cuda.synchronize(dev)
+            if collective:
+                parallel.barrier()
+            dt = time.perf_counter() - t0
+            if prof is not None:
+                e.w.c.prof = None
+        return dt, float(cells_acc.item()), allrec
+
     # the dominant GEMM is timed on every 4th layer, the sampled layers rotating by one per step so that all 24 are
     # covered equally (BENCH_PROF_STRIDE): each event pair costs the stream ~6 us of idle time on either side of the
     # launch (tools/r02_gaps.sh: 0.28 ms per step with every launch timed = 1.1 % of the headline; stride 4: +0.3-0.5 %
@@ -213,23 +259,11 @@ def main():
     prof = C.c_void_p()
     _lib.check(L.cpx_prof_create(steps * args.depth + 8, int(os.environ.get("BENCH_PROF_STRIDE", "4")), 1,
                                  C.byref(prof)), "prof_create")
-    w.c.prof = prof
-    parallel.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ts.release()                                                       # first read / H2D copy of a timed batch happens from here on
-    run_steps(it, steps, keep_last=True)
-    # the path's one exchange: per-cell records of this rank's shard -> every rank (RCCL)
-    rec = rec_keep[-1].reshape(-1, rec_bytes)
-    allrec = parallel.all_gather_records(rec)
-    torch.cuda.synchronize(dev)
-    parallel.barrier()
-    dt = time.perf_counter() - t0
+    dt, cells, allrec = timed_run(eng, steps, args.warmup, inject=True, prof=prof, collective=True)
     dt = parallel.allreduce_max(dt, dev)
-    cells = parallel.allreduce_sum(float(cells_acc.item()), dev)
+    cells = parallel.allreduce_sum(cells, dev)
     ms_k, cnt_k = (C.c_double * 5)(), (C.c_int * 5)()
     _lib.check(L.cpx_prof_collect(prof, ms_k, cnt_k), "prof_collect")
-    w.c.prof = None
     L.cpx_prof_destroy(prof)
     fc1_launches = int(cnt_k[0])
 
@@ -238,9 +272,12 @@ def main():
     avg_ms = ms_k[0] / max(cnt_k[0], 1)
     achieved = FLOPS["fc1"](M) / (avg_ms * 1e-3) / 1e12 if fc1_launches else 0.0
     flop_per_tile = 727.3e9 * eng.n_sub
+    # HBM-side bytes per launch of the dominant kernel cannot be counted from inside this process (PMC counters need
+    # rocprofv3's own passes): the figure is the one measured on THIS command by separate --pmc FETCH_SIZE / WRITE_SIZE
+    # passes (tools/r03_profile.sh -> profiles/), named with its source; null when no such profile is committed
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:      # HBM-side bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes, committed
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["traffic_bytes_per_launch"]
             traffic_src = name
@@ -254,14 +291,9 @@ def main():
         stages = {}
         prof2 = C.c_void_p()
         _lib.check(L.cpx_prof_create(6 * args.depth * 5 + 8, 1, 0x1F, C.byref(prof2)), "prof_create")
-        w.c.prof = prof2
         n6 = min(6, n_distinct)
-        ts2 = make_stream(n6, 0)
-        ts2.start()
-        run_steps(iter(ts2), n6)
-        torch.cuda.synchronize(dev)
+        timed_run(eng, n6, 0, inject=True, prof=prof2)
         _lib.check(L.cpx_prof_collect(prof2, ms_k, cnt_k), "prof_collect")
-        w.c.prof = None
         L.cpx_prof_destroy(prof2)
         for k, name in enumerate(_lib.PROF_KINDS):
             if cnt_k[k]:
@@ -269,29 +301,30 @@ def main():
                 tf = FLOPS[name](M) / (ms * 1e-3) / 1e12
                 stages[name] = {"bound": "mfma", "avg_launch_ms": round(ms, 4), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                                 "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_timed": cnt_k[k]}
-        # post-processing (blend excluded): dynamics + class vote + records of one 8-tile batch, alone on the GPU
-        sl = eng.slots[0]
-        dP, cp, lg = fields[0]
-        st = torch.cuda.current_stream(dev).cuda_stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        for r in range(reps + 2):
-            if r == 2:
-                e0.record()
-            _lib.check(L.cpx_compute_masks(dP.data_ptr(), cp.data_ptr(), lg.data_ptr(), bt, NCLS, TILE, TILE, 0.0, 0.4, 200, 15, 0.4,
-                                           sl.masks.data_ptr(), sl.class_masks.data_ptr(), sl.nlabels.data_ptr(),
-                                           sl.pp_ws.data_ptr(), st), "compute_masks")
-            _lib.check(L.cpx_instance_records(sl.masks.data_ptr(), sl.class_masks.data_ptr(), bt, TILE, TILE, eng.max_rec,
-                                              sl.records.data_ptr(), sl.rec_counts.data_ptr(), sl.pp_ws.data_ptr(), st), "records")
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / reps
-        gbs = POST_BYTES_PER_TILE * bt / (ms * 1e-3) / 1e9
-        stages["post_processing"] = {"bound": "hbm", "ms_per_batch": round(ms, 4), "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS,
-                                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
-                                     "algorithmic_bytes_per_tile": POST_BYTES_PER_TILE,
-                                     "note": "compute_masks + instance_records of one 8-tile batch alone on the GPU; latency-bound "
-                                             "chain of small kernels, hidden on the post stream in the pipeline"}
+        stages["post_processing"] = post_stage(L, eng, fields[0], bt, dev)
+
+    # ---- side lines (N = 1): --precision fp32, and the network's own fields instead of the injected ones
+    side = None
+    if rank == 0 and world == 1 and not args.no_side_lines:
+        side = {}
+        ns = min(12, n_distinct)
+        dts, cs, _ = timed_run(eng, ns, 2, inject=False)
+        side["random_weight_fields_bf16"] = {
+            "tiles_per_s": round(ns * bt / dts, 2), "ms_per_step": round(dts / ns * 1e3, 3), "cells_per_s": round(cs / dts, 1), "steps": ns,
+            "note": "no flow injection: the dynamics consume what the random-init network itself produces (meaningless flows "
+                    "-- a different number of pixels to integrate and of candidate labels than real cells give); everything else as the headline"}
+        del eng
+        torch.cuda.empty_cache()
+        w32 = engine.NetWeights.from_state_dict(sd, "fp32", dev)
+        eng32 = engine.Engine(w32, TILE, batch_tiles=bt)
+        n32 = min(3, n_distinct)
+        dts, cs, _ = timed_run(eng32, n32, 1, inject=True)
+        side["precision_fp32"] = {
+            "tiles_per_s": round(n32 * bt / dts, 2), "ms_per_step": round(dts / n32 * 1e3, 2), "cells_per_s": round(cs / dts, 1), "steps": n32,
+            "network_tflops": round(n32 * bt * flop_per_tile / dts / 1e12, 1), "peak_tflops_f32_mfma": 157.3,
+            "note": "--precision fp32 (what the reference's integration tests pass): exact-f32 MFMA network "
+                    "(v_mfma_f32_32x32x2_f32, 1/16 of the bf16 matrix rate), same pipeline, flow injection"}
+        del eng32, w32
 
     line = {
         "metric": "wsi_tiles_per_sec",
@@ -308,28 +341,94 @@ def main():
         "data": "synthetic",
         "cells_per_sec": cells / dt,
         "network_tflops": n_tiles * flop_per_tile / dt / 1e12 / world,
-        "config": {"workload": "configs[1]: synthetic 10000x10000 WSI (1936 tiles), tile 256 / overlap 32, "
+        "config": {"workload": "%s: synthetic %dx%d WSI (%d tiles), tile 256 / overlap 32, "
                                "conic 7 classes, ViT-L ClassTransformer depth %d random-init, batch 32 "
                                "sub-tiles = %d WSI tiles/step, every step a distinct batch of the rank's shard "
-                               "(tiles sharded k %% n_gpus) streamed pinned host -> hipMemcpyAsync inside the "
-                               "timed region, flow-injection dynamics" % (args.depth, bt),
-                   "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * eng.n_sub,
+                               "(tiles sharded k %% n_gpus, at most %d distinct batches resident, longer runs wrap) "
+                               "streamed pinned host -> hipMemcpyAsync inside the "
+                               "timed region, flow-injection dynamics" % (
+                                   "configs[1]" if S == 10000 else "north-star slide" if S == 40000 else "custom slide",
+                                   S, S, len(coords), args.depth, bt, MAX_DISTINCT_BATCHES),
+                   "slide": S, "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * 4,
                    "tiles_per_step": bt, "distinct_batches": n_distinct, "records_gathered": int(allrec.shape[0])},
-        "roofline": {"bound": "mfma", "kernel": "k_gemm256p<GELU> = void k_gemm256p<1, false, 1>(GemmArgs) (mlp.lin1 %dx4096x1024)" % M,
+        "roofline": {"bound": "mfma", "kernel": "%s (mlp.lin1 %dx4096x1024)" % (_lib.FC1_KERNEL_NAME, M),
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                     "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % traffic_src,
+                     "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes over this command, profiles/%s)" % traffic_src,
                      "algorithmic_bytes": 2.0 * (M * 1024 + 4096 * 1024 + M * 4096),
                      "launches_timed": fc1_launches, "avg_launch_ms": avg_ms},
     }
     if stages is not None:
         line["roofline"]["stages"] = stages
+    if side is not None:
+        line["side_lines"] = side
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, coords)
+            line["cpu_baseline"] = cpu_baseline(S, args.depth)
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def post_stage(L, eng, fields0, bt, dev, reps=20):
+    """Post-processing alone on the GPU (blend excluded): dynamics + class vote + records of one 8-tile batch.  Every
+    repetition gets its own device event pair AND host clock, in two modes -- back to back (the host runs ahead, the
+    device figure is the chain's own time unless the host cannot issue fast enough) and synchronised (idle device, one
+    repetition in flight: issue + drain wall) -- so that a slow host issue path and a slow device path can be told apart."""
+    sl = eng.slots[0]
+    dP, cp, lg = fields0
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def once():
+        _lib.check(L.cpx_compute_masks(dP.data_ptr(), cp.data_ptr(), lg.data_ptr(), bt, NCLS, TILE, TILE, 0.0, 0.4, 200, 15, 0.4,
+                                       sl.masks.data_ptr(), sl.class_masks.data_ptr(), sl.nlabels.data_ptr(),
+                                       sl.pp_ws.data_ptr(), st), "compute_masks")
+        _lib.check(L.cpx_instance_records(sl.masks.data_ptr(), sl.class_masks.data_ptr(), bt, TILE, TILE, eng.max_rec,
+                                          sl.records.data_ptr(), sl.rec_counts.data_ptr(), sl.pp_ws.data_ptr(), st), "records")
+    n0 = L.cpx_postproc_launch_count()
+    once()
+    launches = int(L.cpx_postproc_launch_count() - n0)
+    once()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    host_issue = []
+    t_all = time.perf_counter()
+    for e0, e1 in ev:                                  # mode A: back to back
+        e0.record()
+        h0 = time.perf_counter()
+        once()
+        host_issue.append((time.perf_counter() - h0) * 1e3)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    wall_b2b = (time.perf_counter() - t_all) * 1e3 / reps
+    dev_b2b = [a.elapsed_time(b) for a, b in ev]
+    dev_sync, wall_sync = [], []
+    for e0, e1 in ev:                                  # mode B: one repetition at a time on an idle device
+        torch.cuda.synchronize(dev)
+        h0 = time.perf_counter()
+        e0.record()
+        once()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        wall_sync.append((time.perf_counter() - h0) * 1e3)
+        dev_sync.append(e0.elapsed_time(e1))
+    ms = sorted(dev_b2b)[reps // 2]
+    gbs = POST_BYTES_PER_TILE * bt / (ms * 1e-3) / 1e9
+    prof_sum = None
+    try:                                               # rocprofv3 kernel-time sum of the same chain (tools/r03_post_profile.sh)
+        with open(os.path.join(ROOT, "profiles", "r03_post_kernel_sum.json")) as f:
+            prof_sum = json.load(f)
+    except Exception:
+        pass
+    return {"bound": "hbm", "ms_per_batch": round(ms, 4), "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_tile": POST_BYTES_PER_TILE,
+            "launches_per_batch": launches, "reps": reps,
+            "device_ms_back_to_back": _mmm(dev_b2b), "host_issue_ms_back_to_back": _mmm(host_issue),
+            "wall_ms_per_rep_back_to_back": round(wall_b2b, 4),
+            "device_ms_synchronised": _mmm(dev_sync), "wall_ms_synchronised": _mmm(wall_sync),
+            "rocprof_kernel_time_sum": prof_sum,
+            "note": "compute_masks + instance_records of one 8-tile batch alone on the GPU; ms_per_batch = median of the "
+                    "back-to-back device times; a dispatch-bound chain of small kernels, hidden on the post stream in the pipeline"}
 
 
 if __name__ == "__main__":

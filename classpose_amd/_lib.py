@@ -17,6 +17,8 @@ ABI_VERSION = 2
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 DTYPE_CODE = {"bf16": DT_BF16, "fp16": DT_F16, "fp32": DT_F32}
 PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2")
+# the kernel behind kind "fc1" (the dominant launch of the network; its name as rocprofv3 prints it)
+FC1_KERNEL_NAME = "k_gemm256p<GELU> = void k_gemm256p<1, false, 1>(GemmArgs)"
 
 
 class CpxTiling(C.Structure):
@@ -104,6 +106,7 @@ SIGNATURES = {
     "cpx_attention_relpos": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "cpx_postproc_workspace_bytes": (_sz, [_i, _i, _i]),
     "cpx_postproc_max_labels": (_i, [_i, _i]),
+    "cpx_postproc_launch_count": (C.c_ulonglong, []),
     "cpx_follow_flows": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "cpx_get_masks": (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p]),
     "cpx_remove_bad_flow_masks": (_i, [_p, _p, _i, _i, _i, _d, _p, _p, _p]),

@@ -16,6 +16,13 @@
 #define RPAD 20
 #define NTHR 256
 
+// Every launch of this file is counted per calling thread (a diagnostic for bench.py's dispatch-bound post-processing
+// stage: launches per batch next to its device and host times); the counter is read-only for callers and touches no
+// compute state.
+static thread_local unsigned long long g_pp_launches = 0;
+#define PP_LAUNCH(...) do { ++g_pp_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+extern "C" unsigned long long cpx_postproc_launch_count(void) { return g_pp_launches; }
+
 // ---------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------
@@ -610,7 +617,7 @@ static void pp_init(unsigned what, int nT, const PPLayout &lay, void *ws, hipStr
     if (what & PPI_PAD) n = n > lay.HWp ? n : lay.HWp;
     if (what & PPI_T) n = n > 2 * lay.THW ? n : 2 * lay.THW;
     if (what & PPI_CLS) n = n > lay.L * PP_MAXCLS ? n : lay.L * PP_MAXCLS;
-    hipLaunchKernelGGL(k_pp_init, dim3(cpx_cdiv(n, NTHR), nT), dim3(NTHR), 0, s, what, lay, ws);
+    PP_LAUNCH(k_pp_init, dim3(cpx_cdiv(n, NTHR), nT), dim3(NTHR), 0, s, what, lay, ws);
 }
 
 __device__ __forceinline__ double center_d2(int y, int x, const int *bb, int n,
@@ -1224,8 +1231,8 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
-    hipLaunchKernelGGL(k_prep_flow, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
-    hipLaunchKernelGGL(k_follow, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
+    PP_LAUNCH(k_prep_flow, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
+    PP_LAUNCH(k_follow, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
                        (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
                        p_float, lay, ws, g_follow_early);
     CPX_CHECK_LAUNCH();
@@ -1239,10 +1246,10 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
 static int pp_renumber(int32_t *masks, int nT, const PPLayout &lay, void *ws, hipStream_t s, int mode,
                        int32_t *nlabels_out) {
     // (`first` was set to INT_MAX by the stage's PPI_STATS init and nothing has written it since)
-    if (mode == 1) hipLaunchKernelGGL(k_first<false>, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    else if (mode == 2) hipLaunchKernelGGL(k_first<true>, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_renumber_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, SC_VMAX, lay, ws);
-    hipLaunchKernelGGL(k_relabel, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, nlabels_out, lay, ws);
+    if (mode == 1) PP_LAUNCH(k_first<false>, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    else if (mode == 2) PP_LAUNCH(k_first<true>, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_renumber_rank, GRID_LAB(lay, nT), dim3(NTHR), 0, s, SC_VMAX, lay, ws);
+    PP_LAUNCH(k_relabel, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, nlabels_out, lay, ws);
     return CPX_OK;
 }
 
@@ -1254,12 +1261,12 @@ extern "C" int cpx_get_masks(const int32_t *p_final, int nT, int H, int W, doubl
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     pp_init(PPI_PAD | PPI_SCAL | PPI_STATS, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_hist, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, lay, ws);
-    hipLaunchKernelGGL(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_seed_grow, dim3(SEED_WGS, nT), dim3(NTHR), 0, s, lay, ws);
-    hipLaunchKernelGGL(k_gather, GRID_RUN(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
+    PP_LAUNCH(k_hist, GRID_PIX(lay, nT), dim3(NTHR), 0, s, p_final, lay, ws);
+    PP_LAUNCH(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, lay, ws);
+    PP_LAUNCH(k_seed_grow, dim3(SEED_WGS, nT), dim3(NTHR), 0, s, lay, ws);
+    PP_LAUNCH(k_gather, GRID_RUN(lay, nT), dim3(NTHR), 0, s, p_final, masks, lay, ws);
     double big = (double)((long long)H * W) * max_size_fraction;
-    hipLaunchKernelGGL(k_big_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
+    PP_LAUNCH(k_big_first, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, big, lay, ws);
     pp_renumber(masks, nT, lay, ws, s, 0, nlabels);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
@@ -1274,12 +1281,12 @@ static int bad_flow_impl(int32_t *masks, const float *dP, int nT, int H, int W, 
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     pp_init(PPI_SCAL | PPI_STATS | PPI_T, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 0, lay, ws);
-    hipLaunchKernelGGL(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, dP, threshold, flow_errors, lay, ws);
-    if (!defer_zero) hipLaunchKernelGGL(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 0, lay, ws);
+    PP_LAUNCH(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, dP, threshold, flow_errors, lay, ws);
+    if (!defer_zero) PP_LAUNCH(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -1292,8 +1299,8 @@ extern "C" int cpx_remove_bad_flow_masks(int32_t *masks, const float *dP, int nT
 static void pp_size_filter(int32_t *masks, int nT, int min_size, const PPLayout &lay, void *ws,
                            hipStream_t s, unsigned extra_init, int32_t *nlabels_out, double err_thr = 0.0) {
     pp_init(PPI_SCAL | PPI_STATS | extra_init, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, err_thr > 0 ? 1 : 0, err_thr, lay, ws);
-    hipLaunchKernelGGL(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
+    PP_LAUNCH(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, err_thr > 0 ? 1 : 0, err_thr, lay, ws);
+    PP_LAUNCH(k_size_filter, dim3(1, nT), dim3(1024), 0, s, min_size, lay, ws);
     pp_renumber(masks, nT, lay, ws, s, 2, nlabels_out);        // k_first<true> removes the flagged labels on the way
 }
 
@@ -1309,18 +1316,18 @@ static int fill_holes_impl(int32_t *masks, int nT, int H, int W, int min_size, i
     if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s, 0, nullptr, pending_err_thr);
     else {   // labels may be non-contiguous: bbox loop below handles absent labels (slc None)
         pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
-        hipLaunchKernelGGL(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, pending_err_thr > 0 ? 1 : 0, pending_err_thr, lay, ws);
-        hipLaunchKernelGGL(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, -1, lay, ws);
+        PP_LAUNCH(k_count_labels, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, pending_err_thr > 0 ? 1 : 0, pending_err_thr, lay, ws);
+        PP_LAUNCH(k_copy_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, SC_VMAX, -1, lay, ws);
     }
     // find_objects(masks): bbox per label, then fill
     int nlab_saved_slot = SC_NLAB;
     (void)nlab_saved_slot;
     pp_init(PPI_STATS, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 1, lay, ws);
-    hipLaunchKernelGGL(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_fill_serial, dim3(1, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 1, lay, ws);
+    PP_LAUNCH(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_fill_serial, dim3(1, nT), dim3(NTHR), 0, s, masks, lay, ws);
     if (min_size > 0) pp_size_filter(masks, nT, min_size, lay, ws, s, extra_init, nlabels);
-    else if (nlabels) hipLaunchKernelGGL(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
+    else if (nlabels) PP_LAUNCH(k_store_scalar, dim3(1, nT), dim3(64), 0, s, SC_NLAB, nlabels, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -1339,9 +1346,9 @@ static int class_masks_impl(const int32_t *masks, const float *logits, int nT, i
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     if (init) pp_init(PPI_CLS, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_class_count, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, logits, ncls, lay, ws);
-    hipLaunchKernelGGL(k_class_pick, GRID_LAB(lay, nT), dim3(NTHR), 0, s, ncls, lay, ws);
-    hipLaunchKernelGGL(k_class_write, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, lay, ws);
+    PP_LAUNCH(k_class_count, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, logits, ncls, lay, ws);
+    PP_LAUNCH(k_class_pick, GRID_LAB(lay, nT), dim3(NTHR), 0, s, ncls, lay, ws);
+    PP_LAUNCH(k_class_write, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -1357,9 +1364,9 @@ extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks,
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    hipLaunchKernelGGL(k_fill_i32, dim3(cpx_cdiv(65536, NTHR), nT), dim3(NTHR), 0, s, lay.off_flag, 65536, 0, lay, ws);
-    hipLaunchKernelGGL(k_border_flag, dim3(cpx_cdiv(2 * (H + W), NTHR), nT), dim3(NTHR), 0, s, masks, lay, ws);
-    hipLaunchKernelGGL(k_border_zero, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
+    PP_LAUNCH(k_fill_i32, dim3(cpx_cdiv(65536, NTHR), nT), dim3(NTHR), 0, s, lay.off_flag, 65536, 0, lay, ws);
+    PP_LAUNCH(k_border_flag, dim3(cpx_cdiv(2 * (H + W), NTHR), nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_border_zero, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, class_masks, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -1393,7 +1400,7 @@ extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const f
         if (rc) return rc;
     } else {
         if (class_masks) CPX_HIP(hipMemsetAsync(class_masks, 0, n, s));
-        hipLaunchKernelGGL(k_to_u16, dim3(cpx_cdiv((long long)n, NTHR)), dim3(NTHR), 0, s, masks, masks_u16, n);
+        PP_LAUNCH(k_to_u16, dim3(cpx_cdiv((long long)n, NTHR)), dim3(NTHR), 0, s, masks, masks_u16, n);
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;
@@ -1408,8 +1415,8 @@ extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *cl
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     pp_init(PPI_SCAL | PPI_STATS, nT, lay, ws, s);
-    hipLaunchKernelGGL(k_rec_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks_u16, counts, lay, ws);
-    hipLaunchKernelGGL(k_rec_write, GRID_LAB(lay, nT), dim3(NTHR), 0, s, class_masks, max_rec, records, counts, lay, ws);
+    PP_LAUNCH(k_rec_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks_u16, counts, lay, ws);
+    PP_LAUNCH(k_rec_write, GRID_LAB(lay, nT), dim3(NTHR), 0, s, class_masks, max_rec, records, counts, lay, ws);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }

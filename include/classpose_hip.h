@@ -287,6 +287,10 @@ int cpx_attention(int dtype, const void *qkv, const void *rel_h, const void *rel
  * ---------------------------------------------------------------------- */
 size_t cpx_postproc_workspace_bytes(int nT, int H, int W);
 int cpx_postproc_max_labels(int H, int W);
+/* Diagnostic, read-only: number of kernel launches this THREAD has issued from the a11-a17 entry points since it first
+ * called into the library (difference of two reads = launches of the calls in between).  bench.py reports it next to
+ * the device / host times of the dispatch-bound post-processing stage.  Replaces nothing in the reference. */
+unsigned long long cpx_postproc_launch_count(void);
 
 /* cellpose.dynamics.follow_flows (steps_interp) as driven by
  * dynamics.compute_masks; call site models.py:149-159.
