@@ -11,6 +11,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclasspose_hip.so")
+# the same sources built with -DCPX_DEBUG: the product ABI PLUS include/classpose_hip_debug.h (A/B switches, non-production
+# kernel variants, cycle-stamp builds).  Nothing on the product path loads it; tools/*.py and the variant tests do.
+DEBUG_LIB_PATH = os.path.join(_HERE, "libclasspose_hip_debug.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 2
@@ -123,7 +126,7 @@ SIGNATURES = {
     "cpx_dedup_pairs": (_i, [_p, _i, _d, _d, _d, _i, _i, _d, _p, C.c_longlong, _p, _p, _sz, _p]),
     "cpx_write_geojson": (_i, [C.c_char_p, C.c_char_p, _p, C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _i, _d, _d, _i]),
 }
-# include/classpose_hip_debug.h: process-global A/B and ablation switches (tools/, a few tests)
+# include/classpose_hip_debug.h: process-global A/B and ablation switches -- exported by libclasspose_hip_debug.so only
 _PRIVATE = {
     "cpx_gemm_set_variant": (None, [_i]),
     "cpx_attention_set_trv": (None, [_i]),
@@ -155,22 +158,52 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _load(path: str, signatures: dict):
+    if not os.path.exists(path):
+        raise CpxError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is absent -> loud
+        fn.restype = res
+        fn.argtypes = args
+    if L.cpx_abi_version() != ABI_VERSION:
+        raise CpxError(f"{os.path.basename(path)} ABI version mismatch")
+    return L
+
+
 def lib():
+    """The library every product call goes through: libclasspose_hip.so, unless this process has switched to the debug
+    build (``use_debug_library()`` or CLASSPOSE_HIP_DEBUG=1 in the environment: tools/*.py, variant tests)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise CpxError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
-                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in {**SIGNATURES, **_PRIVATE}.items():
-            fn = getattr(L, name)          # AttributeError if the symbol is absent -> loud
-            fn.restype = res
-            fn.argtypes = args
-        if L.cpx_abi_version() != ABI_VERSION:
-            raise CpxError("libclasspose_hip.so ABI version mismatch")
-        _lib = L
+        if os.environ.get("CLASSPOSE_HIP_DEBUG") == "1":
+            _lib = _load(DEBUG_LIB_PATH, {**SIGNATURES, **_PRIVATE})
+        else:
+            _lib = _load(LIB_PATH, SIGNATURES)
     return _lib
+
+
+_debug_lib = None
+
+
+class use_debug_library:
+    """``with _lib.use_debug_library() as L:`` -- inside the block ``lib()`` (hence ``ops.*``) is the -DCPX_DEBUG build,
+    whose switches ``L.cpx_*_set_*`` select kernel variants; objects created outside the block (an ``Engine``) keep the
+    product library."""
+
+    def __enter__(self):
+        global _lib, _debug_lib
+        if _debug_lib is None:
+            _debug_lib = _load(DEBUG_LIB_PATH, {**SIGNATURES, **_PRIVATE})
+        self._saved = _lib
+        _lib = _debug_lib
+        return _debug_lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
 
 
 def check(rc: int, what: str = "") -> None:

@@ -36,6 +36,16 @@ extern thread_local char cpx_err_buf[256];
         }                                                                         \
     } while (0)
 
+// A/B, ablation and diagnostic switches (include/classpose_hip_debug.h) exist only in the debug build
+// (-DCPX_DEBUG -> libclasspose_hip_debug.so, what tools/*.py and the variant tests load).  In the product library
+// each switch is a compile-time constant at its production value: no setter is exported, no non-production kernel
+// is instantiated, and there is no mutable process-global state that could alter results.
+#ifdef CPX_DEBUG
+#define CPX_SWITCH(name, value) static int name = (value)
+#else
+#define CPX_SWITCH(name, value) [[maybe_unused]] static constexpr int name = (value)
+#endif
+
 static inline size_t cpx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cpx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -1018,25 +1018,25 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
     }
 }
 
-static int g_gemm_persist = 1;      // 1 = persistent 256^2 kernel (k_gemm256p), 0 = one workgroup per tile (k_gemm256)
-extern "C" void cpx_gemm_set_persistent(int on) { g_gemm_persist = on; }
-
-static int g_gemm_variant = 1;     // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
-extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
-
-static int g_gemm_dbg = 0;
-extern "C" void cpx_gemm_set_dbg(int v) { g_gemm_dbg = v; }
-static int g_gemm_l2 = 1;
-static int g_gemm_persist_qkv = 1;   // balanced persistent tile list for the qkv projection (A/B switch, default on)
-extern "C" void cpx_gemm_set_persistent_qkv(int on) { g_gemm_persist_qkv = on; }
-extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
+CPX_SWITCH(g_gemm_persist, 1);      // 1 = persistent 256^2 kernel (k_gemm256p), 0 = one workgroup per tile (k_gemm256)
+CPX_SWITCH(g_gemm_variant, 1);      // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
+CPX_SWITCH(g_gemm_dbg, 0);          // timing-only ablations of the 256^2 epilogue
+CPX_SWITCH(g_gemm_l2, 1);           // 1 = 8 x 4 super-tile order per XCD, N-sweep; 2: M-sweep; 0: row-major
+CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv projection
 // experiment switch (default off): mlp.lin2 walks M backwards so that the most recently written rows of the
 // 268 MB hidden tensor (> the 256 MB Infinity Cache) are read first.  Bitwise identical; measured 26.50 vs
 // 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
-static int g_gemm_rev = 0;
+CPX_SWITCH(g_gemm_rev, 0);
+CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
+#ifdef CPX_DEBUG
+extern "C" void cpx_gemm_set_persistent(int on) { g_gemm_persist = on; }
+extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
+extern "C" void cpx_gemm_set_dbg(int v) { g_gemm_dbg = v; }
+extern "C" void cpx_gemm_set_persistent_qkv(int on) { g_gemm_persist_qkv = on; }
+extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
-static int g_gemm_big = 1;         // 1 = use the 256^2 kernel when the shape allows
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
+#endif
 
 template <int EPI, bool F16, int FLAGS>
 static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
@@ -1082,6 +1082,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
         // one instantiation per (LayerNorm consumer | statistics producer) x (timing ablations, bf16 only)
         constexpr int F1 = EPI == CPX_EPI_RESID_BF16 ? G2F_STATS : G2F_LN;
         const bool f1 = EPI == CPX_EPI_RESID_BF16 ? a.stats_out != nullptr : a.ln_stats != nullptr;
+#ifdef CPX_DEBUG
         if constexpr (!F16) {
             if (a.dbg) {
                 if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DBG>(a, s);
@@ -1089,6 +1090,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                 return true;
             }
         }
+#endif
         if (f1) launch_gemm256_flags<EPI, F16, F1>(a, s);
         else launch_gemm256_flags<EPI, F16, 0>(a, s);
         return true;
@@ -1100,13 +1102,15 @@ static void launch_gemm(const GemmArgs &a, hipStream_t s, bool f16) {
     if (f16 ? launch_gemm256<EPI, true>(a, s) : launch_gemm256<EPI, false>(a, s)) return;
     dim3 grid(a.n_blocks), block(GEMM_THREADS);
     size_t lds = 2 * STAGE_BYTES;
-    if (f16) {
-        if (g_gemm_variant) hipLaunchKernelGGL((k_gemm<EPI, true, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((k_gemm<EPI, true, false>), grid, block, lds, s, a);
-    } else {
-        if (g_gemm_variant) hipLaunchKernelGGL((k_gemm<EPI, false, true>), grid, block, lds, s, a);
+#ifdef CPX_DEBUG
+    if (!g_gemm_variant) {           // register-staged variant of the 128^2 kernel: A/B reference only
+        if (f16) hipLaunchKernelGGL((k_gemm<EPI, true, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_gemm<EPI, false, false>), grid, block, lds, s, a);
+        return;
     }
+#endif
+    if (f16) hipLaunchKernelGGL((k_gemm<EPI, true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_gemm<EPI, false, true>), grid, block, lds, s, a);
 }
 
 // row statistics (sum, sum of squares) of a half-precision [rows][1024] matrix into slot 0 of

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(256) k_v_transpose(const unsigned short *__res
 #define GS_LD 65                       // padded row of the per-wave G scratch (floats)
 __device__ __forceinline__ int pi_perm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
+#ifdef CPX_DEBUG   // ---- non-production attention kernels (variant 0: register ring; variant 1: 8-wave ping-pong) + stamps
 // DBG = true: diagnostic build with s_memtime stamps per loop segment (never used in production;
 // stamp values only go to `dbg`, no output depends on them)
 #define ATT_STAMP(i)                                                                           \
@@ -665,6 +666,7 @@ __global__ void __launch_bounds__(A8_THREADS, 2) k_attention8(const unsigned sho
             *reinterpret_cast<uint2 *>(orow + d) = o;
         }
 }
+#endif  // CPX_DEBUG
 
 
 // ---------------------------------------------------------------------------
@@ -872,17 +874,18 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         }
 }
 
-static int g_att_xcd = 1;          // XCD-aware workgroup order (debug / A-B switch)
-static int g_att_v8 = 2;           // 2: 4-wave kernel with the LDS-DMA ring and software-pipelined S (production); 0: the first 4-wave kernel
+CPX_SWITCH(g_att_xcd, 1);          // XCD-aware workgroup order
+CPX_SWITCH(g_att_v8, 2);           // 2: 4-wave kernel with the LDS-DMA ring and software-pipelined S (production); 0: the first 4-wave kernel
                                    // (register ring); 1: the 8-wave ping-pong experiment
-extern "C" void cpx_attention_set_variant(int v8) { g_att_v8 = v8; }
-extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 // experiment switch (default off): V read from the qkv rows through ds_read_b64_tr_b16, no V^T buffer and a plain
 // qkv epilogue.  Bitwise identical outputs; the whole engine step measured 24.57 vs 24.44 ms (one-process A/B,
 // tools/ab_switch.py cpx_attention_set_trv): the 8 transposed reads per tile cost more than the epilogue saves.
-static int g_att_trv = 0;
-extern "C" void cpx_attention_set_trv(int v) { g_att_trv = v; }
+CPX_SWITCH(g_att_trv, 0);
 int cpx_attention_trv_enabled(void) { return g_att_trv; }
+#ifdef CPX_DEBUG
+extern "C" void cpx_attention_set_variant(int v8) { g_att_v8 = v8; }
+extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
+extern "C" void cpx_attention_set_trv(int v) { g_att_trv = v; }
 // diagnostic: per-wave cycle counts of the loop segments -> dbg [n_subtiles*16*8 blocks][4 waves][9]
 extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
@@ -907,6 +910,7 @@ extern "C" int cpx_attention8_debug(const void *qkv, const void *rel_h, const vo
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
+#endif
 extern "C" int cpx_attention_relpos(const void *qkv, const void *rel_h, const void *rel_w,
                                     int n_subtiles, void *vT_ws, void *out, void *stream) {
     return cpx_attention_half(CPX_DT_BF16, qkv, rel_h, rel_w, n_subtiles, vT_ws, out, stream, true);
@@ -926,22 +930,7 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
     if (transpose_v && !g_att_trv)
         hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
                            (const unsigned short *)qkv, (unsigned short *)vT_ws);
-    if (g_att_v8 == 2 && !g_att_trv) {
-        const dim3 grid4(8, 16, n_subtiles);
-        static CpxOncePerDevice once4;
-        once4([] {
-            (void)hipFuncSetAttribute((const void *)k_attention4p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void *)k_attention4p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
-        });
-        if (dtype == CPX_DT_F16)
-            hipLaunchKernelGGL((k_attention4p<true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
-                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
-        else
-            hipLaunchKernelGGL((k_attention4p<false>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
-                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
-        CPX_CHECK_LAUNCH();
-        return CPX_OK;
-    }
+#ifdef CPX_DEBUG
     if (g_att_v8 == 1 && !g_att_trv) {
         const dim3 grid8(4, 16, n_subtiles);
         if (dtype == CPX_DT_F16)
@@ -953,14 +942,31 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         CPX_CHECK_LAUNCH();
         return CPX_OK;
     }
-    dim3 grid(8, 16, n_subtiles);
+    if (g_att_v8 != 2 || g_att_trv) {
+        dim3 grid(8, 16, n_subtiles);
 #define ATT_LAUNCH(F16_, TRV_)                                                                              \
     hipLaunchKernelGGL((k_attention<F16_, false, TRV_>), grid, dim3(ATT_THREADS), 0, s, (const unsigned short *)qkv, \
                        (const unsigned short *)vT_ws, (const unsigned short *)rel_h, (const unsigned short *)rel_w, \
                        (unsigned short *)out, (unsigned *)nullptr, g_att_xcd)
-    if (dtype == CPX_DT_F16) { if (g_att_trv) ATT_LAUNCH(true, true); else ATT_LAUNCH(true, false); }
-    else { if (g_att_trv) ATT_LAUNCH(false, true); else ATT_LAUNCH(false, false); }
+        if (dtype == CPX_DT_F16) { if (g_att_trv) ATT_LAUNCH(true, true); else ATT_LAUNCH(true, false); }
+        else { if (g_att_trv) ATT_LAUNCH(false, true); else ATT_LAUNCH(false, false); }
 #undef ATT_LAUNCH
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
+#endif
+    const dim3 grid4(8, 16, n_subtiles);
+    static CpxOncePerDevice once4;
+    once4([] {
+        (void)hipFuncSetAttribute((const void *)k_attention4p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_attention4p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+    });
+    if (dtype == CPX_DT_F16)
+        hipLaunchKernelGGL((k_attention4p<true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                           (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+    else
+        hipLaunchKernelGGL((k_attention4p<false>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                           (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }

@@ -1219,8 +1219,10 @@ static int pp_check(int nT, int H, int W) {
     return CPX_OK;
 }
 
-static int g_follow_early = 1;      // exact orbit-closure early exit of the Euler loop (debug / A-B switch)
+CPX_SWITCH(g_follow_early, 1);      // exact orbit-closure early exit of the Euler loop (debug / A-B switch)
+#ifdef CPX_DEBUG
 extern "C" void cpx_follow_set_early_exit(int on) { g_follow_early = on; }
+#endif
 
 extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, int H, int W,
                                 float thr, int niter, int32_t *p_final, float *p_float, void *ws,

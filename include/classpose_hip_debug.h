@@ -1,9 +1,11 @@
 /*
- * classpose_hip_debug.h -- A/B, ablation and diagnostic switches of libclasspose_hip.so.
+ * classpose_hip_debug.h -- A/B, ablation and diagnostic switches.
  *
- * NOT part of the product ABI (include/classpose_hip.h): these are process-global test hooks used
- * by tools/*.py and a few tests to compare kernel variants in one process.  They are not
- * thread-safe, default to the production setting and no product code path calls them.
+ * NOT part of the product ABI (include/classpose_hip.h) and NOT in the product library: these symbols -- and the
+ * non-production kernel variants they select -- exist only in libclasspose_hip_debug.so, the same sources built with
+ * -DCPX_DEBUG (csrc/Makefile).  libclasspose_hip.so exports none of them; there each switch is a compile-time constant
+ * at its production value.  They are process-global test hooks used by tools/*.py and a few tests to compare kernel
+ * variants in one process (classpose_amd._lib.use_debug_library() / CLASSPOSE_HIP_DEBUG=1); not thread-safe.
  */
 #ifndef CLASSPOSE_HIP_DEBUG_H
 #define CLASSPOSE_HIP_DEBUG_H

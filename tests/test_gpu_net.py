@@ -20,7 +20,12 @@ def _rel(a, b):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (1024, 1024, 1024), (2048, 640, 256),
                                    (1024, 256, 2304)])
 def test_gemm_epilogues(cuda, variant, M, N, K):
-    _lib.lib().cpx_gemm_set_variant(variant)
+    with _lib.use_debug_library() as L:          # the register-staged A/B variant only exists in the -DCPX_DEBUG build
+        _gemm_epilogues(L, cuda, variant, M, N, K)
+
+
+def _gemm_epilogues(L, cuda, variant, M, N, K):
+    L.cpx_gemm_set_variant(variant)
     try:
         g = torch.Generator(device="cpu").manual_seed(M + N + K)
         A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
@@ -44,7 +49,7 @@ def test_gemm_epilogues(cuda, variant, M, N, K):
             exp = ref + bias + pos[torch.arange(M, device=cuda) % 1024]
             assert _rel(out.float(), exp) < 4e-3
     finally:
-        _lib.lib().cpx_gemm_set_variant(1)
+        L.cpx_gemm_set_variant(1)
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 1024), (16384, 1024, 128), (16384, 1024, 256),
@@ -58,15 +63,18 @@ def test_gemm256_epilogues(cuda, M, N, K):
     bias = torch.randn(N, generator=g).to(cuda)
     res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(cuda)
     ref = A.float() @ W.float().T
-    L = _lib.lib()
     outs = {}
-    for big in (1, 0):
-        L.cpx_gemm_set_big(big)
+    run = lambda: [ops.gemm(A, W, "bf16", None), ops.gemm(A, W, "bf16", bias), ops.gemm(A, W, "gelu", bias),
+                   ops.gemm(A, W, "relu", bias), ops.gemm(A, W, "resid", bias, res)]
+    outs[1] = run()                                  # the product library
+    with _lib.use_debug_library() as L:              # 128^2 kernel forced on the same shapes (debug-build switch)
+        L.cpx_gemm_set_big(0)
         try:
-            outs[big] = [ops.gemm(A, W, "bf16", None), ops.gemm(A, W, "bf16", bias), ops.gemm(A, W, "gelu", bias),
-                         ops.gemm(A, W, "relu", bias), ops.gemm(A, W, "resid", bias, res)]
+            outs[0] = run()
         finally:
             L.cpx_gemm_set_big(1)
+        dbg_big = run()
+    assert all(torch.equal(a, b) for a, b in zip(outs[1], dbg_big))     # debug build at its defaults == product, bit for bit
     exp = [ref, ref + bias, torch.nn.functional.gelu(ref + bias), torch.relu(ref + bias), ref + bias + res.float()]
     for k, (o1, o0, e) in enumerate(zip(outs[1], outs[0], exp)):
         assert _rel(o1.float(), e) < 5e-3, (k, _rel(o1.float(), e))
@@ -488,7 +496,6 @@ def test_attention_variants_repeatable_and_agree(cuda, variant):
     """race screen for the hand-synchronised attention kernels (LDS-DMA ring behind counted vmcnt + raw barriers,
     8-wave ping-pong): 40 launches on 32 sub-tiles under concurrent load must be bitwise identical, every variant
     within bf16 rounding of the float64 reference"""
-    L = _lib.lib()
     g = torch.Generator().manual_seed(11)
     nS = 32
     qkv = (torch.randn(nS * 1024, 3072, generator=g) * 0.7).to(torch.bfloat16).to(cuda)
@@ -496,17 +503,21 @@ def test_attention_variants_repeatable_and_agree(cuda, variant):
     rel[63] = 0
     noise = torch.empty((8192, 8192), device=cuda)
     side = torch.cuda.Stream(cuda)
-    L.cpx_attention_set_variant(variant)
-    try:
-        first = ops.attention(qkv, rel, rel)
-        for i in range(40):
-            if i % 4 == 0:
-                with torch.cuda.stream(side):               # uneven memory load next to the kernel
-                    noise.normal_()
-            assert torch.equal(ops.attention(qkv, rel, rel), first), (variant, i)
-        side.synchronize()
-    finally:
-        L.cpx_attention_set_variant(2)
+    product = ops.attention(qkv, rel, rel) if variant == 2 else None     # the production kernel in the PRODUCT library
+    with _lib.use_debug_library() as L:                  # variants 0 / 1 only exist in the -DCPX_DEBUG build
+        L.cpx_attention_set_variant(variant)
+        try:
+            first = ops.attention(qkv, rel, rel)
+            for i in range(40):
+                if i % 4 == 0:
+                    with torch.cuda.stream(side):               # uneven memory load next to the kernel
+                        noise.normal_()
+                assert torch.equal(ops.attention(qkv, rel, rel), first), (variant, i)
+            side.synchronize()
+        finally:
+            L.cpx_attention_set_variant(2)
+    if product is not None:
+        assert torch.equal(product, first)
     q, k, v = qkv[:1024].double().reshape(1024, 3, 16, 64).permute(1, 2, 0, 3)
     idx = (torch.arange(32)[:, None] - torch.arange(32)[None, :] + 31).to(cuda)
     R = rel.double()[idx] / 8

@@ -24,6 +24,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
     assert _lib.lib().cpx_abi_version() == _lib.ABI_VERSION
     assert _lib.lib().cpx_postproc_workspace_bytes(2, 256, 256) > 0
+    # what the product library exports is EXACTLY the product header: no A/B setter, no diagnostic entry point
+    import subprocess
+    exported = set(re.findall(r" T (cpx_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", so], text=True)))
+    assert exported == declared, exported ^ declared
+    # the -DCPX_DEBUG build adds include/classpose_hip_debug.h on top of the same ABI
+    dbg_hdr = open(os.path.join(ROOT, "include", "classpose_hip_debug.h")).read()
+    dbg_declared = set(re.findall(r"\b(cpx_[a-z0-9_]+)\s*\(", dbg_hdr))
+    assert dbg_declared == set(_lib._PRIVATE), dbg_declared ^ set(_lib._PRIVATE)
+    dbg_exported = set(re.findall(r" T (cpx_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", _lib.DEBUG_LIB_PATH], text=True)))
+    assert dbg_exported == declared | dbg_declared, dbg_exported ^ (declared | dbg_declared)
+    with _lib.use_debug_library() as D:
+        assert _lib.lib() is D and D.cpx_abi_version() == _lib.ABI_VERSION
+    assert _lib.lib() is not D
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

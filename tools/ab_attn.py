@@ -1,5 +1,7 @@
 """Attention kernel timing + correctness vs a saved reference output (for A/B across builds on one box,
 run the OLD build first with `save`, then the new one with `check`)."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

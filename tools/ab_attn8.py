@@ -1,5 +1,7 @@
 """A/B of the attention kernels in one process (interleaved rounds): 4-wave register-ring kernel (variant 0), 8-wave
 ping-pong (variant 1), 4-wave LDS-DMA ring + software-pipelined S (variant 2); max |difference| of the outputs and both against a float64 reference on 1 sub-tile."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

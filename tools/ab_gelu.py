@@ -1,5 +1,7 @@
 """mlp.lin1 (persistent 256^2 GEMM, folded LayerNorm + GELU) with the production erf (A-S 7.1.26, 5 terms) against a
 3-term variant (7.1.25) and against no GELU at all: timing only, all three in the DBG instantiation, interleaved."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

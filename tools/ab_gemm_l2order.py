@@ -1,6 +1,8 @@
 """A/B of the super-tile order of the 256^2 GEMMs: mode 1 (an XCD sweeps N for a fixed band of 8 row tiles) against
 mode 2 (an XCD keeps one 4-tile W panel and streams the activation rows past it), on the per-layer shapes with the
 production epilogues: interleaved rounds in one process + bitwise comparison."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

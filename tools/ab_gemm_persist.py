@@ -1,6 +1,8 @@
 """A/B of the persistent 256^2 GEMM (k_gemm256p: next tile's K-tile 0 prefetched under the epilogue) against the
 one-workgroup-per-tile kernel (k_gemm256) on the per-layer shapes with the production epilogues (folded LayerNorm
 for qkv / fc1, statistics producer for proj / fc2): interleaved rounds in one process + bitwise comparison."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

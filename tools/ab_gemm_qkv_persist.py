@@ -1,6 +1,8 @@
 """A/B of the qkv projection: one workgroup per tile (k_gemm256) against the persistent kernel with the balanced
 q|k / V^T tile list (cpx_gemm_set_persistent_qkv), folded LayerNorm + V^T epilogue as in production; interleaved
 rounds in one process + bitwise comparison, for 32, 96, 144 (a half round at the end) and 16 sub-tiles."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,7 @@
 """In-process interleaved A/B of a private debug switch on the whole engine step.
 usage: python tools/ab_switch.py cpx_gemm_set_reverse [cpx_other_switch ...]"""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,7 @@
 """Race screen for the 256^2 GEMM: many launches, bitwise comparison against the first result and
 against the 128^2 kernel, with a second stream hammering HBM meanwhile."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
