@@ -124,8 +124,10 @@ class NetWeights:
         if precision == "fp32":
             fuse_ln = False
         fts, ncls, depth = cls.infer_structure(sd)
-        if fts is not None and (any(c % 8 for c in fts) or len(fts) > 3):
-            raise NotImplementedError("UNet semantic head: channel counts must be multiples of 8, at most 3 levels")
+        if fts is not None and len(fts) > 4:
+            # 32 x 32 tokens halve once per encoder level and once more in the bottleneck: a fifth level would hand
+            # torch's own Conv2d(k=2, s=2) a 0 x 0 image in the reference too (unet.py:173-196)
+            raise ValueError("UNet semantic head: at most 4 encoder levels fit the 32 x 32 token grid")
         if sd["encoder.patch_embed.proj.weight"].shape != (1024, 3, 8, 8):
             raise ValueError("only the vit_l / ps=8 Cellpose-SAM backbone is supported")
         self = cls()
@@ -216,9 +218,14 @@ class NetWeights:
         return self
 
     def _build_unet_ops(self, sd, fts, out_ch, half, vec32):
-        """Flatten classpose.unet.UNet (unet.py:146-196) into the conv list of cpx_conv_op."""
+        """Flatten classpose.unet.UNet (unet.py:121-196, any ``n_channels`` list) into the conv list of cpx_conv_op.
+
+        The device kernels move 16-byte channel chunks, so every tensor carries its channel count rounded up to a
+        multiple of 8: the extra input columns and output rows of each weight matrix (and the extra biases) are zero,
+        hence the extra channels hold exact zeros through every ReLU / concat and contribute nothing downstream."""
         hd = {0: torch.bfloat16, 1: torch.float16, 2: torch.float32}[self.c.dtype]
         up = lambda x, m: (x + m - 1) // m * m
+        p8 = lambda c: up(c, 8)
         ops = []
 
         def rounded(t):
@@ -226,12 +233,23 @@ class NetWeights:
 
         def add(kind, src_a, src_b, cin_a, cin_b, cout, h, relu, wkey):
             w, b = rounded(sd[wkey + ".weight"]), rounded(sd[wkey + ".bias"])
+            ca, cb, co = p8(cin_a), p8(cin_b), p8(cout)
             if kind == 2:       # ConvTranspose2d [cin][cout][2][2] -> rows (dy, dx, co), cols ci
-                wm = w.permute(2, 3, 1, 0).reshape(4 * cout, cin_a)
-                bm = b.repeat(4)
-            else:               # Conv2d [cout][cin][k][k] -> cols (ky, kx, ci)
-                wm = w.permute(0, 2, 3, 1).reshape(cout, -1)
-                bm = b
+                wt = torch.zeros(2, 2, co, ca)
+                wt[:, :, :cout, :cin_a] = w.permute(2, 3, 1, 0)
+                wm = wt.reshape(4 * co, ca)
+                bt = torch.zeros(4, co)
+                bt[:, :cout] = b[None, :]
+                bm = bt.reshape(-1)
+            else:               # Conv2d [cout][cin_a + cin_b][k][k] -> cols (ky, kx, ci of a | ci of b)
+                k = w.shape[-1]
+                wt = torch.zeros(co, k, k, ca + cb)
+                wk = w.permute(0, 2, 3, 1)
+                wt[:cout, :, :, :cin_a] = wk[..., :cin_a]
+                wt[:cout, :, :, ca:ca + cin_b] = wk[..., cin_a:]
+                wm = wt.reshape(co, -1)
+                bm = torch.zeros(co)
+                bm[:cout] = b
             n_pad, k_pad = up(wm.shape[0], 128), up(wm.shape[1], 64)
             wp = torch.zeros(n_pad, k_pad)
             wp[: wm.shape[0], : wm.shape[1]] = wm
@@ -239,7 +257,7 @@ class NetWeights:
             bp[: bm.shape[0]] = bm
             op = CpxConvOp()
             op.kind, op.src_a, op.src_b, op.dst = kind, src_a, src_b, len(ops) + 1
-            op.cin_a, op.cin_b, op.cout, op.h, op.w, op.relu = cin_a, cin_b, cout, h, h, int(relu)
+            op.cin_a, op.cin_b, op.cout, op.h, op.w, op.relu = ca, cb, co, h, h, int(relu)
             op.weight, op.bias = half(wp), vec32(bp)
             ops.append(op)
             return op.dst
@@ -271,7 +289,7 @@ class NetWeights:
             t = block(p, cur, fid, seq[i], fc, seq[i + 1], h, last_relu=(i != len(fts) - 1))
             cur = add(2, t, -1, seq[i + 1], 0, seq[i + 1], h, False, p + "upconv")
             h *= 2
-        assert h == 32
+        assert h == 32 and out_ch % 8 == 0
         self.unet_ops = (CpxConvOp * len(ops))(*ops)
         self.c.n_unet_ops = len(ops)
         self.c.unet_ops = C.cast(self.unet_ops, C.POINTER(CpxConvOp))

@@ -152,6 +152,17 @@ def main():
     for k, v in un.state_dict().items():
         out["unet_sd__" + k] = v.numpy()
 
+    # ---- the same with FOUR encoder levels (1 x 1 at the bottom of the bottleneck) and ragged widths
+    torch.manual_seed(8)
+    un4 = UNet(in_channels=16, out_channels=24, n_channels=[6, 10, 12, 20]).eval()
+    xin4 = torch.randn(1, 16, 32, 32)
+    with torch.no_grad():
+        yout4 = un4(xin4)
+    out["unet4_x"] = xin4.numpy()
+    out["unet4_y"] = yout4.numpy()
+    for k, v in un4.state_dict().items():
+        out["unet4_sd__" + k] = v.numpy()
+
     # ---- _get_coords (bound method is a plain generator; call unbound with a dummy self)
     gc = {}
     for dim, tile, ov in ((10000, 256, 32), (40000, 256, 32), (80000, 256, 32),

@@ -322,9 +322,12 @@ def test_net_forward_fused_vs_unfused_layernorm(cuda, fuse):
     assert _rel(ours, ref32) < 2e-2, _rel(ours, ref32)
 
 
-@pytest.mark.parametrize("fts,nS", [([64, 128], 2), ([32], 1), ([64, 128], 8)])
+@pytest.mark.parametrize("fts,nS", [([64, 128], 2), ([32], 1), ([64, 128], 8), ([20, 36], 2), ([12, 20, 36, 68], 1),
+                                    ([64, 128, 256, 512], 1)])
 def test_unet_semantic_head_vs_oracle(cuda, fts, nS):
-    """feature_transformation_structure checkpoints: UNet head as conv list on the MFMA GEMM"""
+    """feature_transformation_structure checkpoints: UNet head as conv list on the MFMA GEMM -- any ``n_channels`` list
+    the reference's UNet accepts (unet.py:121-196): channel counts that are not multiples of 8 (zero-padded on the host),
+    up to the 4 encoder levels the 32 x 32 token grid allows, and the reference's own default [64, 128, 256, 512]"""
     sd = synth.make_state_dict(7, fts, depth=1, seed=11)
     w = engine.NetWeights.from_state_dict(sd, "bf16", cuda)
     assert w.c.n_unet_ops == 3 * (2 * len(fts) + 2)

@@ -170,3 +170,45 @@ def test_wsi_reader_switch_imports_openslide(monkeypatch):
     monkeypatch.setenv("WSI_READER", "bioformats")
     with pytest.raises(ValueError, match="not supported"):
         wsi.WSIReader("/x/s.ndpi")
+
+
+@pytest.mark.parametrize("fts", [[8, 12], [20, 36], [6, 10, 12, 20]])
+def test_unet_conv_list_equals_oracle_unet(fts):
+    """host side of a10: ``NetWeights._build_unet_ops`` flattens unet.py:121-196 into the cpx_conv_op list, with channel
+    counts padded to multiples of 8 by zero weight rows / columns.  The list, executed here on the CPU by a literal
+    im2col + matmul interpreter of the op semantics (include/classpose_hip.h: cpx_conv_op), equals the oracle's UNet
+    (itself pinned on the reference's UNet, tests/test_oracle_pins.py::test_unet_golden)."""
+    import torch
+    from oracle import net as onet
+    ncls = 3
+    sd = synth.make_state_dict(ncls, fts, depth=1, seed=4)
+    w = engine.NetWeights.from_state_dict(sd, "fp32", "cpu")
+    assert w.c.n_unet_ops == 3 * (2 * len(fts) + 2)
+    by_ptr = {t.data_ptr(): t for t in w.keep}
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 256, 32, 32, generator=g)
+    tens = {0: x.permute(0, 2, 3, 1).contiguous()}                       # [S][h][w][c] token-major
+    for i in range(w.c.n_unet_ops):
+        o = w.unet_ops[i]
+        W, b = by_ptr[o.weight], by_ptr[o.bias]
+        a = tens[o.src_a]
+        assert a.shape[-1] == o.cin_a and a.shape[1] == o.h and o.cin_a % 8 == 0 and o.cin_b % 8 == 0 and o.cout % 8 == 0
+        if o.src_b >= 0:
+            a = torch.cat([a, tens[o.src_b]], -1)
+        S, h, _, c = a.shape
+        if o.kind == 0:                                                  # conv3x3 pad 1: k = tap * c_total + c
+            ap = torch.nn.functional.pad(a, (0, 0, 1, 1, 1, 1))
+            col = torch.cat([ap[:, ky:ky + h, kx:kx + h] for ky in range(3) for kx in range(3)], -1)
+            y = col.reshape(-1, 9 * c) @ W[:o.cout, :9 * c].T + b[:o.cout]
+            y = y.reshape(S, h, h, o.cout)
+        elif o.kind == 1:                                                # conv2x2 stride 2
+            col = torch.cat([a[:, dy::2, dx::2] for dy in range(2) for dx in range(2)], -1)
+            y = (col.reshape(-1, 4 * c) @ W[:o.cout, :4 * c].T + b[:o.cout]).reshape(S, h // 2, h // 2, o.cout)
+        else:                                                            # convT2x2 stride 2: n = tap * cout + co
+            z = (a.reshape(-1, c) @ W[:4 * o.cout, :c].T + b[:4 * o.cout]).reshape(S, h, h, 2, 2, o.cout)
+            y = z.permute(0, 1, 3, 2, 4, 5).reshape(S, 2 * h, 2 * h, o.cout)
+        tens[o.dst] = torch.relu(y) if o.relu else y
+    got = tens[w.c.n_unet_ops].permute(0, 3, 1, 2)
+    ref = onet.unet_forward(sd, "out_class.", x, len(fts))
+    assert got.shape == ref.shape == (2, ncls * 64, 32, 32)
+    assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max())

@@ -56,6 +56,11 @@ def test_unet_golden(golden):
           if k.startswith("unet_sd__")}
     y = net.unet_forward(sd, "h.", torch.from_numpy(npz["unet_x"]), 2).numpy()
     assert np.allclose(y, npz["unet_y"], rtol=0, atol=1e-6)
+    # four encoder levels, ragged widths [6, 10, 12, 20] (the reference's UNet run by make_golden.py)
+    sd = {"h." + k[len("unet4_sd__"):]: torch.from_numpy(npz[k]) for k in npz.files if k.startswith("unet4_sd__")}
+    y = net.unet_forward(sd, "h.", torch.from_numpy(npz["unet4_x"]), 4).numpy()
+    assert y.shape == npz["unet4_y"].shape == (1, 24, 32, 32)
+    assert np.allclose(y, npz["unet4_y"], rtol=0, atol=1e-6)
 
 
 def test_get_coords_golden(golden):
