@@ -76,15 +76,22 @@ class CachedSlide:
         return self._tiles[(int(location[0]), int(location[1]))]
 
 
-def physical_cores() -> int:
-    try:
-        import psutil
-        n = psutil.cpu_count(logical=False)
-        if n:
-            return min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    return max(1, len(os.sched_getaffinity(0)))
+def physical_core_cpus() -> list[int]:
+    """one logical CPU id per physical core this process may run on (sysfs topology; SMT siblings dropped)"""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, out = set(), []
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as f:
+                pkg = int(f.read())
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id") as f:
+                core = int(f.read())
+        except Exception:
+            pkg, core = 0, c
+        if (pkg, core) not in seen:
+            seen.add((pkg, core))
+            out.append(c)
+    return out or allowed
 
 
 def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
@@ -93,15 +100,19 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     at ~32 threads on this ViT-L), >= 64 tiles after 4 warm-up tiles unless the wall budget ends a worker earlier.
     The children never touch the GPU; they are started as ordinary child processes (no exec from this process)."""
     import subprocess
-    phys = physical_cores()
+    cpus = physical_core_cpus()
+    phys = len(cpus)
     threads = min(32, phys)
     P = max(1, phys // threads)
     per = -(-n_tiles // P)
     warm = max(1, -(-warm_total // P))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    # each worker is pinned to its own block of physical cores (un-pinned, the four 32-thread pools of a 128-core host
+    # land on each other: 25.7 s per tile instead of 4.9 s, measured)
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--slide", str(slide_px), "--first", str(i),
                                "--stride", str(P), "--tiles", str(per), "--warm", str(warm), "--threads", str(threads),
-                               "--budget", str(budget_s), "--depth", str(depth)],
+                               "--budget", str(budget_s), "--depth", str(depth),
+                               "--cpus", ",".join(map(str, cpus[i * threads:(i + 1) * threads]))],
                               cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(P)]
     res = []
     for p in procs:
@@ -118,7 +129,7 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     stage = {k: round(sum(r["stage_s"][k] for r in res) / tiles * 1e3, 2) for k in res[0]["stage_s"]}
     return dict(value=rate, unit="tiles/s", cores=len(res) * threads, kind="port", cells_per_s=cells / tiles * rate,
                 processes=len(res), threads_per_process=threads, physical_cores=phys, stage_ms_per_tile=stage,
-                sample=f"{tiles} tiles of the same workload ({len(res)} processes x {threads} torch threads on disjoint tiles, "
+                sample=f"{tiles} tiles of the same workload ({len(res)} processes x {threads} torch threads, each pinned to its own {threads} physical cores, on disjoint tiles, "
                        f"{warm} warm-up tile(s) each = {warm * len(res)} in all), one tile per eval (4 sub-tiles, fp32 torch-CPU "
                        f"ViT-L + oracle dynamics on the injected fields); all windows within {span:.1f} s; the literal "
                        f"reference cannot run here (cellpose / cv2 / openslide wheels absent)")

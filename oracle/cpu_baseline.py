@@ -75,7 +75,10 @@ def main() -> None:
     ap.add_argument("--budget", type=float, default=90.0)
     ap.add_argument("--depth", type=int, default=24)
     ap.add_argument("--start-at", type=float, default=0.0)
+    ap.add_argument("--cpus", type=str, default="", help="comma-separated logical CPU ids this worker is pinned to")
     a = ap.parse_args()
+    if a.cpus:
+        os.sched_setaffinity(0, {int(c) for c in a.cpus.split(",")})      # before torch creates its thread pool
     print("CPU_BASELINE " + json.dumps(run(a.slide, a.first, a.stride, a.tiles, a.warm, a.threads, a.budget, a.depth,
                                              start_at=a.start_at)), flush=True)
 
