@@ -1018,6 +1018,235 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
     }
 }
 
+// ===========================================================================
+// "ping-pong" form: 256 (M) x 128 (N) x 64 tile, 256 threads = 4 waves, TWO workgroups per CU
+// ===========================================================================
+// The 256^2 kernel holds a CU with one 8-wave workgroup: while its waves run the VALU-bound epilogue (LayerNorm
+// fold, bias, erf-GELU, conversion, staging, stores: ~40 % of a mlp.lin1 tile) the CU's matrix cores idle, and while
+// they wait at the phase barriers of the main loop nothing else can issue.  Here a workgroup is half as large
+// (4 waves, one per SIMD, <= 256 registers, 80 KB of LDS) so that two of them, working on DIFFERENT tiles and
+// drifting freely against each other, share every SIMD: one workgroup's epilogue VALU stream issues beside the other's
+// MFMA stream (a v_mfma_f32_16x16x32 holds the SIMD's vector issue for 8 of its 16 cycles, tools/micro/coexec.hip), and
+// one's barrier / LDS-latency bubbles are the other's issue slots.
+// Per-wave output = 2 quadrants (hm) of 64 tokens x 64 channels: tokens 128 hm + 64 wm + [0,64), channels 64 wn + [0,64)
+// -> in a phase ALL waves read the same operand items.  Operand items of 16 KB (128 rows x 64 k, lane-linear LDS-DMA
+// image, 16-byte chunk c of row r at position c ^ (r & 7)): per K tile t  W(t), X0(t), X1(t) = items 3t, 3t+1, 3t+2, item
+// j in slot j % 5 of a 5-slot ring.  Two phases per K tile, ONE raw barrier each, behind a counted vmcnt:
+//   A(t): reads W(t), X0(t) -> 32 MFMAs into quadrant 0;  issues item 3t+4 = X0(t+1)   (slot of X1(t-1), read in B(t-1))
+//   B(t): reads X1(t)       -> 32 MFMAs into quadrant 1;  issues items 3t+5, 3t+6 = X1(t+1), W(t+2)  (slots of W(t), X0(t))
+// A slot is re-filled only after the barrier that follows its last reading phase; every item is requested >= 2 phases
+// before the phase that reads it; waits never drain the queue in the steady state (vmcnt(8)).
+#define PP_THREADS 256
+#define PP_SLOT 16384
+#define PP_NSLOT 5
+#define PP_EPI_LD 272                                   // staging row: 128 channels x 2 B + 16
+#define PP_PAR_OFF (256 * PP_EPI_LD)                    // 69632: 256 x (rstd, -mean rstd) behind the staging rows
+#define PP_LDS_BYTES (PP_NSLOT * PP_SLOT)               // 81920 >= PP_PAR_OFF + 2048
+__device__ __forceinline__ u32x4 pp_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int EPI, bool F16, int FLAGS>
+__global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
+    constexpr bool LN_IN = (FLAGS & G2F_LN) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int K = g.K, nk = K / 64;
+    // workgroup -> tile: ids that share an XCD (id % 8) get a contiguous range; the 64 workgroups an XCD runs at a time
+    // (2 per CU) cover an 8 (M) x 8 (N) super-tile = 8 activation panels + 8 weight panels
+    int tile_m, tile_n;
+    {
+        const int nxcd = 8, q = g.n_blocks / nxcd, r = g.n_blocks % nxcd, x = blockIdx.x % nxcd;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / nxcd;
+        const int tiles_m = g.n_blocks / g.tiles_n;
+        if ((tiles_m & 7) == 0 && (g.tiles_n & 7) == 0) {
+            const int grp = bid >> 6, w_ = bid & 63, cgn = g.tiles_n >> 3;
+            const int rg = grp / cgn, cg = grp - rg * cgn;
+            tile_m = rg * 8 + (w_ >> 3);
+            tile_n = cg * 8 + (w_ & 7);
+        } else {
+            tile_m = bid / g.tiles_n;
+            tile_n = bid - tile_m * g.tiles_n;
+        }
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * 128;
+
+    // folded LayerNorm: this thread's token row (m0 + tid) -> (rstd, -mean rstd), parked in LDS after the main loop
+    float ln_rs = 0.f, ln_nm = 0.f;
+    if constexpr (LN_IN) {
+        const float4 a = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8);
+        const float4 b = *reinterpret_cast<const float4 *>(g.ln_stats + (size_t)(m0 + tid) * 8 + 4);
+        const float inv_k = 1.0f / K;
+        const float sum = (a.x + a.z) + (b.x + b.z), sq = (a.y + a.w) + (b.y + b.w);
+        const float mean = sum * inv_k;
+        ln_rs = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-6f);
+        ln_nm = -mean * ln_rs;
+    }
+
+    // staging: one item = 128 rows x 64 k = 4 DMA instructions per wave; thread -> (row = 32 q + tid>>3, position tid&7)
+    const int srow = tid >> 3, kc = (tid & 7) ^ (srow & 7);
+    const unsigned short *pX = g.A + (size_t)(m0 + srow) * K + kc * 8;
+    const unsigned short *pW = g.W + (size_t)(n0 + srow) * K + kc * 8;
+    const size_t k32 = (size_t)32 * K, k128 = (size_t)128 * K;
+    char *sdst = smem + wave * 1024;
+    auto issue = [&](const unsigned short *p, int slot) {
+        char *d = sdst + slot * PP_SLOT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p + q * k32),
+                                             (__attribute__((address_space(3))) void *)(d + q * 4096), 16, 0, 0);
+    };
+    auto issue_w = [&](int t, int slot) { issue(pW + (size_t)t * 64, slot); };
+    auto issue_x = [&](int hm, int t, int slot) { issue(pX + hm * k128 + (size_t)t * 64, slot); };
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    unsigned xa[2], wa[2];                       // per-lane fragment bases (slot offset added per phase)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned sw = (unsigned)(((ks * 4 + fq) ^ (fr & 7)) << 4);
+        xa[ks] = lds0 + (wm * 64 + fr) * 128 + sw;
+        wa[ks] = lds0 + (wn * 64 + fr) * 128 + sw;
+    }
+
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 fx[4][2], fw[4][2];
+
+    // prologue: items 0..4 = W(0), X0(0), X1(0), W(1), X0(1)
+    issue_w(0, 0); issue_x(0, 0, 1); issue_x(1, 0, 2);
+    if (nk > 1) { issue_w(1, 3); issue_x(0, 1, 4); }
+    int sl = 0;                                  // slot of item 3t = W(t)
+    auto nxt = [](int s_, int d) { int r = s_ + d; return r >= PP_NSLOT ? r - PP_NSLOT : r; };
+    for (int t = 0; t < nk; ++t) {
+        const int s_w = sl, s_x0 = nxt(sl, 1), s_x1 = nxt(sl, 2);
+        // ---- phase A(t)
+        if (t == 0) { if (nk > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (t < nk - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t >= 1 && t + 1 < nk) issue_x(0, t + 1, nxt(sl, 4));          // item 3t+4 -> slot of item 3t-1
+        {
+            const unsigned ow = (unsigned)s_w * PP_SLOT, ox = (unsigned)s_x0 * PP_SLOT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fw[i][0] = pp_read128(wa[0] + ow + i * 2048); fw[i][1] = pp_read128(wa[1] + ow + i * 2048); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fx[i][0] = pp_read128(xa[0] + ox + i * 2048); fx[i][1] = pp_read128(xa[1] + ox + i * 2048); }
+        }
+        G2_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[0][mb][nb] = mfma16v<F16>(fw[nb][ks], fx[mb][ks], acc[0][mb][nb]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B(t)
+        if (t < nk - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nk) {
+            issue_x(1, t + 1, nxt(sl, 0));                                 // item 3t+5 -> slot of W(t)
+            if (t + 2 < nk) issue_w(t + 2, nxt(sl, 1));                    // item 3t+6 -> slot of X0(t)
+        }
+        {
+            const unsigned ox = (unsigned)s_x1 * PP_SLOT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fx[i][0] = pp_read128(xa[0] + ox + i * 2048); fx[i][1] = pp_read128(xa[1] + ox + i * 2048); }
+        }
+        G2_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[1][mb][nb] = mfma16v<F16>(fw[nb][ks], fx[mb][ks], acc[1][mb][nb]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        sl = nxt(sl, 3);
+    }
+    // (the vmcnt at the tail depends on how many items were actually issued after the awaited one: see the counts above;
+    // with t + 2 >= nk the B phase issues one item, with t + 1 >= nk none)
+    __builtin_amdgcn_s_barrier();                // every wave is done reading the ring: it becomes the staging area
+    if constexpr (LN_IN) {
+        *reinterpret_cast<float2 *>(smem + PP_PAR_OFF + tid * 8) = make_float2(ln_rs, ln_nm);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: f32 -> (LayerNorm fold, bias, activation) -> half rows in LDS -> whole 256-byte rows to HBM
+    float4 colb[4], colc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int nl = wn * 64 + nb * 16 + fq * 4;
+        colb[nb] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LN_IN) colc[nb] = *reinterpret_cast<const float4 *>(g.ln_colsum + n0 + nl);
+    }
+    // this lane's 8 token rows: LayerNorm parameters to registers BEFORE the staging stores (the stores alias every LDS
+    // pointer for the compiler: read inside the loop, each parameter read would wait for the stores in front of it)
+    float prs[2][4], pnm[2][4];
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            prs[hm][mb] = 1.f; pnm[hm][mb] = 0.f;
+            if constexpr (LN_IN) {
+                const float2 pr = *reinterpret_cast<const float2 *>(smem + PP_PAR_OFF + (hm * 128 + wm * 64 + mb * 16 + fr) * 8);
+                prs[hm][mb] = pr.x; pnm[hm][mb] = pr.y;
+            }
+        }
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int ml = hm * 128 + wm * 64 + mb * 16 + fr;
+            const float rs = prs[hm][mb], nm = pnm[hm][mb];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int nl = wn * 64 + nb * 16 + fq * 4;
+                f32x4 vv = acc[hm][mb][nb];
+                const float4 b = colb[nb];
+                if constexpr (LN_IN) {
+                    const float4 cs = colc[nb];
+                    vv[0] = fmaf(vv[0], rs, fmaf(nm, cs.x, b.x)); vv[1] = fmaf(vv[1], rs, fmaf(nm, cs.y, b.y));
+                    vv[2] = fmaf(vv[2], rs, fmaf(nm, cs.z, b.z)); vv[3] = fmaf(vv[3], rs, fmaf(nm, cs.w, b.w));
+                } else {
+                    vv[0] += b.x; vv[1] += b.y; vv[2] += b.z; vv[3] += b.w;
+                }
+                if constexpr (EPI == CPX_EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
+                } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
+                }
+                uint2 o;
+                o.x = (unsigned)to_half<F16>(vv[0]) | ((unsigned)to_half<F16>(vv[1]) << 16);
+                o.y = (unsigned)to_half<F16>(vv[2]) | ((unsigned)to_half<F16>(vv[3]) << 16);
+                *reinterpret_cast<uint2 *>(smem + ml * PP_EPI_LD + nl * 2) = o;
+            }
+        }
+    __syncthreads();
+    const int c16 = tid & 15;                    // 16-byte chunk of a 256-byte row
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int ml = it * 16 + (tid >> 4);
+        const uint4 vv = *reinterpret_cast<const uint4 *>(smem + ml * PP_EPI_LD + c16 * 16);
+        *reinterpret_cast<uint4 *>((unsigned short *)g.out + (size_t)(m0 + ml) * g.ld_out + n0 + c16 * 8) = vv;
+    }
+}
+
 CPX_SWITCH(g_gemm_persist, 1);      // 1 = persistent 256^2 kernel (k_gemm256p), 0 = one workgroup per tile (k_gemm256)
 CPX_SWITCH(g_gemm_variant, 1);      // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
 CPX_SWITCH(g_gemm_dbg, 0);          // timing-only ablations of the 256^2 epilogue
@@ -1028,6 +1257,7 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 // 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
+CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
 #ifdef CPX_DEBUG
 extern "C" void cpx_gemm_set_persistent(int on) { g_gemm_persist = on; }
 extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
@@ -1036,6 +1266,17 @@ extern "C" void cpx_gemm_set_persistent_qkv(int on) { g_gemm_persist_qkv = on; }
 extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
+extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
+#endif
+
+#ifdef CPX_DEBUG
+// workgroups of the ping-pong kernel the runtime admits per CU (2 is the design point: 2 x 80 KB of LDS = all 160 KB)
+extern "C" int cpx_gemm_pingpong_occupancy(void) {
+    int n = -1;
+    (void)hipFuncSetAttribute((const void *)k_gemm_pp<CPX_EPI_GELU_BF16, false, G2F_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_gemm_pp<CPX_EPI_GELU_BF16, false, G2F_LN>, PP_THREADS, PP_LDS_BYTES) != hipSuccess) return -1;
+    return n;
+}
 #endif
 
 template <int EPI, bool F16, int FLAGS>
@@ -1077,6 +1318,20 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
     else {
         if (!g_gemm_big || a0.M % 256 || a0.N % 256 || (a0.K / 64) % 2 || a0.K < 128) return false;
         if ((a0.M / 256) * (a0.N / 256) < 256) return false;          // not enough tiles for 256 CUs
+        if constexpr (EPI == CPX_EPI_BF16 || EPI == CPX_EPI_GELU_BF16 || EPI == CPX_EPI_RELU_BF16) {
+            if (g_gemm_pp) {
+                GemmArgs p = a0;
+                p.tiles_n = p.N / 128; p.n_blocks = (p.M / 256) * (p.N / 128);
+                static CpxOncePerDevice once_pp;
+                once_pp([] {
+                    (void)hipFuncSetAttribute((const void *)k_gemm_pp<EPI, F16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+                    (void)hipFuncSetAttribute((const void *)k_gemm_pp<EPI, F16, G2F_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+                });
+                if (p.ln_stats) hipLaunchKernelGGL((k_gemm_pp<EPI, F16, G2F_LN>), dim3(p.n_blocks), dim3(PP_THREADS), PP_LDS_BYTES, s, p);
+                else hipLaunchKernelGGL((k_gemm_pp<EPI, F16, 0>), dim3(p.n_blocks), dim3(PP_THREADS), PP_LDS_BYTES, s, p);
+                return true;
+            }
+        }
         GemmArgs a = a0;
         a.tiles_n = a.N / 256; a.n_blocks = (a.M / 256) * (a.N / 256);
         // one instantiation per (LayerNorm consumer | statistics producer) x (timing ablations, bf16 only)

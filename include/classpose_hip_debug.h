@@ -17,6 +17,8 @@ void cpx_gemm_set_big(int on);              /* 1 (default): 256^2 kernel when th
 void cpx_gemm_set_persistent(int on);       /* 1 (default): persistent 256^2 kernel with next-tile prefetch under the epilogue */
 void cpx_gemm_set_persistent_qkv(int on);   /* qkv projection on the persistent kernel with a balanced q|k / V^T tile list */
 void cpx_gemm_set_l2_block(int on);         /* 1 (default): 8 x 4 super-tile order per XCD, N-sweep; 2: M-sweep; 0: row-major */
+void cpx_gemm_set_pingpong(int on);         /* 0 (default): 1 = 256 x 128 "ping-pong" kernel, two 4-wave workgroups per CU (bias / GELU / ReLU epilogues) */
+int cpx_gemm_pingpong_occupancy(void);      /* workgroups of the ping-pong kernel admitted per CU (design point: 2) */
 void cpx_gemm_set_reverse(int on);          /* 0 (default): mlp.lin2 walks M backwards when 1            */
 void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */
 void cpx_attention_set_xcd_order(int on);   /* 1 (default): (sub-tile, head) pairs pinned to one XCD     */

@@ -1,0 +1,63 @@
+"""A/B of the "ping-pong" GEMM (k_gemm_pp: 256 x 128 tiles, two 4-wave workgroups per CU, epilogue of one beside the main
+loop of the other) against the persistent 256^2 kernel on the shapes / epilogues it covers: interleaved rounds in one
+process + bitwise comparison (same fp32 accumulation order per element -> must be identical)."""
+import os as _os
+_os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from classpose_amd import _lib, ops
+dev = torch.device("cuda:0"); L = _lib.lib()
+g = torch.Generator().manual_seed(0)
+shapes = [("fc1", 32768, 4096, 1024, "gelu", True), ("fc1-noLN", 32768, 4096, 1024, "gelu", False), ("qkv-like", 32768, 3072, 1024, "bf16", True),
+          ("relu", 16384, 1024, 2048, "relu", False), ("fc1 96 sub-tiles", 98304, 4096, 1024, "gelu", True)]
+if len(sys.argv) > 1:
+    shapes = shapes[: int(sys.argv[1])]
+st = torch.cuda.current_stream().cuda_stream
+print("ping-pong kernel: workgroups admitted per CU =", L.cpx_gemm_pingpong_occupancy(), flush=True)
+for name, M, N, K, epi, ln in shapes:
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    stats = ops.row_stats(A) if ln else None
+    cs = W.float().sum(1).contiguous() if ln else None
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    def run():
+        _lib.check(L.cpx_gemm_ln(A.data_ptr(), W.data_ptr(), M, N, K, ops.EPI[epi], b.data_ptr(), None,
+                                 out.data_ptr(), N, stats.data_ptr() if ln else None, cs.data_ptr() if ln else None, None, st))
+    outs, t = {}, {0: [], 1: []}
+    for p in (1, 0):
+        L.cpx_gemm_set_pingpong(p)
+        out.zero_()
+        run(); torch.cuda.synchronize()
+        outs[p] = out.clone()
+    same = torch.equal(outs[0], outs[1])
+    if not same:
+        d = (outs[0].float() - outs[1].float()).abs()
+        print(f"   MISMATCH: {int((d > 0).sum())} elements differ, max {float(d.max())}, first at {torch.nonzero(d > 0)[0].tolist()}")
+    # race screen: repeated launches bitwise identical under a concurrent memory stream
+    L.cpx_gemm_set_pingpong(1)
+    noise = torch.empty((8192, 8192), device=dev); side = torch.cuda.Stream(dev)
+    stable = True
+    for i in range(12):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                noise.normal_()
+        out.zero_(); run(); torch.cuda.synchronize()
+        stable &= torch.equal(out, outs[1])
+    side.synchronize()
+    for rnd in range(6):
+        for p in (1, 0):
+            L.cpx_gemm_set_pingpong(p)
+            for _ in range(3): run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): run()
+            e1.record(); torch.cuda.synchronize()
+            t[p].append(e0.elapsed_time(e1) / 20 * 1e3)
+    fl = 2.0 * M * N * K
+    for p in (1, 0):
+        m = float(np.median(t[p]))
+        print(f"{name:18s} M={M:6d} N={N:5d} K={K:5d} {'ping-pong 256x128' if p else 'persistent 256^2 '}: median {m:7.1f} us  min {min(t[p]):7.1f}  "
+              f"{fl / m / 1e6:7.1f} TFLOP/s   bitwise equal: {same}   repeatable: {stable}", flush=True)
+L.cpx_gemm_set_pingpong(0)
