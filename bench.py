@@ -94,6 +94,24 @@ def physical_core_cpus() -> list[int]:
     return out or allowed
 
 
+def cgroup_cpu_limit() -> float | None:
+    """CPU time this process tree may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     """Reference-shaped CPU path (the oracle, kind 'port'; oracle/cpu_baseline.py) on ALL physical host cores:
     P child processes x 32 torch threads over disjoint tiles of the same workload (one torch-CPU process stops scaling
@@ -102,8 +120,13 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     import subprocess
     cpus = physical_core_cpus()
     phys = len(cpus)
-    threads = min(32, phys)
-    P = max(1, phys // threads)
+    quota = cgroup_cpu_limit()
+    # what the host lets this job use: the physical cores of its affinity mask, capped by the cgroup's CPU-time quota
+    # (threads beyond the quota only get throttled: 4 x 32 threads on the GPU box ran 5x slower EACH than 1 x 32)
+    usable = phys if quota is None else max(1, min(phys, int(quota)))
+    threads = min(32, usable)
+    P = max(1, usable // threads)
+    cpus = cpus[:P * threads]
     per = -(-n_tiles // P)
     warm = max(1, -(-warm_total // P))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
@@ -128,7 +151,7 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     span = max(r["t_end"] for r in res) - min(r["t_start"] for r in res)
     stage = {k: round(sum(r["stage_s"][k] for r in res) / tiles * 1e3, 2) for k in res[0]["stage_s"]}
     return dict(value=rate, unit="tiles/s", cores=len(res) * threads, kind="port", cells_per_s=cells / tiles * rate,
-                processes=len(res), threads_per_process=threads, physical_cores=phys, stage_ms_per_tile=stage,
+                processes=len(res), threads_per_process=threads, physical_cores=phys, cgroup_cpu_quota=quota, stage_ms_per_tile=stage,
                 sample=f"{tiles} tiles of the same workload ({len(res)} processes x {threads} torch threads, each pinned to its own {threads} physical cores, on disjoint tiles, "
                        f"{warm} warm-up tile(s) each = {warm * len(res)} in all), one tile per eval (4 sub-tiles, fp32 torch-CPU "
                        f"ViT-L + oracle dynamics on the injected fields); all windows within {span:.1f} s; the literal "

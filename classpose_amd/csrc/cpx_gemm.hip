@@ -52,6 +52,7 @@ struct GemmArgs {
     // implicit 3x3 convolution (128^2 kernel, CONV instantiation): A is the [S*1024][conv_c] token-major activation of
     // 32 x 32-token images, K = 9 * conv_c with k = tap * conv_c + c (tap = 3 (dy + 1) + (dx + 1)); 0 = plain GEMM
     int conv_c;
+    int pp_delay;           // ping-pong kernel: x ~8k cycles the second workgroup of a CU waits at launch (0 = no offset)
 };
 #define LN_SLOTS 4
 __device__ __forceinline__ void ln_row_params(const float *st, int m, float inv_k, float &mean, float &rstd) {
@@ -1047,6 +1048,9 @@ __device__ __forceinline__ u32x4 pp_read128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// Which of a CU's two resident workgroups arrived second?  (arrival counters per CU, monotonically increasing: two
+// consecutive arrivals on a CU always get different parities, so no reset is needed and nothing depends on it but timing)
+__device__ unsigned g_pp_arrival[8 * 256];
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
     constexpr bool LN_IN = (FLAGS & G2F_LN) != 0;
@@ -1056,13 +1060,31 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int K = g.K, nk = K / 64;
+    // ---- phase offset between the two workgroups of a CU: identical tiles take identical time, so two workgroups that
+    // start together stay in lockstep (both in the main loop, then both in the epilogue) and never complement each other.
+    // The second arrival on a CU therefore waits g.pp_delay x ~8k cycles once; from then on one workgroup's epilogue runs
+    // beside the other's main loop for the whole launch.
+    if (g.pp_delay > 0) {
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);      // HW_REG_HW_ID bits 15:8 = SE, SH, CU
+            const unsigned xcc = __builtin_amdgcn_s_getreg((2 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID bits 2:0
+            *reinterpret_cast<unsigned *>(smem) = atomicAdd(&g_pp_arrival[((xcc & 7) << 8) | (hw & 255)], 1u);
+        }
+        __syncthreads();
+        const unsigned arrival = *reinterpret_cast<volatile unsigned *>(smem);
+        __syncthreads();
+        if (arrival & 1)
+            for (int i = 0; i < g.pp_delay; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    const int tiles_m = g.n_blocks / g.tiles_n;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  for (int v = blockIdx.x; v < g.n_blocks; v += gridDim.x) {
     // workgroup -> tile: ids that share an XCD (id % 8) get a contiguous range; the 64 workgroups an XCD runs at a time
     // (2 per CU) cover an 8 (M) x 8 (N) super-tile = 8 activation panels + 8 weight panels
     int tile_m, tile_n;
     {
-        const int nxcd = 8, q = g.n_blocks / nxcd, r = g.n_blocks % nxcd, x = blockIdx.x % nxcd;
-        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / nxcd;
-        const int tiles_m = g.n_blocks / g.tiles_n;
+        const int nxcd = 8, q = g.n_blocks / nxcd, r = g.n_blocks % nxcd, x = v % nxcd;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / nxcd;
         if ((tiles_m & 7) == 0 && (g.tiles_n & 7) == 0) {
             const int grp = bid >> 6, w_ = bid & 63, cgn = g.tiles_n >> 3;
             const int rg = grp / cgn, cg = grp - rg * cgn;
@@ -1103,7 +1125,6 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
     auto issue_w = [&](int t, int slot) { issue(pW + (size_t)t * 64, slot); };
     auto issue_x = [&](int hm, int t, int slot) { issue(pX + hm * k128 + (size_t)t * 64, slot); };
 
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     unsigned xa[2], wa[2];                       // per-lane fragment bases (slot offset added per phase)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1245,6 +1266,8 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
         const uint4 vv = *reinterpret_cast<const uint4 *>(smem + ml * PP_EPI_LD + c16 * 16);
         *reinterpret_cast<uint4 *>((unsigned short *)g.out + (size_t)(m0 + ml) * g.ld_out + n0 + c16 * 8) = vv;
     }
+    __syncthreads();                             // staging rows read: the ring may be re-filled for the next tile
+  }
 }
 
 CPX_SWITCH(g_gemm_persist, 1);      // 1 = persistent 256^2 kernel (k_gemm256p), 0 = one workgroup per tile (k_gemm256)
@@ -1258,6 +1281,8 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
 CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
+CPX_SWITCH(g_gemm_pp_persist, 1);   // ping-pong kernel: 1 = two persistent workgroups per CU walk the tiles, 0 = one workgroup per tile
+CPX_SWITCH(g_gemm_pp_delay, 2);     // ping-pong kernel: start offset of a CU's second workgroup, x s_sleep 127 (~8k cycles)
 #ifdef CPX_DEBUG
 extern "C" void cpx_gemm_set_persistent(int on) { g_gemm_persist = on; }
 extern "C" void cpx_gemm_set_variant(int glds) { g_gemm_variant = glds; }
@@ -1267,6 +1292,7 @@ extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
+extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
 
 #ifdef CPX_DEBUG
@@ -1327,8 +1353,17 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                     (void)hipFuncSetAttribute((const void *)k_gemm_pp<EPI, F16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
                     (void)hipFuncSetAttribute((const void *)k_gemm_pp<EPI, F16, G2F_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
                 });
-                if (p.ln_stats) hipLaunchKernelGGL((k_gemm_pp<EPI, F16, G2F_LN>), dim3(p.n_blocks), dim3(PP_THREADS), PP_LDS_BYTES, s, p);
-                else hipLaunchKernelGGL((k_gemm_pp<EPI, F16, 0>), dim3(p.n_blocks), dim3(PP_THREADS), PP_LDS_BYTES, s, p);
+                static int n_cu_pp = 0;
+                if (!n_cu_pp) {
+                    int dev = 0, cus = 256;
+                    (void)hipGetDevice(&dev);
+                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                    n_cu_pp = cus > 0 ? cus : 256;
+                }
+                const int grid = g_gemm_pp_persist ? (p.n_blocks < 2 * n_cu_pp ? p.n_blocks : 2 * n_cu_pp) : p.n_blocks;
+                p.pp_delay = g_gemm_pp_delay;
+                if (p.ln_stats) hipLaunchKernelGGL((k_gemm_pp<EPI, F16, G2F_LN>), dim3(grid), dim3(PP_THREADS), PP_LDS_BYTES, s, p);
+                else hipLaunchKernelGGL((k_gemm_pp<EPI, F16, 0>), dim3(grid), dim3(PP_THREADS), PP_LDS_BYTES, s, p);
                 return true;
             }
         }
@@ -1424,7 +1459,7 @@ int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K,
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
     a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg;
     a.rev_m = (g_gemm_rev && K >= 4096) ? 1 : 0;
-    a.conv_c = 0;
+    a.conv_c = 0; a.pp_delay = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s, f16); break;
@@ -1454,7 +1489,7 @@ int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C
     a.M = M; a.N = N; a.K = 9 * C; a.bias = bias; a.aux = nullptr; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
     a.ln_stats = nullptr; a.ln_colsum = nullptr; a.stats_out = nullptr; a.l2_block = 0; a.dbg = 0; a.rev_m = 0;
-    a.conv_c = C;
+    a.conv_c = C; a.pp_delay = 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(a.n_blocks), block(GEMM_THREADS);
     const size_t lds = 2 * STAGE_BYTES;

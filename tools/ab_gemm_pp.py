@@ -56,6 +56,21 @@ for name, M, N, K, epi, ln in shapes:
             e1.record(); torch.cuda.synchronize()
             t[p].append(e0.elapsed_time(e1) / 20 * 1e3)
     fl = 2.0 * M * N * K
+    if name == "fc1":       # sweep of the ping-pong options on the dominant shape: (persistent grid, start offset of the 2nd workgroup)
+        for opts in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4)):
+            L.cpx_gemm_set_pingpong(1); L.cpx_gemm_set_pingpong_opts(*opts)
+            out.zero_(); run(); torch.cuda.synchronize()
+            ok = torch.equal(out, outs[0])
+            ts = []
+            for rnd in range(4):
+                for _ in range(3): run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20): run()
+                e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+            print(f"   options persistent={opts[0]} delay={opts[1]}: median {float(np.median(ts)):7.1f} us  min {min(ts):7.1f}   bitwise equal: {ok}", flush=True)
+        L.cpx_gemm_set_pingpong_opts(1, 2)
     for p in (1, 0):
         m = float(np.median(t[p]))
         print(f"{name:18s} M={M:6d} N={N:5d} K={K:5d} {'ping-pong 256x128' if p else 'persistent 256^2 '}: median {m:7.1f} us  min {min(t[p]):7.1f}  "
