@@ -88,14 +88,31 @@ __device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c)
                                                        *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
 }
 
-// exact-erf GELU (nn.GELU default).  erfc by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
-// (below half-precision output rounding by > 3 orders of magnitude); one v_exp + one v_rcp
-// instead of libm erff's ~40-instruction piecewise polynomial in the epilogue.
-//   q = 0.5 erfc(|x| / sqrt2) = 0.5 poly(t) t exp(-x^2 / 2),  t = 1 / (1 + (p / sqrt2) |x|)   (0.5 folded into poly)
-//   gelu(x) = x Phi(x) = max(x, 0) - |x| q      (Phi = 1 - q for x >= 0, q for x < 0: no cancellation in the tail)
-// 11 VALU + 2 transcendental slots per element; the epilogue of mlp.lin1 is VALU-bound, every slot is 0.5 us per tile.
+// erf-GELU (nn.GELU default) in 7 VALU + 1 transcendental slots per element:
+//   gelu(x) = x Phi(x) = max(x, 0) - |x| q(|x|),   q(a) = 0.5 erfc(a / sqrt 2) = 2 ^ P(a)
+// (Phi = 1 - q for x >= 0, q for x < 0: no cancellation in the negative tail).  P is a degree-5 polynomial fitted to
+// log2 q with the weight a q(a), i.e. for the absolute error of the product |x| q, the only place q enters
+// (tools/fit_gelu.py: fit, float32 evaluation against float64 erfc on 4.8 M points of [-14, 14] and far beyond: max |error|
+// 6.4e-7 -- 1.3 ulp of the result at x = 4 -- against 4.8e-7 for the Abramowitz-Stegun 7.1.26 form it replaces, which needed a
+// v_rcp and five more multiply-adds; both are > 3 orders of magnitude below half-precision output rounding).  The leading
+// coefficient is negative, so beyond the fitted interval P -> -inf and q -> 0 without a clamp (|x| q < 1.1e-9 there).
+// The epilogue of mlp.lin1 is VALU-bound: every slot per element is ~0.5 us per 256^2 tile.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float ax = fabsf(x);                                                  // free source modifier
+    float p = -4.732933965e-04f;
+    p = __fmaf_rn(p, ax, 7.084452800e-03f);
+    p = __fmaf_rn(p, ax, -5.182713611e-02f);
+    p = __fmaf_rn(p, ax, -4.599926953e-01f);
+    p = __fmaf_rn(p, ax, -1.150787739e+00f);
+    p = __fmaf_rn(p, ax, -1.000037638e+00f);
+    const float q = __builtin_amdgcn_exp2f(p);
+    return __fmaf_rn(-ax, q, fmaxf(x, 0.0f));
+}
+
+// the form used until round 2 (A/B reference, g.dbg & 16 in the DBG instantiation): erfc by Abramowitz-Stegun 7.1.26,
+// q = 0.5 poly(t) t exp(-x^2 / 2), t = 1 / (1 + (p / sqrt2) |x|): 11 VALU + 2 transcendental slots
+__device__ __forceinline__ float gelu_erf_as26(float x) {
+    const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.23164189f, ax, 1.0f));   // 0.3275911 / sqrt(2); v_rcp_f32 (1 ulp)
     float poly = 0.5f * 1.061405429f;
     poly = __fmaf_rn(poly, t, 0.5f * -1.453152027f);
@@ -103,18 +120,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
     poly = __fmaf_rn(poly, t, 0.5f * -0.284496736f);
     poly = __fmaf_rn(poly, t, 0.5f * 0.254829592f);
     const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2/2)
-    const float q = (poly * t) * ex;
-    return __fmaf_rn(-ax, q, fmaxf(x, 0.0f));
-}
-
-// experiment (timing A/B only, g.dbg & 16 in the DBG instantiation): Abramowitz-Stegun 7.1.25, three terms, |erf error| <= 2.5e-5
-__device__ __forceinline__ float gelu_erf_as25(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.33267251f, ax, 1.0f));   // 0.47047 / sqrt(2)
-    float poly = 0.5f * 0.7478556f;
-    poly = __fmaf_rn(poly, t, 0.5f * -0.0958798f);
-    poly = __fmaf_rn(poly, t, 0.5f * 0.3480242f);
-    const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
     const float q = (poly * t) * ex;
     return __fmaf_rn(-ax, q, fmaxf(x, 0.0f));
 }
@@ -961,7 +966,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                             if constexpr (EPI == CPX_EPI_GELU_BF16) {
                                 if (DBG && (g.dbg & 16)) {
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) vv[r] = gelu_erf_as25(vv[r]);
+                                    for (int r = 0; r < 4; ++r) vv[r] = gelu_erf_as26(vv[r]);
                                 } else if (!DBG || !(g.dbg & 2)) {
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
@@ -1051,6 +1056,21 @@ __device__ __forceinline__ u32x4 pp_read128(unsigned addr) {
 // Which of a CU's two resident workgroups arrived second?  (arrival counters per CU, monotonically increasing: two
 // consecutive arrivals on a CU always get different parities, so no reset is needed and nothing depends on it but timing)
 __device__ unsigned g_pp_arrival[8 * 256];
+#ifdef CPX_DEBUG
+// diagnostic (g.dbg & 32): s_memtime at tile start / main-loop end / tile end of every workgroup's tiles + its CU key and
+// arrival number: [workgroup < 1024][2 + 3 * 32] 64-bit words, fetched by cpx_gemm_pingpong_stamps
+__device__ unsigned long long g_pp_stamps[1024 * 98];
+#define PP_STAMP(slot_)                                                                                   \
+    do {                                                                                                  \
+        if ((g.dbg & 32) && tid == 0 && blockIdx.x < 1024 && it_ < 32) {                                  \
+            unsigned long long t_;                                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            g_pp_stamps[blockIdx.x * 98 + 2 + 3 * it_ + (slot_)] = t_;                                    \
+        }                                                                                                 \
+    } while (0)
+#else
+#define PP_STAMP(slot_) do { } while (0)
+#endif
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
     constexpr bool LN_IN = (FLAGS & G2F_LN) != 0;
@@ -1064,7 +1084,7 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
     // start together stay in lockstep (both in the main loop, then both in the epilogue) and never complement each other.
     // The second arrival on a CU therefore waits g.pp_delay x ~8k cycles once; from then on one workgroup's epilogue runs
     // beside the other's main loop for the whole launch.
-    if (g.pp_delay > 0) {
+    if (g.pp_delay > 0 || (g.dbg & 32)) {
         if (tid == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);      // HW_REG_HW_ID bits 15:8 = SE, SH, CU
             const unsigned xcc = __builtin_amdgcn_s_getreg((2 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID bits 2:0
@@ -1073,12 +1093,21 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
         __syncthreads();
         const unsigned arrival = *reinterpret_cast<volatile unsigned *>(smem);
         __syncthreads();
+#ifdef CPX_DEBUG
+        if ((g.dbg & 32) && tid == 0 && blockIdx.x < 1024) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((2 << 11) | (0 << 6) | 20);
+            g_pp_stamps[blockIdx.x * 98] = ((xcc & 7) << 8) | (hw & 255);
+            g_pp_stamps[blockIdx.x * 98 + 1] = arrival;
+        }
+#endif
         if (arrival & 1)
             for (int i = 0; i < g.pp_delay; ++i) __builtin_amdgcn_s_sleep(127);
     }
     const int tiles_m = g.n_blocks / g.tiles_n;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-  for (int v = blockIdx.x; v < g.n_blocks; v += gridDim.x) {
+  int it_ = 0;
+  for (int v = blockIdx.x; v < g.n_blocks; v += gridDim.x, ++it_) {
+    PP_STAMP(0);
     // workgroup -> tile: ids that share an XCD (id % 8) get a contiguous range; the 64 workgroups an XCD runs at a time
     // (2 per CU) cover an 8 (M) x 8 (N) super-tile = 8 activation panels + 8 weight panels
     int tile_m, tile_n;
@@ -1200,6 +1229,7 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
     // (the vmcnt at the tail depends on how many items were actually issued after the awaited one: see the counts above;
     // with t + 2 >= nk the B phase issues one item, with t + 1 >= nk none)
     __builtin_amdgcn_s_barrier();                // every wave is done reading the ring: it becomes the staging area
+    PP_STAMP(1);
     if constexpr (LN_IN) {
         *reinterpret_cast<float2 *>(smem + PP_PAR_OFF + tid * 8) = make_float2(ln_rs, ln_nm);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1267,6 +1297,7 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
         *reinterpret_cast<uint4 *>((unsigned short *)g.out + (size_t)(m0 + ml) * g.ld_out + n0 + c16 * 8) = vv;
     }
     __syncthreads();                             // staging rows read: the ring may be re-filled for the next tile
+    PP_STAMP(2);
   }
 }
 
@@ -1297,6 +1328,10 @@ extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_p
 
 #ifdef CPX_DEBUG
 // workgroups of the ping-pong kernel the runtime admits per CU (2 is the design point: 2 x 80 KB of LDS = all 160 KB)
+extern "C" int cpx_gemm_pingpong_stamps(unsigned long long *host_out, size_t n_words) {
+    if (n_words > 1024 * 98) n_words = 1024 * 98;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_stamps), n_words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 extern "C" int cpx_gemm_pingpong_occupancy(void) {
     int n = -1;
     (void)hipFuncSetAttribute((const void *)k_gemm_pp<CPX_EPI_GELU_BF16, false, G2F_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);

@@ -19,6 +19,7 @@ void cpx_gemm_set_persistent_qkv(int on);   /* qkv projection on the persistent 
 void cpx_gemm_set_l2_block(int on);         /* 1 (default): 8 x 4 super-tile order per XCD, N-sweep; 2: M-sweep; 0: row-major */
 void cpx_gemm_set_pingpong(int on);         /* 0 (default): 1 = 256 x 128 "ping-pong" kernel, two 4-wave workgroups per CU (bias / GELU / ReLU epilogues) */
 void cpx_gemm_set_pingpong_opts(int persistent, int delay);   /* (1, 2) default: persistent grid; start offset of a CU's 2nd workgroup x ~8k cycles */
+int cpx_gemm_pingpong_stamps(unsigned long long *host_out, size_t n_words);   /* cycle stamps written under cpx_gemm_set_dbg(32) */
 int cpx_gemm_pingpong_occupancy(void);      /* workgroups of the ping-pong kernel admitted per CU (design point: 2) */
 void cpx_gemm_set_reverse(int on);          /* 0 (default): mlp.lin2 walks M backwards when 1            */
 void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */

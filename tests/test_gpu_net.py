@@ -52,6 +52,28 @@ def _gemm_epilogues(L, cuda, variant, M, N, K):
         L.cpx_gemm_set_variant(1)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (32768, 4096, 128)])
+def test_gelu_epilogue_is_erf_gelu_at_half_precision(cuda, M, N, K):
+    """The epilogue's GELU (2 ^ P5(|x|) form of x Phi(x), csrc/cpx_gemm.hip: gelu_erf) against float64 erf-GELU of the
+    SAME float32 pre-activation (the f32 epilogue of the same GEMM): after rounding to bf16 the two agree except where the
+    exact value sits within ~1e-6 of a rounding boundary -- at most 1 bf16 ulp apart, in < 0.1 % of the elements, with
+    the negative tail and large arguments included (bias spread over [-9, 9])."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = torch.linspace(-9, 9, N).to(cuda)
+    z = ops.gemm(A, W, "f32", bias)                                     # exact products, fp32 accumulation, + bias
+    got = ops.gemm(A, W, "gelu", bias)
+    z64 = z.double()
+    want = (0.5 * z64 * torch.special.erfc(-z64 / 2 ** 0.5)).to(torch.bfloat16)
+    diff = got.view(torch.int16).int() - want.view(torch.int16).int()
+    assert int(diff.abs().max()) <= 1, int(diff.abs().max())              # never more than one bf16 ulp
+    frac = float((diff != 0).float().mean())
+    assert frac < 1e-3, frac
+    assert float((got.double() - 0.5 * z64 * torch.special.erfc(-z64 / 2 ** 0.5)).abs().max()) < 0.04       # |z| up to ~14: bf16 ulp there
+    assert torch.isfinite(got).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 1024), (16384, 1024, 128), (16384, 1024, 256),
                                    (4096, 4096, 4096), (32768, 512, 192 * 2)])
 def test_gemm256_epilogues(cuda, M, N, K):

@@ -1,5 +1,6 @@
-"""mlp.lin1 (persistent 256^2 GEMM, folded LayerNorm + GELU) with the production erf (A-S 7.1.26, 5 terms) against a
-3-term variant (7.1.25) and against no GELU at all: timing only, all three in the DBG instantiation, interleaved."""
+"""mlp.lin1 (persistent 256^2 GEMM, folded LayerNorm + GELU) with the production GELU (2 ^ P5(|x|) form, 7 VALU + 1
+transcendental slots, tools/fit_gelu.py) against the Abramowitz-Stegun 7.1.26 form used until round 2 (11 + 2 slots) and
+against no GELU at all: timing only, all three in the DBG instantiation, interleaved."""
 import os as _os
 _os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")      # the A/B switches live in the -DCPX_DEBUG library (libclasspose_hip_debug.so)
 import sys, os
@@ -18,7 +19,7 @@ st = torch.cuda.current_stream().cuda_stream
 def run():
     _lib.check(L.cpx_gemm_ln(A.data_ptr(), W.data_ptr(), M, N, K, ops.EPI["gelu"], b.data_ptr(), None, out.data_ptr(), N,
                              stats.data_ptr(), cs.data_ptr(), None, st))
-variants = {"erf 5 terms (production)": 32, "erf 3 terms": 32 | 16, "no GELU": 32 | 2}
+variants = {"2^P5 form (production)": 32, "A-S 7.1.26 (round 2)": 32 | 16, "no GELU": 32 | 2}
 t = {k: [] for k in variants}
 for rnd in range(6):
     for k, d in variants.items():
