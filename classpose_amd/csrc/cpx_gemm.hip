@@ -1024,8 +1024,19 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
     }
 }
 
+#ifdef CPX_DEBUG
 // ===========================================================================
-// "ping-pong" form: 256 (M) x 128 (N) x 64 tile, 256 threads = 4 waves, TWO workgroups per CU
+// EXPERIMENT (debug build only, cpx_gemm_set_pingpong): "ping-pong" form, 256 (M) x 128 (N) x 64 tile, 256 threads = 4 waves,
+// TWO workgroups per CU.  Bitwise identical to the 256^2 kernel, race-screened, and 5-8 % SLOWER on every layer shape
+// (profiles/r03_gemm_pingpong_ab.txt) -- kept as the measured record of why:
+//   * the two workgroups of a CU do fall into complementary phases by themselves (89 % of every epilogue runs beside the
+//     partner's main loop, tools/pp_stamps.py), a forced start offset changes nothing;
+//   * but a wave's OWN timeline is the limit: per K tile 64 MFMAs (1 088 cycles) + 12 LDS-DMA instructions at ~60-100 issue
+//     cycles each + two LDS round trips + two barriers = ~2 700 cycles, so the main loop of a 256 x 128 tile takes 43 k cycles
+//     where the MFMAs alone need 17 k: half the tile size means 1.5x the operand bytes -- and DMA instructions -- per MFMA
+//     (0.19 against 0.125 KB), and ~35 B/clk/CU is at the rate one CU can pull from its L2 (~70 GB/s);
+//   * beside another wave's saturating MFMA stream a wave issues one VALU instruction per ~8.5 cycles, not one per 3.3
+//     (tools/micro/coexec.hip), so an overlapped epilogue is also a slower epilogue.
 // ===========================================================================
 // The 256^2 kernel holds a CU with one 8-wave workgroup: while its waves run the VALU-bound epilogue (LayerNorm
 // fold, bias, erf-GELU, conversion, staging, stores: ~40 % of a mlp.lin1 tile) the CU's matrix cores idle, and while
@@ -1301,6 +1312,8 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
   }
 }
 
+#endif  // CPX_DEBUG (ping-pong experiment)
+
 CPX_SWITCH(g_gemm_persist, 1);      // 1 = persistent 256^2 kernel (k_gemm256p), 0 = one workgroup per tile (k_gemm256)
 CPX_SWITCH(g_gemm_variant, 1);      // 1 = LDS-DMA staging, 0 = register staging (debug / A-B)
 CPX_SWITCH(g_gemm_dbg, 0);          // timing-only ablations of the 256^2 epilogue
@@ -1379,6 +1392,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
     else {
         if (!g_gemm_big || a0.M % 256 || a0.N % 256 || (a0.K / 64) % 2 || a0.K < 128) return false;
         if ((a0.M / 256) * (a0.N / 256) < 256) return false;          // not enough tiles for 256 CUs
+#ifdef CPX_DEBUG
         if constexpr (EPI == CPX_EPI_BF16 || EPI == CPX_EPI_GELU_BF16 || EPI == CPX_EPI_RELU_BF16) {
             if (g_gemm_pp) {
                 GemmArgs p = a0;
@@ -1402,6 +1416,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                 return true;
             }
         }
+#endif
         GemmArgs a = a0;
         a.tiles_n = a.N / 256; a.n_blocks = (a.M / 256) * (a.N / 256);
         // one instantiation per (LayerNorm consumer | statistics producer) x (timing ablations, bf16 only)

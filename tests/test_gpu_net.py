@@ -56,8 +56,8 @@ def _gemm_epilogues(L, cuda, variant, M, N, K):
 def test_gelu_epilogue_is_erf_gelu_at_half_precision(cuda, M, N, K):
     """The epilogue's GELU (2 ^ P5(|x|) form of x Phi(x), csrc/cpx_gemm.hip: gelu_erf) against float64 erf-GELU of the
     SAME float32 pre-activation (the f32 epilogue of the same GEMM): after rounding to bf16 the two agree except where the
-    exact value sits within ~1e-6 of a rounding boundary -- at most 1 bf16 ulp apart, in < 0.1 % of the elements, with
-    the negative tail and large arguments included (bias spread over [-9, 9])."""
+    exact value sits within ~1e-6 of a rounding boundary -- never more than 1 bf16 ulp (+ 1e-6 absolute) off, correctly
+    rounded in > 99.9 % of the elements, with the negative tail and large arguments included (bias spread over [-9, 9])."""
     g = torch.Generator(device="cpu").manual_seed(3)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
@@ -65,12 +65,16 @@ def test_gelu_epilogue_is_erf_gelu_at_half_precision(cuda, M, N, K):
     z = ops.gemm(A, W, "f32", bias)                                     # exact products, fp32 accumulation, + bias
     got = ops.gemm(A, W, "gelu", bias)
     z64 = z.double()
-    want = (0.5 * z64 * torch.special.erfc(-z64 / 2 ** 0.5)).to(torch.bfloat16)
-    diff = got.view(torch.int16).int() - want.view(torch.int16).int()
-    assert int(diff.abs().max()) <= 1, int(diff.abs().max())              # never more than one bf16 ulp
-    frac = float((diff != 0).float().mean())
+    exact = 0.5 * z64 * torch.special.erfc(-z64 / 2 ** 0.5)
+    err = (got.double() - exact).abs()
+    # bf16: 8 significant bits -> ulp(v) = 2^(floor(log2 |v|) - 7).  Never more than one ulp off (+ the approximation's own
+    # absolute floor, 6.4e-7, tools/fit_gelu.py: in the far negative tail the exact value is ~1e-18 and only the absolute
+    # error means anything) ...
+    ulp = 2.0 ** (torch.floor(torch.log2(exact.abs().clamp_min(1e-30))) - 7)
+    assert bool((err <= ulp + 1e-6).all()), float((err - ulp).max())
+    # ... and almost everywhere it IS the correctly rounded value (half an ulp)
+    frac = float((err > 0.5 * ulp * 1.0001 + 1e-6).double().mean())
     assert frac < 1e-3, frac
-    assert float((got.double() - 0.5 * z64 * torch.special.erfc(-z64 / 2 ** 0.5)).abs().max()) < 0.04       # |z| up to ~14: bf16 ulp there
     assert torch.isfinite(got).all()
 
 
