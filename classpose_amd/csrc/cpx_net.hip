@@ -693,13 +693,33 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-template <bool F16>
+// DBG (debug build only): s_memtime stamps per loop segment -> dbg [workgroup][4 waves][6]: 0 vmcnt wait + barrier,
+// 1 DMA requests + gh + K fragment reads + their wait + the 4 QK^T MFMAs of the NEXT tile (issue), 2 the softmax's vector
+// stream, 3 V fragment reads + wait + the 4 P.V MFMAs (issue), 4 prologue, 5 whole kernel.  The stamps pin the
+// instruction order at the segment borders (no QK^T / softmax interleave across them): a diagnostic of where an in-order
+// wave spends its time, not a timing of the production schedule.
+#define A4_STAMP(i)                                                                            \
+    do {                                                                                       \
+        if constexpr (DBG) {                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            seg[i] += (unsigned)(t_ - tprev);                                                  \
+            tprev = t_;                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    } while (0)
+template <bool F16, bool DBG = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
                                                                 const unsigned short *__restrict__ relh,
                                                                 const unsigned short *__restrict__ relw,
-                                                                unsigned short *__restrict__ out, int xcd_order) {
+                                                                unsigned short *__restrict__ out, int xcd_order,
+                                                                unsigned *__restrict__ dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char a4_smem[];
+    unsigned seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0, tstart = 0;
+    if constexpr (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); tstart = tprev; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h2 = lane >> 5;
@@ -793,6 +813,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     const float cexp = 0.125f * 1.44269504088896340736f;
     constexpr float HEADROOM = F16 ? 3.0f : 6.0f;
 
+    A4_STAMP(4);
     auto tile = [&](const int kh, auto slot_tag, auto next_tag) {
         constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value;
         // tile kh + 1 (this thread's part) has landed; after the barrier every part has, and every wave is done with
@@ -800,12 +821,14 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         if (kh < 30) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        A4_STAMP(0);
         if (kh + 3 < 32) issue(kh + 3);
         unsigned gh_bits;
         asm volatile("ds_read_u16 %0, %1" : "=v"(gh_bits) : "v"(gaddr - 2u * (unsigned)kh));
         f32x16 Sn = S;
         if (kh + 1 < 32) Sn = qk(integral_constant<int, SN>{});          // waits lgkmcnt(0): gh is there too
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        A4_STAMP(1);
         const float gh = (float)__builtin_bit_cast(_Float16, (unsigned short)gh_bits);
         float p[16];
         unsigned pk[8];
@@ -840,6 +863,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             l_run += (a0 + a1) + (a2 + a3);
         }
         const uint4 pf0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), pf1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        if constexpr (DBG) { asm volatile("" ::"v"(pk[0]), "v"(pk[3]), "v"(pk[7]), "v"(l_run)); }
+        A4_STAMP(2);
         {
             const uint4 v00 = a4_read128<SL * A4_SLOT>(va[0]), v01 = a4_read128<SL * A4_SLOT>(va[1]);
             const uint4 v10 = a4_read128<SL * A4_SLOT>(va[2]), v11 = a4_read128<SL * A4_SLOT>(va[3]);
@@ -850,6 +875,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             O0 = mfma32<F16>(v01, pf1, O0);
             O1 = mfma32<F16>(v11, pf1, O1);
         }
+        A4_STAMP(3);
         S = Sn;
     };
     for (int kh0 = 0; kh0 < 32; kh0 += 4) {
@@ -872,6 +898,16 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             o.y = pack2<F16>(O[4 * g4 + 2] * inv, O[4 * g4 + 3] * inv);
             *reinterpret_cast<uint2 *>(orow + d) = o;
         }
+    if constexpr (DBG) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        seg[5] = (unsigned)(t_ - tstart);
+        if (lane == 0 && dbg) {
+            unsigned *d = dbg + ((size_t)lin * 4 + wave) * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = seg[i];
+        }
+    }
 }
 
 CPX_SWITCH(g_att_xcd, 1);          // XCD-aware workgroup order
@@ -895,6 +931,20 @@ extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const voi
     hipLaunchKernelGGL((k_attention<false, true>), dim3(8, 16, n_subtiles), dim3(ATT_THREADS), 0, s,
                        (const unsigned short *)qkv, (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
                        (const unsigned short *)rel_w, (unsigned short *)out, dbg, g_att_xcd);
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+// the same for the PRODUCTION kernel (k_attention4p): dbg [n_subtiles*16*8 blocks][4 waves][6], vT_ws holds V^T already or is
+// filled by the transpose kernel here
+extern "C" int cpx_attention4_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_v_transpose, dim3(16, 16, n_subtiles), dim3(256), 0, s,
+                       (const unsigned short *)qkv, (unsigned short *)vT_ws);
+    (void)hipFuncSetAttribute((const void *)k_attention4p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+    hipLaunchKernelGGL((k_attention4p<false, true>), dim3(8, 16, n_subtiles), dim3(ATT_THREADS), A4_LDS_BYTES, s,
+                       (const unsigned short *)qkv, (const unsigned short *)vT_ws, (const unsigned short *)rel_h,
+                       (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd, dbg);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }

@@ -30,6 +30,9 @@ void cpx_follow_set_early_exit(int on);     /* 1 (default): Euler loop leaves wh
 /* per-wave cycle stamps of the attention loop segments: dbg [n_subtiles*16*8][4][9] */
 int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                         void *vT_ws, void *out, unsigned *dbg, void *stream);
+/* the same for the production kernel (variant 2, k_attention4p): dbg [n_subtiles*16*8][4][6] */
+int cpx_attention4_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
+                         void *vT_ws, void *out, unsigned *dbg, void *stream);
 /* the same for the 8-wave ping-pong kernel (variant 1): dbg [n_subtiles*16*4][8][9] */
 int cpx_attention8_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                          void *vT_ws, void *out, unsigned *dbg, void *stream);
