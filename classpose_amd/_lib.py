@@ -130,6 +130,7 @@ SIGNATURES = {
 _PRIVATE = {
     "cpx_gemm_set_variant": (None, [_i]),
     "cpx_attention_set_trv": (None, [_i]),
+    "cpx_attention_set_lsum": (None, [_i]),
     "cpx_attention_set_variant": (None, [_i]),
     "cpx_follow_set_early_exit": (None, [_i]),
     "cpx_gemm_set_reverse": (None, [_i]),

@@ -709,7 +709,11 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
             __builtin_amdgcn_sched_barrier(0);                                                 \
         }                                                                                      \
     } while (0)
-template <bool F16, bool DBG = false>
+// LSUM: the softmax denominators come out of the matrix pipe -- two more MFMAs per tile with an all-ones A operand
+// (every row of the product is the column sum of P^T, i.e. the sum over the tile's 32 keys of the ROUNDED probabilities, the
+// same values P.V multiplies) instead of a 15-add tree per lane: 16 fewer vector instructions per tile and wave (of 67), no
+// cross-lane step at the end (both lane halves hold the full sum), 20 more registers.
+template <bool F16, bool DBG = false, bool LSUM = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
                                                                 const unsigned short *__restrict__ relh,
@@ -812,6 +816,14 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     float m_run = -1e30f, l_run = 0.f;
     const float cexp = 0.125f * 1.44269504088896340736f;
     constexpr float HEADROOM = F16 ? 3.0f : 6.0f;
+    f32x16 Lacc;
+    uint4 ones;
+    if constexpr (LSUM) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Lacc[i] = 0.f;
+        const unsigned one2 = F16 ? 0x3C003C00u : 0x3F803F80u;
+        ones = make_uint4(one2, one2, one2, one2);
+    }
 
     A4_STAMP(4);
     auto tile = [&](const int kh, auto slot_tag, auto next_tag) {
@@ -848,7 +860,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             const float m_new = __builtin_fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);
             m_run = m_new;
-            l_run *= alpha;
+            if constexpr (LSUM) Lacc[0] *= alpha;        // only row 0 of the (all equal) rows is ever read
+            else l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
             const float off = (gh - m_run) * cexp;
@@ -857,7 +870,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
 #pragma unroll
             for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
         }
-        {
+        if constexpr (!LSUM) {
             const float a0 = (p[0] + p[1]) + (p[2] + p[3]), a1 = (p[4] + p[5]) + (p[6] + p[7]);
             const float a2 = (p[8] + p[9]) + (p[10] + p[11]), a3 = (p[12] + p[13]) + (p[14] + p[15]);
             l_run += (a0 + a1) + (a2 + a3);
@@ -874,6 +887,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             O1 = mfma32<F16>(v10, pf0, O1);
             O0 = mfma32<F16>(v01, pf1, O0);
             O1 = mfma32<F16>(v11, pf1, O1);
+            if constexpr (LSUM) { Lacc = mfma32<F16>(ones, pf0, Lacc); Lacc = mfma32<F16>(ones, pf1, Lacc); }
         }
         A4_STAMP(3);
         S = Sn;
@@ -884,7 +898,9 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         tile(kh0 + 2, integral_constant<int, 2>{}, integral_constant<int, 3>{});
         tile(kh0 + 3, integral_constant<int, 3>{}, integral_constant<int, 0>{});
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if constexpr (LSUM) l_tot = Lacc[0];
+    else l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     unsigned short *orow = out + (tok0 + qh * 32 + r) * 1024 + head * 64;
 #pragma unroll
@@ -917,11 +933,13 @@ CPX_SWITCH(g_att_v8, 2);           // 2: 4-wave kernel with the LDS-DMA ring and
 // qkv epilogue.  Bitwise identical outputs; the whole engine step measured 24.57 vs 24.44 ms (one-process A/B,
 // tools/ab_switch.py cpx_attention_set_trv): the 8 transposed reads per tile cost more than the epilogue saves.
 CPX_SWITCH(g_att_trv, 0);
+CPX_SWITCH(g_att_lsum, 0);         // 1: softmax denominators by an all-ones MFMA instead of the vector add tree (k_attention4p<.., LSUM>)
 int cpx_attention_trv_enabled(void) { return g_att_trv; }
 #ifdef CPX_DEBUG
 extern "C" void cpx_attention_set_variant(int v8) { g_att_v8 = v8; }
 extern "C" void cpx_attention_set_xcd_order(int v) { g_att_xcd = v; }
 extern "C" void cpx_attention_set_trv(int v) { g_att_trv = v; }
+extern "C" void cpx_attention_set_lsum(int v) { g_att_lsum = v; }
 // diagnostic: per-wave cycle counts of the loop segments -> dbg [n_subtiles*16*8 blocks][4 waves][9]
 extern "C" int cpx_attention_debug(const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles,
                                    void *vT_ws, void *out, unsigned *dbg, void *stream) {
@@ -1011,6 +1029,23 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         (void)hipFuncSetAttribute((const void *)k_attention4p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)k_attention4p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
     });
+#ifdef CPX_DEBUG
+    if (g_att_lsum) {
+        static CpxOncePerDevice once4l;
+        once4l([] {
+            (void)hipFuncSetAttribute((const void *)k_attention4p<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+        });
+        if (dtype == CPX_DT_F16)
+            hipLaunchKernelGGL((k_attention4p<true, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        else
+            hipLaunchKernelGGL((k_attention4p<false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
+#endif
     if (dtype == CPX_DT_F16)
         hipLaunchKernelGGL((k_attention4p<true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
                            (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);

@@ -25,6 +25,7 @@ void cpx_gemm_set_reverse(int on);          /* 0 (default): mlp.lin2 walks M bac
 void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */
 void cpx_attention_set_xcd_order(int on);   /* 1 (default): (sub-tile, head) pairs pinned to one XCD     */
 void cpx_attention_set_variant(int v);      /* 2 (default): 4-wave, LDS-DMA ring + pipelined S; 0: 4-wave register ring; 1: 8-wave ping-pong */
+void cpx_attention_set_lsum(int on);        /* 0 (default): 1 = softmax denominators by an all-ones MFMA (experiment)           */
 void cpx_attention_set_trv(int on);         /* 0 (default): V through ds_read_b64_tr_b16                  */
 void cpx_follow_set_early_exit(int on);     /* 1 (default): Euler loop leaves when its orbit closes      */
 /* per-wave cycle stamps of the attention loop segments: dbg [n_subtiles*16*8][4][9] */
