@@ -260,7 +260,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         by_size.setdefault(plan.coords[ti][1], []).append(ti)
     pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
     futures = []
-    cells_all, xy_all, n_invalid = [], [], 0
+    cells_all, xy_all, tile_all, n_invalid = [], [], [], 0
     scale = plan.polygon_scale        # min(train_mpp / mpp_x, train_mpp / mpp_y) from the shared slots, predict_wsi.py:1517-1524
     t0 = time.time()
     n_done = 0
@@ -288,7 +288,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
                 raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
             polys = eng.fetch_polygons(n, out)
             if polys is not None:                                    # contours traced on the device (f1)
-                cells, _, xy = polys
+                cells, tile_in_batch, xy = polys
                 keep = cells["valid"] == 1
                 n_invalid += int((~keep).sum())
                 xy_all.append(geojson.gather_vertices(xy, cells["offset"][keep], cells["n_pts"][keep]))
@@ -296,13 +296,14 @@ def run_rank(args, rank: int, world: int, device: torch.device):
                 for name in ("area", "perimeter", "cx", "cy", "n_pts", "cls"):
                     rows[name] = cells[keep][name]
                 cells_all.append(rows)
+                tile_all.append(np.asarray(chunk, np.int64)[tile_in_batch[keep]])       # global tile index of every cell
             else:                                                    # vertex pool overflow: host polygoniser
                 masks = out.masks.cpu().numpy().view(np.uint16)      # D2H: 2 B / pixel
                 recs = eng.fetch_records(n, out)
                 for k, ti in enumerate(chunk):
                     origin = plan.coords[ti][0]
-                    futures.append(pool.submit(postprocess.polygonize_tile, masks[k].copy(),
-                                               recs[recs["tile"] == k], scale, origin))
+                    futures.append((ti, pool.submit(postprocess.polygonize_tile, masks[k].copy(),
+                                                    recs[recs["tile"] == k], scale, origin)))
             n_done += n
             if rank == 0 and (n_done // nT) % 20 == 0:
                 logger.info(f"Predicted tiles: {n_done}/{len(mine)} "
@@ -326,7 +327,7 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         if in_flight is not None:
             collect(*in_flight)
         del eng, stream
-    for f in futures:
+    for ti, f in futures:
         cells, xy = f.result()
         keep = cells["valid"] == 1
         n_invalid += int((~keep).sum())
@@ -335,21 +336,39 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         for name in ("area", "perimeter", "cx", "cy", "n_pts", "cls"):
             rows[name] = cells[keep][name]
         cells_all.append(rows)
+        tile_all.append(np.full(len(rows), ti, np.int64))
     pool.shutdown()
     slide.close()
     cells = np.concatenate(cells_all) if cells_all else np.zeros(0, CELL_ROW)
     xy = np.concatenate(xy_all) if xy_all else np.zeros((0, 2))
+    plan.cell_tiles = np.concatenate(tile_all) if tile_all else np.zeros(0, np.int64)
     logger.info(f"[rank {rank}] {len(cells)} cells, {n_invalid} invalid, {len(mine)} tiles in {time.time() - t0:.1f}s")
     return cells, xy, labels, plan
 
 
-def gather_cells(cells: np.ndarray, xy: np.ndarray, device) -> tuple[np.ndarray, np.ndarray]:
-    """The path's one collective: per-rank cell tables + vertex pools -> every rank."""
+def canonical_cell_order(cells: np.ndarray, xy: np.ndarray, tiles: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Cells in the order of their tile's index in the ``_get_coords`` walk (within a tile: label order), whatever rank,
+    batch, tile-size group or fallback path produced them.  The reference's order is whatever its worker processes happen
+    to deliver (a shared queue); de-duplication depends on it inside clusters of >= 3 cells, so THIS order is what makes the
+    output of an N-GPU run identical to the 1-GPU run (static sharding)."""
+    if len(cells) == 0 or bool(np.all(tiles[1:] >= tiles[:-1])):
+        return cells, xy
+    order = np.argsort(tiles, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])])[:-1]
+    return cells[order], geojson.gather_vertices(xy, offs[order], cells["n_pts"][order])
+
+
+def gather_cells(cells: np.ndarray, xy: np.ndarray, device, tiles: np.ndarray | None = None):
+    """The path's one collective: per-rank cell tables + vertex pools (+ the cells' tile indices) -> every rank."""
     c = torch.from_numpy(cells.view(np.uint8).reshape(len(cells), CELL_ROW.itemsize).copy()).to(device)
     v = torch.from_numpy(np.ascontiguousarray(xy).view(np.uint8).reshape(len(xy), 16).copy()).to(device)
     c = parallel.all_gather_records(c).cpu().numpy()
     v = parallel.all_gather_records(v).cpu().numpy()
-    return c.reshape(-1).view(CELL_ROW), v.reshape(-1).view(np.float64).reshape(-1, 2)
+    out = (c.reshape(-1).view(CELL_ROW), v.reshape(-1).view(np.float64).reshape(-1, 2))
+    if tiles is None:
+        return out
+    t = torch.from_numpy(np.ascontiguousarray(tiles, dtype=np.int64).view(np.uint8).reshape(len(tiles), 8).copy()).to(device)
+    return out + (parallel.all_gather_records(t).cpu().numpy().reshape(-1).view(np.int64),)
 
 
 def _qc_override(kind: str):
@@ -540,8 +559,10 @@ def main(args, spawned: bool = False, parser_factory=None):
     device = torch.device("cuda", local) if world > 1 else \
         (devices[0] if devices[0].index is not None else torch.device("cuda", 0))
     cells, xy, labels, plan = run_rank(args, rank, world, device)
+    tiles = plan.cell_tiles
     if world > 1:
-        cells, xy = gather_cells(cells, xy, device)
+        cells, xy, tiles = gather_cells(cells, xy, device, tiles)
+    cells, xy = canonical_cell_order(cells, xy, tiles)
     if rank == 0:
         write_outputs(args, cells, xy, labels, plan, device)
     if torch.distributed.is_initialized():

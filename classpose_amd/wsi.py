@@ -85,6 +85,7 @@ class SlidePlan:
     # Python float as is (the typecode is ignored; only sharedctypes.Value would round to a C float) -- so mpp, bounds, ts and
     # resize_factor are all read back as full doubles and this equals prediction_to_slide_scale.
     polygon_scale: float = 1.0
+    cell_tiles: object = None        # filled by run_rank: tile index (into coords) of every cell it returns
     rois: list | None = None
     tissue_cnts: list | None = None
     roi_class_dict: dict | None = None

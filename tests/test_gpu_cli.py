@@ -515,3 +515,34 @@ def test_predict_wsi_cli_openslide_protocol_reader_at_level_1(cuda, tmp_path, mo
     if bounds != (0.0, 0.0):
         xs = np.concatenate([np.asarray(f["geometry"]["coordinates"][0])[:, 0] for f in cont])
         assert xs.min() < 0                                   # cells left of the bounds origin come out negative, as in the reference
+
+
+@pytest.mark.parametrize("geometry", ["conic-256-32-tta", "fp16-512-64"])
+def test_predict_wsi_two_ranks_share_one_gpu_gloo(cuda, tmp_path, monkeypatch, geometry):
+    """The N > 1 leg of BASELINE configs[3] (conic, --tta) and configs[4] (fp16, 512-px tiles) on a ONE-GPU box:
+    ``--device cuda:0,0`` spawns two fresh rank processes on the same GPU (the spawn / static ``k % 2`` shard / all-gather of
+    cell tables, vertex pools and tile indices / rank-0 outputs path of ``--device cuda:0,1``), with the collective carried
+    by gloo (CPX_DIST_BACKEND) because one device cannot host two RCCL ranks.  The files must equal the single-rank run
+    cell for cell -- including the de-duplication's order-dependent choices, which is what the canonical tile order of the
+    gathered table is for."""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    monkeypatch.setenv("CPX_DIST_BACKEND", "gloo")
+    from classpose_amd.entrypoints import predict_wsi
+    if geometry == "conic-256-32-tta":
+        slide, extra = "synthetic://1180x956?mpp=0.5&seed=51", dict(tile_size=256, overlap=32, tta=True, precision="bf16", batch_size=8)
+    else:
+        slide, extra = "synthetic://2000x1500?mpp=0.5&seed=52", dict(tile_size=512, overlap=64, tta=False, precision="fp16", batch_size=8)
+    o1, o2 = tmp_path / "one", tmp_path / "two"
+    predict_wsi.main(_reference_integration_args(slide, o1, device="cuda:0", **extra))
+    predict_wsi.main(_reference_integration_args(slide, o2, device="cuda:0,0", **extra))
+    feats = []
+    for o in (o1, o2):
+        fs = json.load(open(next(o.glob("*_cell_contours.geojson"))))["features"]
+        feats.append([(f["geometry"]["coordinates"], f["properties"]["classification"], f["properties"]["measurements"]) for f in fs])
+    assert len(feats[0]) > 100
+    assert feats[0] == feats[1]                              # same cells, same order, same polygons
+    cent = [json.load(open(next(o.glob("*_cell_centroids.geojson"))))["features"] for o in (o1, o2)]
+    assert [f["geometry"] for f in cent[0]] == [f["geometry"] for f in cent[1]]
