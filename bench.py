@@ -134,8 +134,10 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     # land on each other: 25.7 s per tile instead of 4.9 s, measured)
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--slide", str(slide_px), "--first", str(i),
                                "--stride", str(P), "--tiles", str(per), "--warm", str(warm), "--threads", str(threads),
-                               "--budget", str(budget_s), "--depth", str(depth),
-                               "--cpus", ",".join(map(str, cpus[i * threads:(i + 1) * threads]))],
+                               "--budget", str(budget_s), "--depth", str(depth)]
+                              # several workers: each pinned to its own block of physical cores; a single worker is left to
+                              # the scheduler (on a shared host the first cores are not the idle ones)
+                              + (["--cpus", ",".join(map(str, cpus[i * threads:(i + 1) * threads]))] if P > 1 else []),
                               cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(P)]
     res = []
     for p in procs:
@@ -152,7 +154,9 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
     stage = {k: round(sum(r["stage_s"][k] for r in res) / tiles * 1e3, 2) for k in res[0]["stage_s"]}
     return dict(value=rate, unit="tiles/s", cores=len(res) * threads, kind="port", cells_per_s=cells / tiles * rate,
                 processes=len(res), threads_per_process=threads, physical_cores=phys, cgroup_cpu_quota=quota, stage_ms_per_tile=stage,
-                sample=f"{tiles} tiles of the same workload ({len(res)} processes x {threads} torch threads, each pinned to its own {threads} physical cores, on disjoint tiles, "
+                sample=f"{tiles} tiles of the same workload ({len(res)} process(es) x {threads} torch threads"
+                       f"{', each pinned to its own block of physical cores' if len(res) > 1 else ''}; host: {phys} physical cores, cgroup CPU quota "
+                       f"{quota if quota is not None else 'none'}; disjoint tiles, "
                        f"{warm} warm-up tile(s) each = {warm * len(res)} in all), one tile per eval (4 sub-tiles, fp32 torch-CPU "
                        f"ViT-L + oracle dynamics on the injected fields); all windows within {span:.1f} s; the literal "
                        f"reference cannot run here (cellpose / cv2 / openslide wheels absent)")

@@ -212,3 +212,27 @@ def test_unet_conv_list_equals_oracle_unet(fts):
     ref = onet.unet_forward(sd, "out_class.", x, len(fts))
     assert got.shape == ref.shape == (2, ncls * 64, 32, 32)
     assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+def test_canonical_cell_order_makes_rank_count_invisible():
+    """predict_wsi.canonical_cell_order: whatever order ranks / batches / the fallback path deliver cells in, the table that
+    reaches de-duplication is in tile order (label order inside a tile), vertices following their cells"""
+    from classpose_amd.entrypoints.predict_wsi import CELL_ROW, canonical_cell_order
+    rng = np.random.default_rng(0)
+    n_tiles, per = 7, [3, 0, 5, 2, 4, 1, 6]
+    tiles = np.repeat(np.arange(n_tiles), per)
+    n = len(tiles)
+    cells = np.zeros(n, CELL_ROW)
+    cells["n_pts"] = rng.integers(3, 9, n)
+    cells["area"] = np.arange(n)                                   # identifies the cell
+    xy = np.repeat(np.arange(n, dtype=np.float64), cells["n_pts"])[:, None] * np.ones((1, 2))     # vertex rows carry their cell's id
+    c1, x1 = canonical_cell_order(cells, xy, tiles)
+    assert c1 is cells and x1 is xy                                 # already canonical: untouched
+    # two-rank delivery: rank 0 holds tiles 0, 2, 4, 6, rank 1 tiles 1, 3, 5
+    order = np.concatenate([np.flatnonzero(tiles % 2 == 0), np.flatnonzero(tiles % 2 == 1)])
+    offs = np.concatenate([[0], np.cumsum(cells["n_pts"])])
+    xy2 = np.concatenate([xy[offs[i]:offs[i + 1]] for i in order])
+    c2, x2 = canonical_cell_order(cells[order], xy2, tiles[order])
+    assert np.array_equal(c2, cells) and np.array_equal(x2, xy)
+    c3, x3 = canonical_cell_order(cells[:0], xy[:0], tiles[:0])
+    assert len(c3) == 0 and len(x3) == 0
