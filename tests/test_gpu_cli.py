@@ -546,3 +546,33 @@ def test_predict_wsi_two_ranks_share_one_gpu_gloo(cuda, tmp_path, monkeypatch, g
     assert feats[0] == feats[1]                              # same cells, same order, same polygons
     cent = [json.load(open(next(o.glob("*_cell_centroids.geojson"))))["features"] for o in (o1, o2)]
     assert [f["geometry"] for f in cent[0]] == [f["geometry"] for f in cent[1]]
+
+
+def test_predict_wsi_cli_full_depth_network(cuda, tmp_path, monkeypatch):
+    """The command line with the FULL 24-block ViT-L (random-init weights of the reference layout, as bench.py runs it) in
+    flow-injection mode, BASELINE configs[1] geometry on a slide of 4 x 3 tiles: every nucleus inside the covered area comes
+    out exactly once with the class of its id hash -- the property the depth-1 CLI tests check, at the depth that is benched."""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "24")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    from classpose_amd.entrypoints import predict_wsi
+    W, Hs, seed = 960, 730, 61
+    args = predict_wsi.build_parser().parse_args([
+        "--model_config", "conic", "--slide_path", f"synthetic://{W}x{Hs}?mpp=0.5&seed={seed}",
+        "--output_folder", str(tmp_path), "--tile_size", "256", "--overlap", "32", "--batch_size", "32", "--device", "cuda:0"])
+    assert args.precision == "bf16"
+    predict_wsi.main(args)
+    cont = json.load(open(next(tmp_path.glob("*contours.geojson"))))
+    nx, ny = (W - 256) // 224 + 1, (Hs - 256) // 224 + 1
+    assert (nx, ny) == (4, 3)
+    cov_w, cov_h = (nx - 1) * 224 + 256, (ny - 1) * 224 + 256
+    cx, cy, r, ident = synth.nuclei_in_region(seed, 0, 0, cov_w, cov_h)
+    inner = (cx - r > 12) & (cx + r < cov_w - 12) & (cy - r > 12) & (cy + r < cov_h - 12)
+    found = np.array([[m["value"] for m in f["properties"]["measurements"] if m["name"].startswith("centroid")]
+                      for f in cont["features"]])
+    from scipy.spatial import cKDTree
+    d, idx = cKDTree(found).query(np.stack([cx[inner], cy[inner]], 1))
+    assert np.all(d < 1.5) and len(np.unique(idx)) == inner.sum()
+    names = ["Neutrophil", "Epithelial", "Lymphocyte", "Plasma cell", "Eosinophil", "Connective"]
+    assert [cont["features"][j]["properties"]["classification"]["name"] for j in idx] == [names[int(i % np.uint64(6))] for i in ident[inner]]
