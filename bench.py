@@ -112,7 +112,7 @@ def cgroup_cpu_limit() -> float | None:
         return None
 
 
-def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=100.0):
+def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=75.0):
     """Reference-shaped CPU path (the oracle, kind 'port'; oracle/cpu_baseline.py) on ALL physical host cores:
     P child processes x 32 torch threads over disjoint tiles of the same workload (one torch-CPU process stops scaling
     at ~32 threads on this ViT-L), >= 64 tiles after 4 warm-up tiles unless the wall budget ends a worker earlier.
