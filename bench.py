@@ -23,8 +23,7 @@ streamed pixels.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Besides the headline the line carries ``roofline`` (dominant kernel + per-stage table; the post-processing stage is timed
-repetition by repetition with device AND host clocks), ``cpu_baseline`` (P oracle processes x 32 torch threads over all
-physical host cores) and, at N = 1, ``side_lines``: the same pipeline with ``--precision fp32`` and with the network's own
+repetition by repetition with device AND host clocks), ``cpu_baseline`` (oracle worker processes sized by the cores / cgroup CPU quota the host grants) and, at N = 1, ``side_lines``: the same pipeline with ``--precision fp32`` and with the network's own
 (random-weight) fields driving the dynamics instead of the injected ones (SURVEY 8d asks for both modes).
 """
 from __future__ import annotations
@@ -113,9 +112,11 @@ def cgroup_cpu_limit() -> float | None:
 
 
 def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=75.0):
-    """Reference-shaped CPU path (the oracle, kind 'port'; oracle/cpu_baseline.py) on ALL physical host cores:
-    P child processes x 32 torch threads over disjoint tiles of the same workload (one torch-CPU process stops scaling
-    at ~32 threads on this ViT-L), >= 64 tiles after 4 warm-up tiles unless the wall budget ends a worker earlier.
+    """Reference-shaped CPU path (the oracle, kind 'port'; oracle/cpu_baseline.py) on every core the host grants the job:
+    P child processes x up to 32 torch threads over disjoint tiles of the same workload (one torch-CPU process stops scaling
+    at ~32 threads on this ViT-L; P and the thread count follow the physical cores of the affinity mask capped by the cgroup
+    CPU quota), 64 tiles after 4 warm-up tiles unless the wall budget (75 s of timed tiles per worker, so that the default
+    bench run stays within a few minutes) ends a worker earlier -- on a host that grants 16 CPUs a tile takes 5.4 s: ~14 tiles.
     The children never touch the GPU; they are started as ordinary child processes (no exec from this process)."""
     import subprocess
     cpus = physical_core_cpus()
