@@ -10,6 +10,8 @@ torch is used for device memory, streams and (elsewhere) torch.distributed only.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -384,7 +386,10 @@ class Engine:
         self.max_pts = nT * max(4096, H * W // 8)             # device vertex pool (f1), 16 B per vertex
         self.slots = [_Slot(self) for _ in range(self.N_SLOTS)]
         self.s_net = torch.cuda.Stream(d)
-        self.s_post = torch.cuda.Stream(d)
+        # the post-processing chain is ~38 short kernels that run beside persistent network kernels holding every CU: a
+        # higher stream priority lets their workgroups take a CU the moment one frees instead of queueing behind the
+        # network's next tiles (CPX_POST_STREAM_PRIORITY: -1 high, 0 normal; A/B in tools/ab_post_priority.py)
+        self.s_post = torch.cuda.Stream(d, priority=int(os.environ.get("CPX_POST_STREAM_PRIORITY", "0")))
         self._next = 0
         self._last: _Slot | None = None
 
