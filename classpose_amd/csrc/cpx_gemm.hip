@@ -381,8 +381,8 @@ __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][
 #define G2F_DBG 4
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
-    constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16;
-    constexpr bool STATS = (FLAGS & G2F_STATS) != 0 && EPI == CPX_EPI_RESID_BF16;
+    constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16 && EPI != CPX_EPI_POS_BF16;
+    constexpr bool STATS = (FLAGS & G2F_STATS) != 0 && (EPI == CPX_EPI_RESID_BF16 || EPI == CPX_EPI_POS_BF16);
     constexpr bool DBG = (FLAGS & G2F_DBG) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -509,10 +509,11 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
     }
 
-    for (int t = 0; t < nk; t += 2) {
+    for (int t = 0; t + 1 < nk; t += 2) {
         G2_TILE(t, 0)
         G2_TILE(t + 1, 1)
     }
+    if (nk & 1) G2_TILE(nk - 1, 0)               // odd number of K tiles (the patch embedding: K = 192): the last one sits in buffer 0
 #undef G2_TILE
     if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
     __builtin_amdgcn_sched_barrier(0);
@@ -592,6 +593,9 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                     } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    } else if constexpr (EPI == CPX_EPI_POS_BF16) {      // + pos_embed[token within its sub-tile][channel], float32
+                        const float4 pe = *reinterpret_cast<const float4 *>((const float *)g.aux + (size_t)((m0 + ml) & 1023) * g.N + n0 + nl);
+                        v[0] += pe.x; v[1] += pe.y; v[2] += pe.z; v[3] += pe.w;
                     }
                     if constexpr (VT) {          // transposed image [channel][token] for the V^T layout
 #pragma unroll
@@ -1388,9 +1392,11 @@ static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
 
 template <int EPI, bool F16>
 static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
-    if constexpr (EPI == CPX_EPI_F32 || EPI == CPX_EPI_POS_BF16) return false;
+    if constexpr (EPI == CPX_EPI_F32) return false;
     else {
-        if (!g_gemm_big || a0.M % 256 || a0.N % 256 || (a0.K / 64) % 2 || a0.K < 128) return false;
+        // (an odd number of K tiles only on the one-workgroup-per-tile kernel, which is what the positional epilogue takes)
+        if (!g_gemm_big || a0.M % 256 || a0.N % 256 || a0.K < 128) return false;
+        if ((a0.K / 64) % 2 && EPI != CPX_EPI_POS_BF16) return false;
         if ((a0.M / 256) * (a0.N / 256) < 256) return false;          // not enough tiles for 256 CUs
 #ifdef CPX_DEBUG
         if constexpr (EPI == CPX_EPI_BF16 || EPI == CPX_EPI_GELU_BF16 || EPI == CPX_EPI_RELU_BF16) {
@@ -1420,20 +1426,32 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
         GemmArgs a = a0;
         a.tiles_n = a.N / 256; a.n_blocks = (a.M / 256) * (a.N / 256);
         // one instantiation per (LayerNorm consumer | statistics producer) x (timing ablations, bf16 only)
-        constexpr int F1 = EPI == CPX_EPI_RESID_BF16 ? G2F_STATS : G2F_LN;
-        const bool f1 = EPI == CPX_EPI_RESID_BF16 ? a.stats_out != nullptr : a.ln_stats != nullptr;
+        constexpr bool PRODUCER = EPI == CPX_EPI_RESID_BF16 || EPI == CPX_EPI_POS_BF16;
+        constexpr int F1 = PRODUCER ? G2F_STATS : G2F_LN;
+        const bool f1 = PRODUCER ? a.stats_out != nullptr : a.ln_stats != nullptr;
+        if constexpr (EPI == CPX_EPI_POS_BF16) {       // one workgroup per tile (its epilogue reads the positional table with plain loads)
+            static CpxOncePerDevice once_pos;
+            once_pos([] {
+                (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, F16, G2F_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+            });
+            if (f1) hipLaunchKernelGGL((k_gemm256<EPI, F16, G2F_STATS>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
+            else hipLaunchKernelGGL((k_gemm256<EPI, F16, 0>), dim3(a.n_blocks), dim3(G2_THREADS), G2_LDS_BYTES, s, a);
+            return true;
+        } else {
 #ifdef CPX_DEBUG
-        if constexpr (!F16) {
-            if (a.dbg) {
-                if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DBG>(a, s);
-                else launch_gemm256_flags<EPI, F16, G2F_DBG>(a, s);
-                return true;
+            if constexpr (!F16) {
+                if (a.dbg) {
+                    if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DBG>(a, s);
+                    else launch_gemm256_flags<EPI, F16, G2F_DBG>(a, s);
+                    return true;
+                }
             }
-        }
 #endif
-        if (f1) launch_gemm256_flags<EPI, F16, F1>(a, s);
-        else launch_gemm256_flags<EPI, F16, 0>(a, s);
-        return true;
+            if (f1) launch_gemm256_flags<EPI, F16, F1>(a, s);
+            else launch_gemm256_flags<EPI, F16, 0>(a, s);
+            return true;
+        }
     }
 }
 
@@ -1487,8 +1505,9 @@ extern "C" int cpx_row_stats(const void *x, int rows, float *stats, void *stream
 
 // does this shape take the 256^2 kernel (whose RESID epilogue can emit LN statistics)?
 int cpx_gemm_half_uses_big_tile(int M, int N, int K, int epilogue) {
-    if (epilogue == CPX_EPI_F32 || epilogue == CPX_EPI_POS_BF16) return 0;
-    if (!g_gemm_big || M % 256 || N % 256 || (K / 64) % 2 || K < 128) return 0;
+    if (epilogue == CPX_EPI_F32) return 0;
+    if (!g_gemm_big || M % 256 || N % 256 || K < 128) return 0;
+    if ((K / 64) % 2 && epilogue != CPX_EPI_POS_BF16) return 0;
     return (M / 256) * (N / 256) >= 256;
 }
 
@@ -1502,7 +1521,7 @@ int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K,
     CPX_REQUIRE((epilogue != CPX_EPI_RESID_BF16 && epilogue != CPX_EPI_POS_BF16 && epilogue != CPX_EPI_QKV_BF16) || aux);
     CPX_REQUIRE(epilogue != CPX_EPI_QKV_BF16 || (N == 3072 && M % 1024 == 0));
     CPX_REQUIRE(!ln_stats || (ln_colsum && epilogue != CPX_EPI_RESID_BF16));
-    CPX_REQUIRE(!stats_out || (epilogue == CPX_EPI_RESID_BF16 && N == 1024 && cpx_gemm_half_uses_big_tile(M, N, K, epilogue)));
+    CPX_REQUIRE(!stats_out || ((epilogue == CPX_EPI_RESID_BF16 || epilogue == CPX_EPI_POS_BF16) && N == 1024 && cpx_gemm_half_uses_big_tile(M, N, K, epilogue)));
     GemmArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;

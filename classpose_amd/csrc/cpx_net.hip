@@ -1150,14 +1150,17 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
     cpx_gemm_half(dt, A_, W_, M, N_, K_, EPI_, B_, AUX_, OUT_, LD_, nullptr, nullptr, nullptr, stream)
 #define TIMED(kind_, layer_, call_) do { const bool t_ = cpx_prof_begin(prof, kind_, layer_, hs); RUN(call_); if (t_) cpx_prof_end(prof, hs); } while (0)
     // patch embed (+bias +pos_embed)
-    RUN(GEMM(patches, w->pe_w, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024));
     float *st = (float *)(ws + L.off_st);
     // LayerNorm fusion: the RESID GEMMs emit partial row statistics of the residual stream, the
     // next GEMM applies (x - mean) * rstd algebraically in its epilogue (weights pre-folded)
     const bool fuse = w->fuse_ln != 0;
     const bool big_stats = fuse && cpx_gemm_half_uses_big_tile(M, 1024, 1024, CPX_EPI_RESID_BF16) &&
                            cpx_gemm_half_uses_big_tile(M, 1024, 4096, CPX_EPI_RESID_BF16);
-    if (fuse) RUN(cpx_row_stats_half(dt, x, M, st, stream));
+    // on the 256^2 kernel (three K tiles) the patch embedding emits the first layer's row statistics itself
+    const bool pe_stats = big_stats && cpx_gemm_half_uses_big_tile(M, 1024, 192, CPX_EPI_POS_BF16);
+    RUN(cpx_gemm_half(dt, patches, w->pe_w, M, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024, nullptr, nullptr,
+                      pe_stats ? st : nullptr, stream));
+    if (fuse && !pe_stats) RUN(cpx_row_stats_half(dt, x, M, st, stream));
     const int qkv_epi = trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16;
     for (int i = 0; i < w->depth; ++i) {
         const cpx_block_weights &b = w->blocks[i];

@@ -52,6 +52,36 @@ def _gemm_epilogues(L, cuda, variant, M, N, K):
         L.cpx_gemm_set_variant(1)
 
 
+def test_patch_embedding_on_the_256_tile_kernel(cuda):
+    """The patch embedding (M x 1024 x 192 = THREE K tiles, bias + float32 positional table, bf16 out) takes the 256^2 kernel
+    since round 3 and emits the first layer's LayerNorm row statistics itself: bitwise equal to the 128^2 kernel (same
+    fp32 accumulation order), within bf16 rounding of torch fp32, statistics equal to the row sums of the rounded output."""
+    M, N, K = 32768, 1024, 192
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    pos = torch.randn(1024, N, generator=g).to(cuda)
+    assert _lib.lib().cpx_gemm_uses_big_tile(M, N, K, ops.EPI["pos"]) == 1
+    assert _lib.lib().cpx_gemm_uses_big_tile(M, N, K, ops.EPI["bf16"]) == 0          # odd K-tile counts only for this epilogue
+    out, st = ops.gemm_ln(A, W, "pos", bias, pos, want_stats=True)
+    plain = ops.gemm(A, W, "pos", bias, pos)
+    assert torch.equal(out, plain)
+    with _lib.use_debug_library() as L:
+        L.cpx_gemm_set_big(0)
+        try:
+            small = ops.gemm(A, W, "pos", bias, pos)
+        finally:
+            L.cpx_gemm_set_big(1)
+    assert torch.equal(out, small)
+    ref = A.float() @ W.float().T + bias + pos[torch.arange(M, device=cuda) % 1024]
+    assert _rel(out.float(), ref) < 4e-3
+    o = out.double()
+    s1, s2 = st[:, :, 0].double().sum(1), st[:, :, 1].double().sum(1)
+    assert float((s1 - o.sum(1)).abs().max()) < 1e-3 * float(o.abs().sum(1).max())
+    assert float(((s2 - (o * o).sum(1)) / (o * o).sum(1)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (32768, 4096, 128)])
 def test_gelu_epilogue_is_erf_gelu_at_half_precision(cuda, M, N, K):
     """The epilogue's GELU (2 ^ P5(|x|) form of x Phi(x), csrc/cpx_gemm.hip: gelu_erf) against float64 erf-GELU of the
