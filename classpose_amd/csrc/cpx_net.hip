@@ -713,7 +713,10 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
 // (every row of the product is the column sum of P^T, i.e. the sum over the tile's 32 keys of the ROUNDED probabilities, the
 // same values P.V multiplies) instead of a 15-add tree per lane: 16 fewer vector instructions per tile and wave (of 67), no
 // cross-lane step at the end (both lane halves hold the full sum), 20 more registers.
-template <bool F16, bool DBG = false, bool LSUM = false>
+// ERD ("early reads"): the K fragments of tile kh + 1 AND the V fragments of tile kh are requested right behind the barrier and
+// the softmax's vector stream runs under their LDS latency (gh is waited for with a counted lgkmcnt(8)); the eight MFMAs
+// follow in one block.  Without it the wave sits in lgkmcnt(0) twice per tile (in front of QK^T and in front of P.V).
+template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
                                                                 const unsigned short *__restrict__ relh,
@@ -838,8 +841,19 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         unsigned gh_bits;
         asm volatile("ds_read_u16 %0, %1" : "=v"(gh_bits) : "v"(gaddr - 2u * (unsigned)kh));
         f32x16 Sn = S;
-        if (kh + 1 < 32) Sn = qk(integral_constant<int, SN>{});          // waits lgkmcnt(0): gh is there too
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint4 ek0, ek1, ek2, ek3, ev00, ev01, ev10, ev11;
+        if constexpr (ERD) {
+            // 8 fragment reads in flight behind gh (for the last tile the K reads repeat slot SN's stale rows: never used)
+            ek0 = a4_read128<SN * A4_SLOT>(ka[0]); ek1 = a4_read128<SN * A4_SLOT>(ka[1]);
+            ek2 = a4_read128<SN * A4_SLOT>(ka[2]); ek3 = a4_read128<SN * A4_SLOT>(ka[3]);
+            ev00 = a4_read128<SL * A4_SLOT>(va[0]); ev01 = a4_read128<SL * A4_SLOT>(va[1]);
+            ev10 = a4_read128<SL * A4_SLOT>(va[2]); ev11 = a4_read128<SL * A4_SLOT>(va[3]);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");             // gh only
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (kh + 1 < 32) Sn = qk(integral_constant<int, SN>{});          // waits lgkmcnt(0): gh is there too
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         A4_STAMP(1);
         const float gh = (float)__builtin_bit_cast(_Float16, (unsigned short)gh_bits);
         float p[16];
@@ -878,7 +892,21 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         const uint4 pf0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), pf1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         if constexpr (DBG) { asm volatile("" ::"v"(pk[0]), "v"(pk[3]), "v"(pk[7]), "v"(l_run)); }
         A4_STAMP(2);
-        {
+        if constexpr (ERD) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // long since landed: the vector stream ran meanwhile
+            __builtin_amdgcn_sched_barrier(0);
+            O0 = mfma32<F16>(ev00, pf0, O0);
+            O1 = mfma32<F16>(ev10, pf0, O1);
+            if (kh + 1 < 32) Sn = mfma32<F16>(ek0, qf[0], GW);
+            O0 = mfma32<F16>(ev01, pf1, O0);
+            O1 = mfma32<F16>(ev11, pf1, O1);
+            if (kh + 1 < 32) {
+                Sn = mfma32<F16>(ek1, qf[1], Sn);
+                Sn = mfma32<F16>(ek2, qf[2], Sn);
+                Sn = mfma32<F16>(ek3, qf[3], Sn);
+            }
+            if constexpr (LSUM) { Lacc = mfma32<F16>(ones, pf0, Lacc); Lacc = mfma32<F16>(ones, pf1, Lacc); }
+        } else {
             const uint4 v00 = a4_read128<SL * A4_SLOT>(va[0]), v01 = a4_read128<SL * A4_SLOT>(va[1]);
             const uint4 v10 = a4_read128<SL * A4_SLOT>(va[2]), v11 = a4_read128<SL * A4_SLOT>(va[3]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1030,6 +1058,21 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         (void)hipFuncSetAttribute((const void *)k_attention4p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
     });
 #ifdef CPX_DEBUG
+    if (g_att_lsum == 2) {           // experiment: early fragment reads (k_attention4p<.., ERD>)
+        static CpxOncePerDevice once4e;
+        once4e([] {
+            (void)hipFuncSetAttribute((const void *)k_attention4p<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+        });
+        if (dtype == CPX_DT_F16)
+            hipLaunchKernelGGL((k_attention4p<true, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        else
+            hipLaunchKernelGGL((k_attention4p<false, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                               (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
     if (g_att_lsum) {
         static CpxOncePerDevice once4l;
         once4l([] {
