@@ -144,6 +144,7 @@ _PRIVATE = {
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),
     "cpx_gemm_set_pingpong": (None, [_i]),
+    "cpx_gemm_set_epi4": (None, [_i]),
     "cpx_gemm_pingpong_occupancy": (_i, []),
     "cpx_gemm_pingpong_stamps": (_i, [_p, _sz]),
     "cpx_gemm_set_pingpong_opts": (None, [_i, _i]),

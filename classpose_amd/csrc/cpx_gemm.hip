@@ -52,6 +52,7 @@ struct GemmArgs {
     // implicit 3x3 convolution (128^2 kernel, CONV instantiation): A is the [S*1024][conv_c] token-major activation of
     // 32 x 32-token images, K = 9 * conv_c with k = tap * conv_c + c (tap = 3 (dy + 1) + (dx + 1)); 0 = plain GEMM
     int conv_c;
+    int epi4;               // persistent 256^2 kernel: 1 = quarter-tile epilogue (conversion of quarter q beside the stores of q - 1)
     int pp_delay;           // ping-pong kernel: x ~8k cycles the second workgroup of a CU waits at launch (0 = no offset)
 };
 #define LN_SLOTS 4
@@ -379,6 +380,7 @@ __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][
 #define G2F_LN 1
 #define G2F_STATS 2
 #define G2F_DBG 4
+#define G2F_Q4 8          // persistent kernel: quarter-tile epilogue (experiment, debug build)
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16 && EPI != CPX_EPI_POS_BF16;
@@ -926,6 +928,80 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G2_BAR();
+        } else if constexpr (EPI != CPX_EPI_RESID_BF16 && (FLAGS & G2F_Q4) != 0) {
+            // ---- quarter-tile epilogue: the tile leaves in four 128-row x 128-column quarters through TWO 34 KB staging
+            // buffers; in stage q a wave first requests its 16-byte chunks of quarter q - 1 from LDS, then converts quarter q
+            // (the VALU stream: LayerNorm fold, bias, GELU, pack) into the other buffer, then stores quarter q - 1 -- the LDS
+            // round trip and the store issue of one quarter run beside the vector work of the next instead of behind it.
+            // Five barriers per tile instead of four; outputs bit for bit those of the two-half epilogue.
+            if (has_next) prefetch_next();
+            char *stg = smem + G2P_STG_OFF;
+            const int srow = tid >> 4, sc16 = tid & 15;          // store side: 32 rows x 16 chunks of 16 bytes per pass
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                uint4 h0 = make_uint4(0u, 0u, 0u, 0u), h1 = h0, h2 = h0, h3 = h0;      // (named registers: an array here goes to scratch)
+                const int hm = (q >> 1) & 1, hn = q & 1;
+                const int phm = ((q - 1) >> 1) & 1, phn = (q - 1) & 1;
+                char *buf = stg + (q & 1) * 34816, *pbuf = stg + ((q - 1) & 1) * 34816;
+                if (q > 0) {
+                    const char *src = pbuf + srow * 272 + sc16 * 16;
+                    h0 = *reinterpret_cast<const uint4 *>(src);
+                    h1 = *reinterpret_cast<const uint4 *>(src + 32 * 272);
+                    h2 = *reinterpret_cast<const uint4 *>(src + 64 * 272);
+                    h3 = *reinterpret_cast<const uint4 *>(src + 96 * 272);
+                }
+                if (q < 4) {
+                    float ln_rs[4], ln_nm[4];
+                    if constexpr (LN_IN) {
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) {
+                            const float2 pr = *reinterpret_cast<const float2 *>(smem + G2P_TAIL + (hm * 128 + wm * 64 + mb * 16 + fr) * 8);
+                            ln_rs[mb] = pr.x; ln_nm[mb] = pr.y;
+                        }
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int nq = wn * 32 + nb * 16 + fq * 4;                  // column inside the quarter
+                        const int nl = hn * 128 + nq;
+                        const float4 b = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 2048 + nl * 4);
+                        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (LN_IN) cs = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 3072 + nl * 4);
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) {
+                            const int mlh = wm * 64 + mb * 16 + fr;
+                            f32x4 vv = acc[hm][hn][mb][nb];
+                            if constexpr (LN_IN) {
+                                const float nm = ln_nm[mb], rs = ln_rs[mb];
+                                vv[0] = fmaf(vv[0], rs, fmaf(nm, cs.x, b.x)); vv[1] = fmaf(vv[1], rs, fmaf(nm, cs.y, b.y));
+                                vv[2] = fmaf(vv[2], rs, fmaf(nm, cs.z, b.z)); vv[3] = fmaf(vv[3], rs, fmaf(nm, cs.w, b.w));
+                            } else {
+                                vv[0] += b.x; vv[1] += b.y; vv[2] += b.z; vv[3] += b.w;
+                            }
+                            if constexpr (EPI == CPX_EPI_GELU_BF16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
+                            } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
+                            }
+                            uint2 o;
+                            o.x = (unsigned)to_half<F16>(vv[0]) | ((unsigned)to_half<F16>(vv[1]) << 16);
+                            o.y = (unsigned)to_half<F16>(vv[2]) | ((unsigned)to_half<F16>(vv[3]) << 16);
+                            *reinterpret_cast<uint2 *>(buf + mlh * 272 + nq * 2) = o;
+                        }
+                    }
+                }
+                if (q > 0) {
+                    unsigned short *dst = (unsigned short *)g.out + (size_t)(m0 + phm * 128 + srow) * g.ld_out + n0 + phn * 128 + sc16 * 8;
+                    const size_t r32 = (size_t)32 * g.ld_out;
+                    *reinterpret_cast<uint4 *>(dst) = h0;
+                    *reinterpret_cast<uint4 *>(dst + r32) = h1;
+                    *reinterpret_cast<uint4 *>(dst + 2 * r32) = h2;
+                    *reinterpret_cast<uint4 *>(dst + 3 * r32) = h3;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                G2_BAR();
+            }
         } else {
             if constexpr (EPI != CPX_EPI_RESID_BF16) {
                 if (has_next) prefetch_next();       // no global load result is consumed from here to the next tile top
@@ -1328,6 +1404,7 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 // 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
+CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
 CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
 CPX_SWITCH(g_gemm_pp_persist, 1);   // ping-pong kernel: 1 = two persistent workgroups per CU walk the tiles, 0 = one workgroup per tile
 CPX_SWITCH(g_gemm_pp_delay, 2);     // ping-pong kernel: start offset of a CU's second workgroup, x s_sleep 127 (~8k cycles)
@@ -1339,6 +1416,7 @@ extern "C" void cpx_gemm_set_persistent_qkv(int on) { g_gemm_persist_qkv = on; }
 extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
+extern "C" void cpx_gemm_set_epi4(int on) { g_gemm_epi4 = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
 extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
@@ -1448,6 +1526,15 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                 }
             }
 #endif
+#ifdef CPX_DEBUG
+            if constexpr (EPI != CPX_EPI_RESID_BF16) {
+                if (g_gemm_epi4) {
+                    if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_Q4>(a, s);
+                    else launch_gemm256_flags<EPI, F16, G2F_Q4>(a, s);
+                    return true;
+                }
+            }
+#endif
             if (f1) launch_gemm256_flags<EPI, F16, F1>(a, s);
             else launch_gemm256_flags<EPI, F16, 0>(a, s);
             return true;
@@ -1528,7 +1615,7 @@ int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K,
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
     a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg;
     a.rev_m = (g_gemm_rev && K >= 4096) ? 1 : 0;
-    a.conv_c = 0; a.pp_delay = 0;
+    a.conv_c = 0; a.pp_delay = 0; a.epi4 = g_gemm_epi4;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CPX_EPI_BF16: launch_gemm<CPX_EPI_BF16>(a, s, f16); break;
@@ -1558,7 +1645,7 @@ int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C
     a.M = M; a.N = N; a.K = 9 * C; a.bias = bias; a.aux = nullptr; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
     a.ln_stats = nullptr; a.ln_colsum = nullptr; a.stats_out = nullptr; a.l2_block = 0; a.dbg = 0; a.rev_m = 0;
-    a.conv_c = C; a.pp_delay = 0;
+    a.conv_c = C; a.pp_delay = 0; a.epi4 = 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(a.n_blocks), block(GEMM_THREADS);
     const size_t lds = 2 * STAGE_BYTES;

@@ -17,6 +17,7 @@ void cpx_gemm_set_big(int on);              /* 1 (default): 256^2 kernel when th
 void cpx_gemm_set_persistent(int on);       /* 1 (default): persistent 256^2 kernel with next-tile prefetch under the epilogue */
 void cpx_gemm_set_persistent_qkv(int on);   /* qkv projection on the persistent kernel with a balanced q|k / V^T tile list */
 void cpx_gemm_set_l2_block(int on);         /* 1 (default): 8 x 4 super-tile order per XCD, N-sweep; 2: M-sweep; 0: row-major */
+void cpx_gemm_set_epi4(int on);             /* 0 (default): 1 = quarter-tile epilogue of the persistent 256^2 kernel (experiment) */
 void cpx_gemm_set_pingpong(int on);         /* 0 (default): 1 = 256 x 128 "ping-pong" kernel, two 4-wave workgroups per CU (bias / GELU / ReLU epilogues) */
 void cpx_gemm_set_pingpong_opts(int persistent, int delay);   /* (1, 2) default: persistent grid; start offset of a CU's 2nd workgroup x ~8k cycles */
 int cpx_gemm_pingpong_stamps(unsigned long long *host_out, size_t n_words);   /* cycle stamps written under cpx_gemm_set_dbg(32) */
