@@ -59,7 +59,7 @@ def run(slide: int, first: int, stride: int, n_tiles: int, warm: int, threads: i
         cells += int(m.max())
         n += 1
         t_end = time.time()
-        if dt > budget_s and n >= 4:
+        if dt > budget_s and n >= 2:
             break
     return dict(tiles=n, cells=cells, busy_s=dt, t_start=t_start, t_end=t_end, threads=threads, stage_s=stage)
 
