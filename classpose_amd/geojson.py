@@ -69,32 +69,13 @@ def _measure(feature: dict, name: str):
 
 
 def dedup_indices(centers, sizes, max_dist: float = 15 / 2) -> list[int]:
-    """Indices kept by the reference's greedy grouping (identical control flow)."""
+    """Indices kept by the reference's ``deduplicate`` (predict_wsi.py:896-965): every pair of scipy's set, in the set's own
+    order, through the grouping loop -- the plain form ``dedup_exact`` is checked against."""
     if len(centers) == 0:
         return []
-    neighbours = KDTree(centers).query_pairs(max_dist)
-    groups: dict[int, list] = {}
-    member_to_group: dict[int, int] = {}
-    for pair in neighbours:
-        if pair[0] not in member_to_group and pair[1] not in member_to_group:
-            gi = len(groups)
-            groups[gi] = []
-            member_to_group[pair[0]] = gi
-            member_to_group[pair[1]] = gi
-        else:
-            gi = member_to_group[pair[0]] if pair[0] in member_to_group else member_to_group[pair[1]]
-        if pair[0] not in groups[gi]:
-            groups[gi].append(pair[0])
-        if pair[1] not in groups[gi]:
-            groups[gi].append(pair[1])
-    to_remove = {}
-    for group in groups.values():
-        if len(group) > 1:
-            largest = group[int(np.argmax([sizes[i] for i in group]))]
-            for i in group:
-                if i != largest and i not in to_remove:
-                    to_remove[i] = True
-    return [i for i in range(len(centers)) if i not in to_remove]
+    keep = np.ones(len(centers), bool)
+    _group_pairs_in_order(KDTree(centers).query_pairs(max_dist), np.asarray(sizes), keep)
+    return np.flatnonzero(keep).tolist()
 
 
 _XXP1, _XXP2, _XXP5 = np.uint64(11400714785074694791), np.uint64(14029467366897019727), np.uint64(2870177450012600261)
