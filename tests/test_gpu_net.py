@@ -67,6 +67,17 @@ def test_patch_embedding_on_the_256_tile_kernel(cuda):
     out, st = ops.gemm_ln(A, W, "pos", bias, pos, want_stats=True)
     plain = ops.gemm(A, W, "pos", bias, pos)
     assert torch.equal(out, plain)
+    # race screen of the odd-K-tile tail (LDS-DMA behind counted vmcnt, raw barriers): repeated launches under a concurrent
+    # memory stream stay bitwise identical
+    noise = torch.empty((8192, 8192), device=cuda)
+    side = torch.cuda.Stream(cuda)
+    for i in range(16):
+        if i % 4 == 0:
+            with torch.cuda.stream(side):
+                noise.normal_()
+        o2, s2 = ops.gemm_ln(A, W, "pos", bias, pos, want_stats=True)
+        assert torch.equal(o2, out) and torch.equal(s2, st), i
+    side.synchronize()
     with _lib.use_debug_library() as L:
         L.cpx_gemm_set_big(0)
         try:
