@@ -93,7 +93,7 @@ def physical_core_cpus() -> list[int]:
     return out or allowed
 
 
-def measure_traffic_live(timeout_s: float = 180.0):
+def measure_traffic_live(timeout_s: float = 90.0):
     """HBM-side bytes per launch of the dominant kernel, measured NOW on this box: two rocprofv3 --pmc passes (FETCH_SIZE,
     WRITE_SIZE -- separate passes, they do not fit one; kernel-trace only) over tools/pmc_fc1.py, which runs mlp.lin1 of one
     8-tile batch alone.  PMC counters cannot be read from inside this process, so the passes run as child processes (the
