@@ -130,6 +130,16 @@ __device__ __forceinline__ unsigned short to_half(float f) {
     if constexpr (F16) { _Float16 h = (_Float16)f; return *reinterpret_cast<unsigned short *>(&h); }
     else return f32_to_bf16(f);
 }
+// two f32 -> one dword of two halves (lo = a, hi = b) in ONE instruction: the scalar to_half pair above lowers to two
+// conversions with a dead second source plus a shift and an SDWA OR (4 VALU slots per dword in the epilogues' ISA).
+// Same rounding as to_half (round to nearest even; the instruction the compiler itself picks for the scalar cast).
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    unsigned r;
+    if constexpr (F16) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <bool F16>
 __device__ __forceinline__ float from_half(unsigned short u) {
     if constexpr (F16) { return (float)*reinterpret_cast<_Float16 *>(&u); }
@@ -300,8 +310,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(GemmArgs g) {
                 }
             } else {
                 uint2 o;
-                o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
-                o.y = (unsigned)to_half<F16>(v[2]) | ((unsigned)to_half<F16>(v[3]) << 16);
+                o.x = pack2<F16>(v[0], v[1]);
+                o.y = pack2<F16>(v[2], v[3]);
                 *reinterpret_cast<uint2 *>((unsigned short *)g.out + (size_t)m * g.ld_out + n) = o;
             }
         }
@@ -360,7 +370,9 @@ __device__ __forceinline__ void g2_read_w(u32x4 (&fw)[2][2], unsigned b0, unsign
     fw[0][0] = lds_read128<(2 + HN) * G2_HALF + 0 * 2048>(b0); fw[0][1] = lds_read128<(2 + HN) * G2_HALF + 0 * 2048>(b1);
     fw[1][0] = lds_read128<(2 + HN) * G2_HALF + 1 * 2048>(b0); fw[1][1] = lds_read128<(2 + HN) * G2_HALF + 1 * 2048>(b1);
 }
-template <bool F16>
+// FIRST: the quadrant's first K step of a tile -- the accumulators START as the product (C operand = the inline constant 0)
+// instead of being cleared by 128 v_mov_b32 per lane in front of every tile
+template <bool F16, bool FIRST = false>
 __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][2], const u32x4 (&fw)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -368,7 +380,8 @@ __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma16v<F16>(fw[nb][ks], fx[mb][ks], acc[mb][nb]);
+            for (int nb = 0; nb < 2; ++nb)
+                acc[mb][nb] = mfma16v<F16>(fw[nb][ks], fx[mb][ks], (FIRST && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][nb]);
     __builtin_amdgcn_s_setprio(0);
 }
 #define G2_BAR() __builtin_amdgcn_s_barrier()
@@ -600,13 +613,15 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                         v[0] += pe.x; v[1] += pe.y; v[2] += pe.z; v[3] += pe.w;
                     }
                     if constexpr (VT) {          // transposed image [channel][token] for the V^T layout
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            *reinterpret_cast<unsigned short *>(smem + (nl + r) * G2_EPI_LD + ml * 2) = to_half<F16>(v[r]);
+                        const unsigned p01 = pack2<F16>(v[0], v[1]), p23 = pack2<F16>(v[2], v[3]);
+                        *reinterpret_cast<unsigned short *>(smem + (nl + 0) * G2_EPI_LD + ml * 2) = (unsigned short)p01;
+                        *reinterpret_cast<unsigned short *>(smem + (nl + 1) * G2_EPI_LD + ml * 2) = (unsigned short)(p01 >> 16);
+                        *reinterpret_cast<unsigned short *>(smem + (nl + 2) * G2_EPI_LD + ml * 2) = (unsigned short)p23;
+                        *reinterpret_cast<unsigned short *>(smem + (nl + 3) * G2_EPI_LD + ml * 2) = (unsigned short)(p23 >> 16);
                     } else {
                         uint2 o;
-                        o.x = (unsigned)to_half<F16>(v[0]) | ((unsigned)to_half<F16>(v[1]) << 16);
-                        o.y = (unsigned)to_half<F16>(v[2]) | ((unsigned)to_half<F16>(v[3]) << 16);
+                        o.x = pack2<F16>(v[0], v[1]);
+                        o.y = pack2<F16>(v[2], v[3]);
                         if (DBG && EPI != CPX_EPI_RESID_BF16 && (g.dbg & 8)) {
                             // EXPERIMENT (timing + correctness switch): no LDS staging.  Lanes fq and fq^1 (16 lanes
                             // apart) trade one 8-byte piece so that each holds 8 consecutive channels -- the even
@@ -655,7 +670,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
                 for (int i = 0; i < 4; ++i) {
                     float lo = from_half<F16>(a[i] & 0xFFFF) + from_half<F16>(b[i] & 0xFFFF);
                     float hi = from_half<F16>(a[i] >> 16) + from_half<F16>(b[i] >> 16);
-                    a[i] = (unsigned)to_half<F16>(lo) | ((unsigned)to_half<F16>(hi) << 16);
+                    a[i] = pack2<F16>(lo, hi);
                 }
                 v = make_uint4(a[0], a[1], a[2], a[3]);
             }
@@ -825,45 +840,39 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         G2_BAR();
         if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
 
-        f32x4 acc[2][2][4][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[2][2][4][2];                       // not cleared: K tile 0 is peeled and starts every accumulator with C = 0
         u32x4 fx[4][2], fw[2][2];
-#define G2_TILE(T, B)                                                                       \
+#define G2_TILE(T, B, FIRST)                                                                       \
     {                                                                                       \
         const int t_ = (T);                                                                 \
         g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
         g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                               \
         if (t_ + 1 < nk) stage(1, t_ + 1);                                                  \
         G2_BAR(); G2_LGKM0();                                                               \
-        g2_mma<F16>(acc[0][0], fx, fw);                                                     \
+        g2_mma<F16, FIRST>(acc[0][0], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
         g2_read_w<1>(fw, wb[B][0], wb[B][1]);                                               \
         if (t_ + 1 < nk) stage(2, t_ + 1);                                                  \
         G2_BAR(); G2_LGKM0();                                                               \
-        g2_mma<F16>(acc[0][1], fx, fw);                                                     \
+        g2_mma<F16, FIRST>(acc[0][1], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
         g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                               \
         if (t_ + 2 < nk) stage(0, t_ + 2);                                                  \
         G2_BAR(); G2_LGKM0();                                                               \
-        g2_mma<F16>(acc[1][1], fx, fw);                                                     \
+        g2_mma<F16, FIRST>(acc[1][1], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
         g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
         if (t_ + 2 < nk) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
         else if (t_ + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
         G2_BAR(); G2_LGKM0();                                                               \
-        g2_mma<F16>(acc[1][0], fx, fw);                                                     \
+        g2_mma<F16, FIRST>(acc[1][0], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
     }
-        for (int t = 0; t < nk; t += 2) {
-            G2_TILE(t, 0)
-            G2_TILE(t + 1, 1)
+        G2_TILE(0, 0, true)
+        G2_TILE(1, 1, false)
+        for (int t = 2; t < nk; t += 2) {
+            G2_TILE(t, 0, false)
+            G2_TILE(t + 1, 1, false)
         }
 #undef G2_TILE
         if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
@@ -911,9 +920,11 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                                 vv[0] += b.x; vv[1] += b.y; vv[2] += b.z; vv[3] += b.w;
                             }
                             // (tail reads above complete before the staging writes below reach the tail: rows < 256)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                *reinterpret_cast<unsigned short *>(smem + (nl + r) * G2_EPI_LD + ml * 2) = to_half<F16>(vv[r]);
+                            const unsigned p01 = pack2<F16>(vv[0], vv[1]), p23 = pack2<F16>(vv[2], vv[3]);
+                            *reinterpret_cast<unsigned short *>(smem + (nl + 0) * G2_EPI_LD + ml * 2) = (unsigned short)p01;
+                            *reinterpret_cast<unsigned short *>(smem + (nl + 1) * G2_EPI_LD + ml * 2) = (unsigned short)(p01 >> 16);
+                            *reinterpret_cast<unsigned short *>(smem + (nl + 2) * G2_EPI_LD + ml * 2) = (unsigned short)p23;
+                            *reinterpret_cast<unsigned short *>(smem + (nl + 3) * G2_EPI_LD + ml * 2) = (unsigned short)(p23 >> 16);
                         }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G2_BAR();
@@ -985,8 +996,8 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                                 for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
                             }
                             uint2 o;
-                            o.x = (unsigned)to_half<F16>(vv[0]) | ((unsigned)to_half<F16>(vv[1]) << 16);
-                            o.y = (unsigned)to_half<F16>(vv[2]) | ((unsigned)to_half<F16>(vv[3]) << 16);
+                            o.x = pack2<F16>(vv[0], vv[1]);
+                            o.y = pack2<F16>(vv[2], vv[3]);
                             *reinterpret_cast<uint2 *>(buf + mlh * 272 + nq * 2) = o;
                         }
                     }
@@ -1056,8 +1067,8 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                                 for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
                             }
                             uint2 o;
-                            o.x = (unsigned)to_half<F16>(vv[0]) | ((unsigned)to_half<F16>(vv[1]) << 16);
-                            o.y = (unsigned)to_half<F16>(vv[2]) | ((unsigned)to_half<F16>(vv[3]) << 16);
+                            o.x = pack2<F16>(vv[0], vv[1]);
+                            o.y = pack2<F16>(vv[2], vv[3]);
                             *reinterpret_cast<uint2 *>(stg + mlh * G2_EPI_LD + nl * 2) = o;
                         }
                     }
@@ -1076,7 +1087,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                         for (int i = 0; i < 4; ++i) {
                             float lo = from_half<F16>(a[i] & 0xFFFF) + from_half<F16>(b[i] & 0xFFFF);
                             float hi = from_half<F16>(a[i] >> 16) + from_half<F16>(b[i] >> 16);
-                            a[i] = (unsigned)to_half<F16>(lo) | ((unsigned)to_half<F16>(hi) << 16);
+                            a[i] = pack2<F16>(lo, hi);
                         }
                         vv = make_uint4(a[0], a[1], a[2], a[3]);
                     }
@@ -1374,8 +1385,8 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmArgs g) {
                     for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
                 }
                 uint2 o;
-                o.x = (unsigned)to_half<F16>(vv[0]) | ((unsigned)to_half<F16>(vv[1]) << 16);
-                o.y = (unsigned)to_half<F16>(vv[2]) | ((unsigned)to_half<F16>(vv[3]) << 16);
+                o.x = pack2<F16>(vv[0], vv[1]);
+                o.y = pack2<F16>(vv[2], vv[3]);
                 *reinterpret_cast<uint2 *>(smem + ml * PP_EPI_LD + nl * 2) = o;
             }
         }
