@@ -1051,6 +1051,9 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         return CPX_OK;
     }
 #endif
+#ifdef CPX_DEBUG
+    if (g_att_v8 == 3) return cpx_attention2q_launch(dtype, qkv, vT_ws, rel_h, rel_w, n_subtiles, out, s);   // round-4 experiment
+#endif
     const dim3 grid4(8, 16, n_subtiles);
     static CpxOncePerDevice once4;
     once4([] {
