@@ -103,18 +103,41 @@ def measure_traffic_live(timeout_s: float = 90.0):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
+    # never from under a profiler: a rocprofv3 started from a process that is itself running under rocprofv3 inherits the
+    # outer tool's LD_PRELOAD / ROCP_TOOL_LIBRARIES, its launcher initialises the GPU and then execs -- which takes the
+    # box down on this pool -- and the nested passes would pollute the outer counters anyway
+    def _profiler_var(k):
+        return k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB") or k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_", "ROCTRACER"))
+    if any(_profiler_var(k) and os.environ.get(k) for k in os.environ):
+        return None
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
+    child_env = {k: v for k, v in os.environ.items() if not _profiler_var(k)}
+    child_env["TMPDIR"] = "/tmp"
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="cpx_pmc_", dir="/tmp")
         try:
-            subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
-                            os.path.join(ROOT, "tools", "pmc_fc1.py")], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            # own session: on a timeout the WHOLE group goes (rocprofv3 may spawn its target rather than exec it, and an
+            # orphaned pmc_fc1.py would keep the GPU busy under the side lines)
+            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
+                                     os.path.join(ROOT, "tools", "pmc_fc1.py")], cwd="/tmp", env=child_env,
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
             tot, n = 0.0, 0
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:
@@ -361,7 +384,7 @@ def main():
         if traffic_detail is not None:
             traffic, traffic_src = traffic_detail["traffic"], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over tools/pmc_fc1.py"
     if traffic is None:
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["traffic_bytes_per_launch"]
@@ -370,22 +393,40 @@ def main():
             except Exception:
                 pass
 
-    # ---- per-stage roofline (after the timed region, so the extra event pairs do not touch the headline)
+    # ---- per-stage roofline (after the timed region, so the extra event pairs do not touch the headline).
+    # Rounds 2 and 3 reported one bogus stage each in the driver's run (post-processing 5.03 ms, proj 0.518 ms): this pass
+    # had NO warm-up -- it starts a fresh TileStream (new pinned buffers, reader threads) inside the measured steps -- and
+    # reported a plain mean, so a single event pair that straddled a host stall or a clock ramp owned the figure.  Now:
+    # two untimed warm-up steps on the SAME TileStream, every launch's own duration (cpx_prof_collect_launches), frac from
+    # the MEDIAN, min / max beside it and an `outlier` flag when max > 3 x median.
     stages = None
+    kernel_time_sum = None
     if rank == 0 and not args.no_stages:
         stages = {}
-        prof2 = C.c_void_p()
-        _lib.check(L.cpx_prof_create(6 * args.depth * 5 + 8, 1, 0x1F, C.byref(prof2)), "prof_create")
         n6 = min(6, n_distinct)
-        timed_run(eng, n6, 0, inject=True, prof=prof2)
-        _lib.check(L.cpx_prof_collect(prof2, ms_k, cnt_k), "prof_collect")
+        cap = n6 * args.depth * 5 + 8
+        prof2 = C.c_void_p()
+        _lib.check(L.cpx_prof_create(cap, 1, 0x1F, C.byref(prof2)), "prof_create")
+        timed_run(eng, n6, 2, inject=True, prof=prof2)
+        ms_l, kind_l, n_l = (C.c_float * cap)(), (C.c_int * cap)(), C.c_int(0)
+        _lib.check(L.cpx_prof_collect_launches(prof2, ms_l, kind_l, cap, C.byref(n_l)), "prof_collect_launches")
         L.cpx_prof_destroy(prof2)
+        n_l = min(n_l.value, cap)
+        per_kind = {k: [] for k in range(len(_lib.PROF_KINDS))}
+        for i in range(n_l):
+            per_kind[kind_l[i]].append(float(ms_l[i]))
+        kernel_time_sum = 0.0
         for k, name in enumerate(_lib.PROF_KINDS):
-            if cnt_k[k]:
-                ms = ms_k[k] / cnt_k[k]
-                tf = FLOPS[name](M) / (ms * 1e-3) / 1e12
-                stages[name] = {"bound": "mfma", "avg_launch_ms": round(ms, 4), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_timed": cnt_k[k]}
+            v = sorted(per_kind[k])
+            if not v:
+                continue
+            med = v[len(v) // 2]
+            tf = FLOPS[name](M) / (med * 1e-3) / 1e12
+            kernel_time_sum += med * args.depth
+            stages[name] = {"bound": "mfma", "launch_ms": {"min": round(v[0], 4), "median": round(med, 4), "max": round(v[-1], 4)},
+                            "avg_launch_ms": round(sum(v) / len(v), 4), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_timed": len(v),
+                            "outlier": bool(v[-1] > 3.0 * med)}
         stages["post_processing"] = post_stage(L, eng, fields[0], bt, dev)
 
     # ---- side lines (N = 1): --precision fp32, and the network's own fields instead of the injected ones
@@ -446,6 +487,9 @@ def main():
     }
     if stages is not None:
         line["roofline"]["stages"] = stages
+        # the five per-layer kernels at their median launch time x depth: the part of ms_per_step the network stream spends
+        # in them (must be <= ms_per_step; the rest is the small kernels: patch embedding, neck, head, blend, normalise)
+        line["roofline"]["kernel_time_sum_ms_per_step"] = round(kernel_time_sum, 3)
     if side is not None:
         line["side_lines"] = side
     if rank == 0:

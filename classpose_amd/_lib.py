@@ -96,6 +96,7 @@ SIGNATURES = {
     "cpx_unet_head_forward": (_i, [C.POINTER(CpxConvOp), _i, _p, _i, _p, _i, _i, _i, _p, _sz, _p]),
     "cpx_prof_create": (_i, [_i, _i, C.c_uint, C.POINTER(C.c_void_p)]),
     "cpx_prof_collect": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "cpx_prof_collect_launches": (_i, [_p, C.POINTER(C.c_float), C.POINTER(C.c_int), _i, C.POINTER(C.c_int)]),
     "cpx_prof_destroy": (None, [_p]),
     "cpx_gemm": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
     "cpx_gemm_uses_big_tile": (_i, [_i, _i, _i, _i]),

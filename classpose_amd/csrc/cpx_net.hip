@@ -1166,6 +1166,18 @@ extern "C" int cpx_prof_collect(void *prof, double *ms_sum, int *count) {
     p->n = 0;
     return CPX_OK;
 }
+// every timed launch since the last collect, in launch order: ms[i] / kind[i] for i < min(n, cap), *n_out = n.  Does not reset
+// (call it before cpx_prof_collect); after a stream sync.  bench.py turns these into min / median / max per stage.
+extern "C" int cpx_prof_collect_launches(void *prof, float *ms, int *kind, int cap, int *n_out) {
+    CpxProf *p = (CpxProf *)prof;
+    CPX_REQUIRE(p && ms && kind && n_out && cap >= 0);
+    for (int i = 0; i < p->n && i < cap; ++i) {
+        CPX_HIP(hipEventElapsedTime(&ms[i], p->ev[2 * i], p->ev[2 * i + 1]));
+        kind[i] = p->kind[i];
+    }
+    *n_out = p->n;
+    return CPX_OK;
+}
 extern "C" void cpx_prof_destroy(void *prof) {
     CpxProf *p = (CpxProf *)prof;
     if (!p) return;

@@ -200,6 +200,9 @@ int cpx_net_forward(const cpx_net_weights *w_host, const void *patches, int n_su
 #define CPX_PROF_N_KINDS 5
 int cpx_prof_create(int max_launches, int stride, unsigned kinds_mask, void **prof_out);
 int cpx_prof_collect(void *prof, double *ms_sum, int *count);
+/* the same launches one by one (launch order; ms[i], kind[i] for i < min(n, cap); *n_out = n; no reset: call it before
+ * cpx_prof_collect) -- bench.py reports min / median / max per stage from these                                      */
+int cpx_prof_collect_launches(void *prof, float *ms, int *kind, int cap, int *n_out);
 void cpx_prof_destroy(void *prof);
 
 /* ------------------------------------------------------------------------

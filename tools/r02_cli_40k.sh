@@ -2,7 +2,7 @@
 # the CLI end to end on the 40 000 x 40 000 synthetic slide (configs[2] geometry, 1 GPU): plain (random weights, few cells)
 # and with the synth plug-in (2.5 M cells: exercises records, device polygons, device de-duplication, GeoJSON)
 set -u
-R=$GRAFT_REPO_ROOT
+R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
 O=$R/gpurun_out
 export CLASSPOSE_SYNTHETIC_WEIGHTS=1 CLASSPOSE_MODEL_DIR=/tmp/nomodels
 for MODE in plain plugin; do

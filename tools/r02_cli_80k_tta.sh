@@ -1,7 +1,7 @@
 #!/bin/bash
 # BASELINE configs[3] geometry on ONE GPU (the config itself names 8): synthetic 80 000^2 slide, conic, --tta, random weights
 set -u
-R=$GRAFT_REPO_ROOT
+R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
 export CLASSPOSE_SYNTHETIC_WEIGHTS=1 CLASSPOSE_MODEL_DIR=/tmp/nomodels
 rm -rf /tmp/out80; mkdir -p /tmp/out80
 T0=$(date +%s)

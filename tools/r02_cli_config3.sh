@@ -2,7 +2,7 @@
 # BASELINE configs[2] through the CLI on one GPU: synthetic 40 000^2 slide at 0.22 um/px, puma, default 1024 / 64 tiles,
 # GrandQC tissue + artefact detection (class maps from the synth plug-in: the GrandQC weights are random), artefact filter, csv
 set -u
-R=$GRAFT_REPO_ROOT
+R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
 export CLASSPOSE_SYNTHETIC_WEIGHTS=1 CLASSPOSE_MODEL_DIR=/tmp/nomodels CLASSPOSE_AMD_PLUGINS=classpose_amd.synth:flow+qc
 rm -rf /tmp/out3; mkdir -p /tmp/out3
 T0=$(date +%s)

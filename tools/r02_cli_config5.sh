@@ -1,7 +1,7 @@
 #!/bin/bash
 # BASELINE configs[4] geometry on ONE GPU (the config names 8): 512-px tiles, fp16, semantic head, synthetic 40 000^2 slide
 set -u
-R=$GRAFT_REPO_ROOT
+R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
 export CLASSPOSE_SYNTHETIC_WEIGHTS=1 CLASSPOSE_MODEL_DIR=/tmp/nomodels
 rm -rf /tmp/out5; mkdir -p /tmp/out5
 T0=$(date +%s)

@@ -3,11 +3,11 @@
 # separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA utilisation).  The program itself follows `--` (no wrapper).
 set -u
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
 O=$R/gpurun_out/r03prof
 mkdir -p $O
-B="python3 $R/bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-side-lines"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-side-lines > $O/stats.log 2>&1
+B="python3 $R/bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-side-lines --no-live-traffic"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-side-lines --no-live-traffic > $O/stats.log 2>&1
 rocprofv3 -L > $O/counters.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -o run -- $B > $O/pmc_$C.log 2>&1

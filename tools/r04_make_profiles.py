@@ -1,11 +1,11 @@
-"""Builds profiles/r03_pmc_mfma.json, profiles/r03_pmc_traffic.json and profiles/r03_bench_kernel_stats.csv from what
-tools/r03_profile.sh left under gpurun_out/r03prof (pmc_table.json = per-kernel counter averages, kernel_stats.csv = the
+"""Builds profiles/r04_pmc_mfma.json, profiles/r04_pmc_traffic.json and profiles/r04_bench_kernel_stats.csv from what
+tools/r04_profile.sh left under gpurun_out/r04prof (pmc_table.json = per-kernel counter averages, kernel_stats.csv = the
 rocprofv3 --kernel-trace --stats summary of the same bench command).
-usage: python tools/r03_make_profiles.py [gpurun_out/r03prof]"""
+usage: python tools/r04_make_profiles.py [gpurun_out/r04prof]"""
 import csv, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03prof")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04prof")
 tab = json.load(open(os.path.join(src, "pmc_table.json")))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv")))}
 
@@ -70,21 +70,21 @@ for prefix, what, flops, abytes in KERNELS:
     out[k] = e
 
 note = ("rocprofv3 --pmc passes of `python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-side-lines --no-live-traffic` "
-        "(tools/r03_profile.sh; one pass per counter group, kernel-trace only; averages per launch over all launches of the "
-        "kernel; assembled by tools/r03_make_profiles.py). MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) "
+        "(tools/r04_profile.sh; one pass per counter group, kernel-trace only; averages per launch over all launches of the "
+        "kernel; assembled by tools/r04_make_profiles.py). MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) "
         "x 1024 SIMDs): the fraction of SIMD cycles in which the matrix pipe executes (rocprofv3's own MfmaUtil formula; "
         "GRBM_GUI_ACTIVE is the sum over the 8 XCDs, MI355X_MICROARCH 'DVFS give-back'). effective_clock_GHz = "
         "(GRBM_GUI_ACTIVE / 8) / average kernel duration from the --kernel-trace --stats pass of the same command "
-        "(profiles/r03_bench_kernel_stats.csv). frac_of_2.5PF = algorithmic flops / that duration / 2.5 PFLOP/s: what "
+        "(profiles/r04_bench_kernel_stats.csv). frac_of_2.5PF = algorithmic flops / that duration / 2.5 PFLOP/s: what "
         "bench.py's roofline.frac measures with HIP events. FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request "
         "for wide coalesced / LDS-DMA reads).")
-json.dump({"note": note, "kernels": out}, open(os.path.join(ROOT, "profiles", "r03_pmc_mfma.json"), "w"), indent=1)
+json.dump({"note": note, "kernels": out}, open(os.path.join(ROOT, "profiles", "r04_pmc_mfma.json"), "w"), indent=1)
 
 dom = find(tab, KERNELS[0][0])
 fetch = tab[dom]["FETCH_SIZE"] * 1024 * 2
 write = tab[dom]["WRITE_SIZE"] * 1024
 traffic = {
-    "note": ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/r03_profile.sh) of `bench.py --steps 4 "
+    "note": ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/r04_profile.sh) of `bench.py --steps 4 "
              "--warmup 2`; KB per launch averaged over all launches. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
              "counts 64 B per 128-B request for wide coalesced / LDS-DMA reads -> doubled. FETCH_SIZE is the L2's fabric-side "
              "traffic and includes Infinity-Cache hits (the W panels, 8.4 MB, and most of the 67 MB activation panel stay "
@@ -97,23 +97,23 @@ traffic = {
     "kernels": {k: {"FETCH_SIZE_KB_avg_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_avg_per_launch": v["WRITE_SIZE"],
                     "launches": int(v["launches"])} for k, v in tab.items()},
 }
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
-shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv"))
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), "w"), indent=1)
+shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv"))
 for k, e in out.items():
     print(f"{k[:44]:46s} MfmaUtil {e['MfmaUtil_percent']:5.1f}%  {e.get('avg_duration_us_kernel_trace', 0):7.1f} us  "
           f"frac {e.get('frac_of_2.5PF', 0):.3f}  clock {e.get('effective_clock_GHz', 0):.3f} GHz")
 
 # post-processing chain alone: sum of kernel time per 8-tile batch (tools/run_post.py runs 12 iterations)
 try:
-    post = os.path.join(ROOT, "gpurun_out", "r03post", "kernel_stats.csv")
+    post = os.path.join(ROOT, "gpurun_out", "r04post", "kernel_stats.csv")
     rows = list(csv.DictReader(open(post)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / 12 / 1e3
     calls = sum(int(r["Calls"]) for r in rows) / 12
     json.dump({"sum_of_kernel_time_us_per_8_tile_batch": round(tot, 1), "kernel_launches_per_batch": calls,
                "source": "rocprofv3 --kernel-trace --stats -- python3 tools/run_post.py (12 iterations of cpx_compute_masks on one 8-tile batch; "
-                         "tools/r03_profile.sh); per-kernel table: profiles/r03_post_kernel_stats.csv"},
-              open(os.path.join(ROOT, "profiles", "r03_post_kernel_sum.json"), "w"), indent=1)
-    shutil.copy(post, os.path.join(ROOT, "profiles", "r03_post_kernel_stats.csv"))
+                         "tools/r04_profile.sh); per-kernel table: profiles/r04_post_kernel_stats.csv"},
+              open(os.path.join(ROOT, "profiles", "r04_post_kernel_sum.json"), "w"), indent=1)
+    shutil.copy(post, os.path.join(ROOT, "profiles", "r04_post_kernel_stats.csv"))
     print(f"post-processing: {tot:.1f} us of kernel time per 8-tile batch, {calls:.1f} launches")
 except Exception as e:
     print("no post-processing stats:", e)

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-2 profile collection (run on the GPU box from the repo root): kernel-trace stats of the bench command and
+# Round-4 profile collection (run on the GPU box from the repo root): kernel-trace stats of the bench command and
 # separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA utilisation).  The program itself follows `--` (no wrapper).
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
-O=$R/gpurun_out/r02prof
+O=$R/gpurun_out/r04prof
 mkdir -p $O
-B="python3 $R/bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-stages"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/stats.log 2>&1
+B="python3 $R/bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-side-lines --no-live-traffic"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-side-lines --no-live-traffic > $O/stats.log 2>&1
 rocprofv3 -L > $O/counters.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -o run -- $B > $O/pmc_$C.log 2>&1
@@ -23,3 +23,12 @@ grep -i "mfma" $O/counters.txt | head -40 > $O/mfma_counters.txt
 find $O -type f \( -name "*kernel_trace.csv" -o -name "*.db" -o -name "*counter_collection.csv" -o -name "*agent_info.csv" \) -delete
 find $O -type f -size +1M -delete
 du -sh $O; du -sh $R/gpurun_out
+# post-processing chain alone (tools/run_post.py: 12 iterations of compute_masks on one 8-tile batch) under the same tracer
+cd /tmp
+P=$R/gpurun_out/r04post
+rm -rf $P; mkdir -p $P
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o run -- python3 $R/tools/run_post.py > $P/stats.log 2>&1
+find $P/stats -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
+find $P -type f \( -name "*kernel_trace.csv" -o -name "*.db" -o -name "*agent_info.csv" \) -delete
+cd $R
+python3 tools/r04_make_profiles.py > $O/make_profiles.log 2>&1; cat $O/make_profiles.log
