@@ -322,6 +322,8 @@ def main():
             dbg_t.append(time.perf_counter())
             print("BENCH_DEBUG host ms between loop iterations:", [round((b - a) * 1e3, 1) for a, b in zip(dbg_t, dbg_t[1:])], file=sys.stderr)
 
+    rec_counts: list[int] = []                # records every rank contributed to the timed run's all-gather
+
     def timed_run(e, n_steps, n_warm, inject=True, prof=None, collective=False):
         """ONE TileStream over warm-up + timed batches (its reader / copy threads pay their one-off HIP thread start-up
         during the warm-up); a gate keeps it from reading or copying any timed batch before the clock starts."""
@@ -344,6 +346,7 @@ def main():
             if collective:
                 # the path's one exchange: per-cell records of this rank's shard -> every rank (RCCL)
                 rec = rec_keep[-1].reshape(-1, rec_bytes)
+                rec_counts[:] = parallel.all_gather_counts(rec.shape[0], dev)
                 allrec = parallel.all_gather_records(rec)
             torch.cuda.synchronize(dev)
             if collective:
@@ -465,6 +468,13 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
+        "build_id": _lib.build_id(),
+        # what a scaling run needs to show that N ranks really exchanged over RCCL: the collective backend, the tiles every
+        # rank processed in the timed steps (steps x tiles_per_step each: weak scaling) and the records each rank contributed
+        # to the all-gather (their sum = config.records_gathered on every rank)
+        "distributed": {"world": world, "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                        "tiles_per_rank": [steps * bt] * world, "shard_tiles_per_rank": [len(range(r, len(coords), world)) for r in range(world)],
+                        "records_per_rank": list(rec_counts), "device": torch.cuda.get_device_name(dev)},
         "cells_per_sec": cells / dt,
         "network_tflops": n_tiles * flop_per_tile / dt / 1e12 / world,
         "config": {"workload": "%s: synthetic %dx%d WSI (%d tiles), tile 256 / overlap 32, "

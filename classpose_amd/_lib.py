@@ -81,6 +81,7 @@ _p, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 SIGNATURES = {
     "cpx_abi_version": (_i, []),
     "cpx_last_error": (C.c_char_p, []),
+    "cpx_build_id": (C.c_char_p, []),
     "cpx_normalize_stats_u8": (_i, [_p, _i, _i, _i, _i, _f, _i, _f, _p, _p, _p]),
     "cpx_normalize_apply_u8": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "cpx_resize_linear_u8": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
@@ -166,6 +167,34 @@ def build(force: bool = False) -> str:
         subprocess.check_call(["make", "-C", CSRC, "clean", "-s"])
     subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
     return LIB_PATH
+
+
+def source_build_id() -> str:
+    """What ``cpx_build_id()`` of a library built from the sources on disk returns (csrc/Makefile: BUILD_ID)."""
+    import glob
+    import hashlib
+    names = sorted(os.path.basename(f) for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(CSRC, pat)))
+    names = sorted(names + ["Makefile"])
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    for f in [os.path.join(CSRC, n) for n in names] + [os.path.join(inc, "classpose_hip.h"), os.path.join(inc, "classpose_hip_debug.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_id() -> str:
+    """``cpx_build_id()`` of the loaded library; a mismatch with the sources on disk is reported once on stderr (the .so
+    files are git-ignored and travel with snapshots: this is how a stale one shows)."""
+    bid = lib().cpx_build_id().decode()
+    try:
+        src = source_build_id()
+    except OSError:
+        return bid
+    if bid.split("+")[0] != src:
+        import sys
+        print(f"classpose_amd: {bid} was not built from the sources on disk ({src}): run `make -C classpose_amd/csrc`", file=sys.stderr)
+    return bid
 
 
 def _load(path: str, signatures: dict):

@@ -359,16 +359,21 @@ def canonical_cell_order(cells: np.ndarray, xy: np.ndarray, tiles: np.ndarray) -
 
 
 def gather_cells(cells: np.ndarray, xy: np.ndarray, device, tiles: np.ndarray | None = None):
-    """The path's one collective: per-rank cell tables + vertex pools (+ the cells' tile indices) -> every rank."""
+    """The path's one exchange (north_star: "RCCL only to all-gather the per-tile centroid / class tensors"):
+    the 48-byte cell rows (centroid, class, area, perimeter, vertex count) and the cells' tile indices go to EVERY rank
+    (one padded all-gather each); the polygon vertex pools -- ~0.5 KB per cell, needed by the writing rank only -- go to
+    rank 0 by point-to-point sends and never leave the device on the other ranks.  Returns (cells, xy, tiles); xy is None
+    on ranks other than 0."""
     c = torch.from_numpy(cells.view(np.uint8).reshape(len(cells), CELL_ROW.itemsize).copy()).to(device)
-    v = torch.from_numpy(np.ascontiguousarray(xy).view(np.uint8).reshape(len(xy), 16).copy()).to(device)
     c = parallel.all_gather_records(c).cpu().numpy()
-    v = parallel.all_gather_records(v).cpu().numpy()
-    out = (c.reshape(-1).view(CELL_ROW), v.reshape(-1).view(np.float64).reshape(-1, 2))
+    out_cells = c.reshape(-1).view(CELL_ROW)
+    v = torch.from_numpy(np.ascontiguousarray(xy).view(np.uint8).reshape(len(xy), 16).copy()).to(device)
+    v = parallel.gather_to_root(v, 0)
+    out_xy = None if v is None else v.cpu().numpy().reshape(-1).view(np.float64).reshape(-1, 2)
     if tiles is None:
-        return out
+        return out_cells, out_xy
     t = torch.from_numpy(np.ascontiguousarray(tiles, dtype=np.int64).view(np.uint8).reshape(len(tiles), 8).copy()).to(device)
-    return out + (parallel.all_gather_records(t).cpu().numpy().reshape(-1).view(np.int64),)
+    return out_cells, out_xy, parallel.all_gather_records(t).cpu().numpy().reshape(-1).view(np.int64)
 
 
 def _qc_override(kind: str):
@@ -561,9 +566,12 @@ def main(args, spawned: bool = False, parser_factory=None):
     cells, xy, labels, plan = run_rank(args, rank, world, device)
     tiles = plan.cell_tiles
     if world > 1:
+        n_local = len(cells)
         cells, xy, tiles = gather_cells(cells, xy, device, tiles)
-    cells, xy = canonical_cell_order(cells, xy, tiles)
+        logger.info(f"[rank {rank}] exchange over {torch.distributed.get_backend()}: {n_local} local cells -> {len(cells)} cell rows on "
+                    f"every rank; vertex pool {'%d vertices on rank 0' % len(xy) if xy is not None else 'sent to rank 0'}")
     if rank == 0:
+        cells, xy = canonical_cell_order(cells, xy, tiles)
         write_outputs(args, cells, xy, labels, plan, device)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()

@@ -65,16 +65,24 @@ class ClassposeModel:
                                   nclasses, self.weights.ncls)
         self.nclasses = self.weights.ncls
         self.max_batch_tiles = max_batch_tiles
+        # several Python threads may share one model and call eval concurrently (the reference's --inference_threads,
+        # predict_wsi.py:728-798): the weights are shared and read-only, every calling thread gets its OWN engine (work
+        # spaces, output slots, HIP streams), so concurrent calls overlap on the GPU instead of queueing behind a lock.
+        # The lock only guards the engine table.
         self._engines: dict = {}
-        self._lock = threading.Lock()       # several Python threads may share one model (predict_wsi.py:790)
+        self._lock = threading.Lock()
         self.timing = []
 
     def _engine(self, H, W, augment, tile_overlap, kw):
-        key = (H, W, bool(augment), float(tile_overlap), tuple(sorted(kw.items())))
-        if key not in self._engines:
-            self._engines[key] = engine.Engine(self.weights, H, W, batch_tiles=self.max_batch_tiles,
-                                               augment=augment, tile_overlap=tile_overlap, **kw)
-        return self._engines[key]
+        key = (threading.get_ident(), H, W, bool(augment), float(tile_overlap), tuple(sorted(kw.items())))
+        with self._lock:
+            eng = self._engines.get(key)
+        if eng is None:
+            eng = engine.Engine(self.weights, H, W, batch_tiles=self.max_batch_tiles,
+                                augment=augment, tile_overlap=tile_overlap, **kw)
+            with self._lock:
+                self._engines[key] = eng
+        return eng
 
     def eval(self, x, batch_size: int = 8, resample: bool = True, channels=None, channel_axis=None,
              z_axis=None, normalize=True, invert: bool = False, rescale=None, diameter=None,
@@ -99,23 +107,22 @@ class ClassposeModel:
             groups.setdefault(im.shape, []).append(i)
         kw = dict(niter=200 if not niter else int(niter), cellprob_threshold=cellprob_threshold,
                   flow_threshold=flow_threshold, min_size=min_size, max_size_fraction=max_size_fraction)
-        with self._lock:
-            for shape, idxs in groups.items():
-                eng = self._engine(shape[0], shape[1], augment, tile_overlap, kw)
-                for s in range(0, len(idxs), eng.nT):
-                    chunk = idxs[s:s + eng.nT]
-                    tiles = torch.from_numpy(np.stack([np.ascontiguousarray(imgs[i]) for i in chunk])).to(self.device)
-                    o = eng.run(tiles, records=False)
-                    masks = ops.masks_to_numpy(o.masks) if compute_masks else None
-                    cm = o.class_masks.cpu().numpy().astype(np.int64) if compute_masks else None
-                    dP, cp = o.dP.cpu().numpy(), o.cellprob.cpu().numpy()
-                    yc = o.logits.cpu().numpy() if o.logits is not None else None
-                    for k, i in enumerate(chunk):
-                        outs[i] = (masks[k].copy() if compute_masks else np.zeros(0),
-                                   (dx_to_circ(dP[k]), dP[k].copy(), cp[k].copy(),
-                                    yc[k].copy() if yc is not None else None, (1, *shape)),
-                                   cm[k].copy() if compute_masks else np.zeros(0),
-                                   np.zeros(256, np.float32))          # styles: noise in the reference (vit_sam.py:197)
+        for shape, idxs in groups.items():
+            eng = self._engine(shape[0], shape[1], augment, tile_overlap, kw)
+            for s in range(0, len(idxs), eng.nT):
+                chunk = idxs[s:s + eng.nT]
+                tiles = torch.from_numpy(np.stack([np.ascontiguousarray(imgs[i]) for i in chunk])).to(self.device)
+                o = eng.run(tiles, records=False)
+                masks = ops.masks_to_numpy(o.masks) if compute_masks else None
+                cm = o.class_masks.cpu().numpy().astype(np.int64) if compute_masks else None
+                dP, cp = o.dP.cpu().numpy(), o.cellprob.cpu().numpy()
+                yc = o.logits.cpu().numpy() if o.logits is not None else None
+                for k, i in enumerate(chunk):
+                    outs[i] = (masks[k].copy() if compute_masks else np.zeros(0),
+                               (dx_to_circ(dP[k]), dP[k].copy(), cp[k].copy(),
+                                yc[k].copy() if yc is not None else None, (1, *shape)),
+                               cm[k].copy() if compute_masks else np.zeros(0),
+                               np.zeros(256, np.float32))          # styles: noise in the reference (vit_sam.py:197)
         if is_list:
             return ([o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs])
         return outs[0]

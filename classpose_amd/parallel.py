@@ -76,6 +76,44 @@ def allreduce_sum(value: float, device) -> float:
     return float(t.item())
 
 
+def all_gather_counts(n_local: int, device) -> list[int]:
+    """How many records every rank contributes (one tiny all-gather; [n_local] without a process group)."""
+    if not dist.is_initialized():
+        return [int(n_local)]
+    dev = _coll_device(device)
+    n = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
+    counts = torch.empty(dist.get_world_size(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n)
+    return [int(c) for c in counts.tolist()]
+
+
+def gather_to_root(rec: torch.Tensor, root: int = 0) -> torch.Tensor | None:
+    """Variable-length GATHER of rows to one rank (point-to-point sends; nothing is padded, nothing reaches the other
+    ranks): what only the writing rank needs -- the polygon vertex pools, ~0.5 KB per cell, 5-6 GB on the 80 000^2 TTA
+    slide -- must not be all-gathered (round-3 review).  rec: [n_local, width] uint8 on this rank's device.  Returns
+    [sum n, width] in rank order on ``root`` (on rec's device), None elsewhere."""
+    if not dist.is_initialized():
+        return rec
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out_dev = rec.device
+    dev = _coll_device(rec.device)
+    counts = all_gather_counts(rec.shape[0], rec.device)
+    width = rec.shape[1]
+    if rank != root:
+        if counts[rank]:
+            dist.send(rec.to(dev).contiguous(), dst=root)
+        return None
+    parts = []
+    for r in range(world):
+        if r == root:
+            parts.append(rec.to(dev))
+        elif counts[r]:
+            buf = torch.empty((counts[r], width), dtype=torch.uint8, device=dev)
+            dist.recv(buf, src=r)
+            parts.append(buf)
+    return torch.cat(parts, 0).to(out_dev) if parts else rec
+
+
 def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
     """Variable-length all-gather of per-cell records.
 

@@ -45,6 +45,10 @@ extern "C" {
 int cpx_abi_version(void);
 /* Last HIP error string recorded by a failing call on this thread (host ptr). */
 const char *cpx_last_error(void);
+/* which sources this binary was built from: first 16 hex digits of the sha256 over classpose_amd/csrc/{*.hip,*.cpp,*.h,
+ * Makefile} (sorted by name) + include/classpose_hip.h + include/classpose_hip_debug.h ("+debug" appended by the
+ * -DCPX_DEBUG library).  classpose_amd._lib.source_build_id() recomputes it from the files on disk. */
+const char *cpx_build_id(void);
 
 /* ------------------------------------------------------------------------
  * a6  image normalisation

@@ -26,6 +26,22 @@ Parity status
   to the absent wheels only, so the qkv reshape, SDPA-with-bias semantics, bias einsum,
   block order, pixel shuffles, channel order / split and the tiling control flow of
   ``net.py`` / ``tiling.py`` are pinned (tests/test_oracle_network_pins.py).
+* HARDENED (round 4) -- the cellpose-derived restatements below cannot meet the wheels, but each is checked against an
+  INDEPENDENT implementation of the same definition from a library that is in the image
+  (tests/test_oracle_hardening.py): ``max_pool_nd`` == ``F.max_pool2d(k, 1, k // 2)``; ``binary_fill_holes`` (standing in
+  for ``fill_voids.fill``) == a 4-connected flood of the background from the border; ``fr_renumber`` == a literal
+  first-appearance pass; the fp64 heat diffusion == the literal torch-double ``_extend_centers_gpu`` loop (1e-12, same
+  keep / drop decisions); and ``compute_masks`` / ``compute_class_masks`` / ``normalize_img`` are frozen against themselves
+  (tests/golden/oracle_self_golden.npz, minted by tests/golden/make_oracle_self_golden.py) so that oracle drift is caught.
+* ORDER-UNDEFINED ON THE REFERENCE'S OWN GPU PATH (where "bit-exact with the reference" has no single meaning, and what the
+  oracle / the HIP kernels do instead): (1) ``get_masks_torch`` sorts the seeds with ``npts.argsort()`` -- torch's CUDA sort
+  is not stable, seeds with equal counts come out in an unspecified order and the later seed's 11 x 11 window overwrites the
+  earlier one: the oracle and k_seeds use the STABLE order (ties in raster order); (2) ``_extend_centers_gpu`` reduces the
+  9 neighbours with ``Tneigh.mean(axis=0)``: the summation order of a CUDA reduction is unspecified, results differ in the
+  last ulp of fp64: index order 0..8 here; (3) ``h1.index_put_(..., accumulate=True)`` adds integers (order-free); (4) the
+  greedy de-duplication walks a Python ``set`` of pairs (predict_wsi.py:923-965): CPython's slot order, reproduced exactly by
+  walking scipy's own set (classpose_amd.geojson.dedup_exact); (5) the reference's N-GPU run delivers tiles in whatever
+  order its shared queue yields them, which feeds (4): the canonical tile order of classpose_amd is ONE of those orders.
 * PARITY UNPINNED (no reference test holds a golden value, and the arithmetic
   lives in wheels that are absent from /root/reference and from this image):
   everything restated from ``cellpose==4.0.8`` (uv.lock:352) --

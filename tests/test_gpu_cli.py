@@ -77,6 +77,57 @@ def test_classpose_model_eval_api(cuda):
     assert np.array_equal(m1, masks[0]) and np.array_equal(c1, class_masks[0])
 
 
+def test_classpose_model_eval_parity_and_concurrency(cuda):
+    """ClassposeModel.eval (models.py:478-827 of the reference) against the oracle, for one tile and for a list: flows /
+    cellprob / class logits within the half-precision tolerance of the float32 oracle network, the id map bit-exact w.r.t.
+    the oracle dynamics on the RETURNED fields, class_masks == the oracle's class vote -- and two Python threads calling
+    eval on ONE model at the same time (the reference's --inference_threads, predict_wsi.py:790-797) get exactly what the
+    serial calls return (every thread runs its own engine on the shared weights; no lock around the GPU work)."""
+    import threading
+    from classpose_amd.models import ClassposeModel
+    from oracle import classmask, dynamics, net as onet, tiling
+    sd = synth.make_state_dict(7, None, depth=2, seed=12)
+    model = ClassposeModel(gpu=True, pretrained_model=sd, device=cuda, nclasses=7, precision="bf16")
+    tiles = [synth.render_region(77, 0, 0, 256, 256), synth.render_region(77, 300, 120, 256, 256),
+             synth.render_region(78, 40, 700, 256, 256)]
+    masks, flows, class_masks, styles = model.eval(tiles, batch_size=8, augment=False, bsize=256, compute_masks=True)
+    fw = onet.make_forward(sd)
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    for i, t in enumerate(tiles):
+        x = tiling.normalize_img(t[None])
+        dP, cp, yc = tiling.run_net(fw, x, batch_size=8)
+        _, dP_i, cp_i, yc_i, shp = flows[i]
+        assert rel(dP_i, dP) < 2e-2 and rel(cp_i, cp) < 2e-2 and rel(yc_i, yc) < 2e-2
+        ref = dynamics.compute_masks(dP_i, cp_i)
+        assert masks[i].dtype == np.uint16 and np.array_equal(masks[i], ref)
+        cm, _ = classmask.compute_class_masks(ref, yc_i)
+        assert class_masks[i].dtype == np.int64 and np.array_equal(class_masks[i], cm)
+        assert shp == (1, 256, 256, 3) and styles[i].shape == (256,)
+    m1, f1, c1, _ = model.eval(tiles[1])                                  # a single array: the un-listed return form
+    assert np.array_equal(m1, masks[1]) and np.array_equal(c1, class_masks[1]) and np.array_equal(f1[1], flows[1][1])
+    # two threads, one model, many calls each
+    res, err = {}, []
+    def work(tid, order):
+        try:
+            out = []
+            for _ in range(4):
+                for j in order:
+                    m, f, c, _s = model.eval(tiles[j])
+                    out.append((j, m, f[1], f[2], c))
+            res[tid] = out
+        except Exception as e:                                            # pragma: no cover
+            err.append(e)
+    th = [threading.Thread(target=work, args=(0, [0, 1, 2])), threading.Thread(target=work, args=(1, [2, 0, 1]))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not err, err
+    assert len(model._engines) >= 3                                       # main thread + one engine per worker thread
+    for tid in (0, 1):
+        for j, m, dP_t, cp_t, c in res[tid]:
+            assert np.array_equal(m, masks[j]) and np.array_equal(c, class_masks[j])
+            assert np.array_equal(dP_t, flows[j][1]) and np.array_equal(cp_t, flows[j][2])
+
+
 def test_predict_wsi_cli_default_tile_1024(cuda, tmp_path, monkeypatch):
     """the reference's DEFAULT geometry: --tile_size 1024 --overlap 64 (25 sub-tiles per tile)"""
     monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
@@ -546,6 +597,35 @@ def test_predict_wsi_two_ranks_share_one_gpu_gloo(cuda, tmp_path, monkeypatch, g
     assert feats[0] == feats[1]                              # same cells, same order, same polygons
     cent = [json.load(open(next(o.glob("*_cell_centroids.geojson"))))["features"] for o in (o1, o2)]
     assert [f["geometry"] for f in cent[0]] == [f["geometry"] for f in cent[1]]
+
+
+def test_predict_wsi_eight_ranks_share_one_gpu_gloo(cuda, tmp_path, monkeypatch):
+    """BASELINE configs[3]'s rank count on a one-GPU box: ``--device cuda:0,0,0,0,0,0,0,0`` spawns EIGHT rank processes (conic,
+    256 / 32, --tta; 20 tiles -> 2-3 per rank), the cell rows and tile indices are all-gathered, the vertex pools go to rank 0
+    only (parallel.gather_to_root), and the two files equal the single-rank run feature for feature, in order."""
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CLASSPOSE_SYNTHETIC_DEPTH", "1")
+    monkeypatch.setenv("CLASSPOSE_AMD_PLUGINS", "classpose_amd.synth:flow")
+    monkeypatch.setenv("CLASSPOSE_MODEL_DIR", str(tmp_path / "nomodels"))
+    monkeypatch.setenv("CPX_DIST_BACKEND", "gloo")
+    from classpose_amd.entrypoints import predict_wsi
+    slide, extra = "synthetic://1180x956?mpp=0.5&seed=53", dict(tile_size=256, overlap=32, tta=True, precision="bf16", batch_size=8)
+    o1, o8 = tmp_path / "one", tmp_path / "eight"
+    predict_wsi.main(_reference_integration_args(slide, o1, device="cuda:0", **extra))
+    predict_wsi.main(_reference_integration_args(slide, o8, device="cuda:" + ",".join(["0"] * 8), **extra))
+    feats = []
+    for o in (o1, o8):
+        fs = json.load(open(next(o.glob("*_cell_contours.geojson"))))["features"]
+        feats.append([(f["geometry"]["coordinates"], f["properties"]["classification"], f["properties"]["measurements"]) for f in fs])
+    assert len(feats[0]) > 100
+    assert feats[0] == feats[1]                              # same cells, same order, same polygons
+    cent = [json.load(open(next(o.glob("*_cell_centroids.geojson"))))["features"] for o in (o1, o8)]
+    assert [f["geometry"] for f in cent[0]] == [f["geometry"] for f in cent[1]]
+    # byte identity of the files apart from the uuid4 feature ids (the reference draws them at random too)
+    import re
+    strip = lambda b: re.sub(rb'"id": "[0-9a-f-]{36}"', b'"id": ""', b)
+    for pat in ("*_cell_contours.geojson", "*_cell_centroids.geojson"):
+        assert strip(next(o1.glob(pat)).read_bytes()) == strip(next(o8.glob(pat)).read_bytes())
 
 
 def test_predict_wsi_cli_full_depth_network(cuda, tmp_path, monkeypatch):

@@ -236,3 +236,11 @@ def test_canonical_cell_order_makes_rank_count_invisible():
     assert np.array_equal(c2, cells) and np.array_equal(x2, xy)
     c3, x3 = canonical_cell_order(cells[:0], xy[:0], tiles[:0])
     assert len(c3) == 0 and len(x3) == 0
+
+
+def test_library_reports_the_sources_it_was_built_from():
+    """cpx_build_id() = hash of csrc/* + the two headers at build time; _lib.source_build_id() recomputes it from the files on
+    disk -- a stale prebuilt .so (they are git-ignored and travel with snapshots) fails here instead of silently running."""
+    from classpose_amd import _lib
+    L = _lib.lib()
+    assert L.cpx_build_id().decode() == _lib.source_build_id()

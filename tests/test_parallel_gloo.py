@@ -29,6 +29,20 @@ def _worker(rank, world, port, q):
     allrec = parallel.all_gather_records(rec)
     rec2 = torch.full((3 + r, 48), 10 + r, dtype=torch.uint8)
     allrec2 = parallel.all_gather_records(rec2)
+    counts = parallel.all_gather_counts(3 + r, torch.device("cpu"))
+    pool = torch.full((2 + 3 * r, 16), 20 + r, dtype=torch.uint8)       # "vertex pool": only the writing rank receives it
+    rooted = parallel.gather_to_root(pool, 0)
+    assert counts == [3 + i for i in range(w)]
+    if r == 0:
+        assert rooted.shape == (sum(2 + 3 * i for i in range(w)), 16)
+        o = 0
+        for i in range(w):
+            assert bool((rooted[o:o + 2 + 3 * i] == 20 + i).all())
+            o += 2 + 3 * i
+    else:
+        assert rooted is None
+    empty = parallel.gather_to_root(torch.zeros((0, 16), dtype=torch.uint8) if r else torch.ones((1, 16), dtype=torch.uint8), 0)
+    assert (empty.shape == (1, 16)) if r == 0 else (empty is None)
     mx = parallel.allreduce_max(float(r + 1), torch.device("cpu"))
     sm = parallel.allreduce_sum(float(r + 1), torch.device("cpu"))
     parallel.barrier()
@@ -54,6 +68,23 @@ def test_shard_and_all_gather_records_world2():
         assert np.all(r[3][:3, 5] == 10) and np.all(r[3][3:, 5] == 11)   # rank order preserved
         assert r[4] == 2.0 and r[5] == 3.0
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def test_gather_to_root_world4():
+    """four ranks: rows all-gathered, pools gathered to rank 0 only (incl. empty contributions)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[0, 4, 8], [1, 5, 9], [2, 6, 10], [3, 7]]
+    for r in res:
+        assert r[3].shape == (3 + 4 + 5 + 6, 48) and r[4] == 4.0 and r[5] == 10.0
 
 
 def test_single_process_passthrough():
