@@ -520,11 +520,9 @@ def post_stage(L, eng, fields0, bt, dev, reps=20):
     st = torch.cuda.current_stream(dev).cuda_stream
 
     def once():
-        _lib.check(L.cpx_compute_masks(dP.data_ptr(), cp.data_ptr(), lg.data_ptr(), bt, NCLS, TILE, TILE, 0.0, 0.4, 200, 15, 0.4,
-                                       sl.masks.data_ptr(), sl.class_masks.data_ptr(), sl.nlabels.data_ptr(),
-                                       sl.pp_ws.data_ptr(), st), "compute_masks")
-        _lib.check(L.cpx_instance_records(sl.masks.data_ptr(), sl.class_masks.data_ptr(), bt, TILE, TILE, eng.max_rec,
-                                          sl.records.data_ptr(), sl.rec_counts.data_ptr(), sl.pp_ws.data_ptr(), st), "records")
+        _lib.check(L.cpx_compute_masks_records(dP.data_ptr(), cp.data_ptr(), lg.data_ptr(), bt, NCLS, TILE, TILE, 0.0, 0.4, 200, 15, 0.4,
+                                               sl.masks.data_ptr(), sl.class_masks.data_ptr(), sl.nlabels.data_ptr(), eng.max_rec,
+                                               sl.records.data_ptr(), sl.rec_counts.data_ptr(), sl.pp_ws.data_ptr(), st), "compute_masks_records")
     n0 = L.cpx_postproc_launch_count()
     once()
     launches = int(L.cpx_postproc_launch_count() - n0)

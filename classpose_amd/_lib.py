@@ -120,6 +120,7 @@ SIGNATURES = {
     "cpx_remove_border_instances": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "cpx_compute_masks": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _d, _i, _i, _d, _p, _p, _p, _p, _p]),
     "cpx_instance_records": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "cpx_compute_masks_records": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _d, _i, _i, _d, _p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_find_contours_ccomp_host": (_i, [_p, _i, _i, _p, _i, _p, _p, _p, _i]),
     "cpx_polygonize_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "cpx_polygonize_device": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _p, _p, _i, _p, _p, _p, _p]),
@@ -145,6 +146,7 @@ _PRIVATE = {
     "cpx_attention4_debug": (_i, [_p, _p, _p, _i, _p, _p, _p, _p]),
     "cpx_attention2q_debug": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
     "cpx_attention2q_set_ablation": (None, [_i]),
+    "cpx_postproc_set_fused": (None, [_i]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),
     "cpx_gemm_set_pingpong": (None, [_i]),

@@ -30,8 +30,9 @@ struct PPLayout {
     int H, W, HW, Hp, Wp, HWp, L, TW, TH, THW;
     size_t off_h1, off_M1, off_tmp, off_im, off_fg, off_fgcnt, off_T, off_e, off_seed_pos, off_seed_cnt,
         off_rank, off_cnt, off_first, off_remap, off_flag, off_bbox, off_sumy, off_sumx,
-        off_d2, off_center, off_err, off_cls, off_scal, per_tile;
+        off_d2, off_center, off_err, off_cls, off_scal, per_tile, tab0, tab_bytes;
 };
+#define PP_NSETS 6
 #define PP_NSCAL 16
 #define SC_NSEEDS 0
 #define SC_NLAB 1
@@ -40,6 +41,8 @@ struct PPLayout {
 #define SC_HASBIG 4
 #define SC_HASBG 5
 #define SC_VMAX 6
+#define SC_TICKET 8         // "last workgroup of this launch" counter (fused chain)
+#define SC_TICKET2 9
 #define PP_MAXCLS 32
 
 #define FG_BLOCK 1024       // k_prep_flow workgroup = one segment of the foreground list
@@ -57,6 +60,11 @@ static PPLayout pp_layout(int H, int W) {
     p.off_fgcnt = take(sizeof(int) * cpx_cdiv(p.THW, FG_BLOCK));
     p.off_T = take(sizeof(double) * 2 * p.THW);
     p.off_e = take(sizeof(double) * 2 * p.HW);
+    p.off_cls = take(sizeof(int) * (size_t)p.L * PP_MAXCLS);
+    // ---- the per-label tables + scalars: one contiguous block, PP_NSETS copies of it (the fused chain of
+    // cpx_compute_masks gives every stage its own copy, all of them cleared by ONE pass at the start of the chain;
+    // the stage-wise entry points use copy 0)
+    p.tab0 = o;
     p.off_seed_pos = take(sizeof(int) * p.L);
     p.off_seed_cnt = take(sizeof(int) * p.L);
     p.off_rank = take(sizeof(int) * p.L);
@@ -70,9 +78,19 @@ static PPLayout pp_layout(int H, int W) {
     p.off_d2 = take(sizeof(unsigned long long) * p.L);
     p.off_center = take(sizeof(int) * p.L);
     p.off_err = take(sizeof(double) * p.L);
-    p.off_cls = take(sizeof(int) * (size_t)p.L * PP_MAXCLS);
     p.off_scal = take(sizeof(int) * PP_NSCAL);
+    p.tab_bytes = o - p.tab0;
+    o = p.tab0 + p.tab_bytes * PP_NSETS;
     p.per_tile = o;
+    return p;
+}
+
+// the layout with its table block moved to copy k
+static PPLayout lay_set(PPLayout p, int k) {
+    const size_t d = (size_t)k * p.tab_bytes;
+    p.off_seed_pos += d; p.off_seed_cnt += d; p.off_rank += d; p.off_cnt += d; p.off_first += d; p.off_remap += d;
+    p.off_flag += d; p.off_bbox += d; p.off_sumy += d; p.off_sumx += d; p.off_d2 += d; p.off_center += d; p.off_err += d;
+    p.off_scal += d;
     return p;
 }
 
@@ -102,10 +120,39 @@ extern "C" int cpx_postproc_max_labels(int H, int W) { return H * W / 11 + 2; }
 // 1024-cell block into that block's segment of the foreground list (ballot + a 16-entry LDS prefix, no atomics, so
 // the list order is fixed): the Euler loop then runs on dense waves instead of one thread per pixel with ~70 % of the
 // lanes idle for 200 dependent steps (it is VALU-issue bound: every resident wave issues the whole loop).
+// INIT (fused chain of cpx_compute_masks): the same launch clears everything the 15 launches behind it accumulate into --
+// the padded histogram / seed-label frames, the two fp64 diffusion planes, the class-vote table and ALL PP_NSETS copies of
+// the per-label tables and scalars (every stage has its own copy) -- instead of one k_pp_init launch per stage.
+__device__ __forceinline__ void pp_init_stats_entry(char *tb, const PPLayout &lay, size_t d, int v) {
+    int *bb = (int *)(tb + lay.off_bbox + d) + 4 * v;
+    bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
+    ((int *)(tb + lay.off_cnt + d))[v] = 0;
+    ((unsigned long long *)(tb + lay.off_sumy + d))[v] = 0;
+    ((unsigned long long *)(tb + lay.off_sumx + d))[v] = 0;
+    ((unsigned long long *)(tb + lay.off_d2 + d))[v] = 0xFFFFFFFFFFFFFFFFull;
+    ((int *)(tb + lay.off_center + d))[v] = 0x7FFFFFFF;
+    ((int *)(tb + lay.off_flag + d))[v] = 0;
+    ((int *)(tb + lay.off_first + d))[v] = 0x7FFFFFFF;
+}
+template <bool INIT>
 __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict__ dP, const float *__restrict__ cp,
                                                         float thr, float kx, float ky, int32_t *__restrict__ p_final,
                                                         float *__restrict__ p_float, PPLayout lay, void *ws) {
     __shared__ int sW[FG_BLOCK / 64];
+    if constexpr (INIT) {
+        char *tb = (char *)ws + (size_t)blockIdx.y * lay.per_tile;
+        const int n_cls = lay.L * PP_MAXCLS, n_tab = lay.L * PP_NSETS;
+        int nmax = lay.HWp > 2 * lay.THW ? lay.HWp : 2 * lay.THW;
+        nmax = nmax > n_cls ? nmax : n_cls;
+        nmax = nmax > n_tab ? nmax : n_tab;
+        for (int i = blockIdx.x * FG_BLOCK + threadIdx.x; i < nmax; i += gridDim.x * FG_BLOCK) {
+            if (i < lay.HWp) { ((int *)(tb + lay.off_h1))[i] = 0; ((int *)(tb + lay.off_M1))[i] = 0; }
+            if (i < 2 * lay.THW) ((double *)(tb + lay.off_T))[i] = 0.0;
+            if (i < n_cls) ((int *)(tb + lay.off_cls))[i] = 0;
+            if (i < n_tab) { const int k = i / lay.L; pp_init_stats_entry(tb, lay, (size_t)k * lay.tab_bytes, i - k * lay.L); }
+            if (i < PP_NSCAL * PP_NSETS) ((int *)(tb + lay.off_scal + (size_t)(i / PP_NSCAL) * lay.tab_bytes))[i % PP_NSCAL] = 0;
+        }
+    }
     const int c = blockIdx.x * FG_BLOCK + threadIdx.x;
     size_t t = blockIdx.y;
     const int py = c / lay.TW, px = c - py * lay.TW;
@@ -139,6 +186,8 @@ __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict_
 
 typedef float flow4 __attribute__((ext_vector_type(4), aligned(8)));
 
+// HIST (fused chain): the final position goes straight into the padded histogram of get_masks (k_hist's pass)
+template <bool HIST>
 __global__ void k_follow(int niter, float shx, float shy,
                          float hw, float hh, int32_t *__restrict__ p_final,
                          float *__restrict__ p_float, PPLayout lay, void *ws, int early_exit) {
@@ -187,6 +236,12 @@ __global__ void k_follow(int niter, float shx, float shy,
     if (p_float) { p_float[(t * 2) * lay.HW + idx] = py; p_float[(t * 2 + 1) * lay.HW + idx] = px; }
     int iy = (int)py, ix = (int)px;            // .int(): truncation toward zero
     p_final[t * lay.HW + idx] = (iy << 16) | (ix & 0xFFFF);
+    if constexpr (HIST) {                      // exactly k_hist on the value just written
+        int hy = iy + RPAD, hx = (int)(short)(ix & 0xFFFF) + RPAD;
+        hy = max(hy, 0); hx = max(hx, 0);
+        hy = min(hy, lay.H + RPAD - 1); hx = min(hx, lay.W + RPAD - 1);
+        atomicAdd(&WS(int, off_h1)[hy * lay.Wp + hx], 1);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1025,10 +1080,8 @@ __global__ void __launch_bounds__(NTHR) k_fill_parallel(int32_t *__restrict__ ma
 
 // Sequential exact fallback (one workgroup per tile), only when flagged.
 // scratch `out`side map lives in h1 (int per pixel of the padded frame, >= HW ints).
-__global__ void __launch_bounds__(NTHR) k_fill_serial(int32_t *__restrict__ masks, PPLayout lay,
-                                                      void *ws) {
+__device__ void fill_serial_body(int32_t *__restrict__ masks, const PPLayout &lay, void *ws) {
     __shared__ int s_changed;
-    if (!(WS(int, off_scal)[SC_CONFLICT] || WS(int, off_scal)[SC_HASBIG])) return;
     const int nlab = WS(int, off_scal)[SC_NLAB];
     int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
     const int32_t *src = WS(int32_t, off_tmp);
@@ -1101,6 +1154,11 @@ __global__ void __launch_bounds__(NTHR) k_fill_serial(int32_t *__restrict__ mask
         __threadfence_block();
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(NTHR) k_fill_serial(int32_t *__restrict__ masks, PPLayout lay,
+                                                      void *ws) {
+    if (!(WS(int, off_scal)[SC_CONFLICT] || WS(int, off_scal)[SC_HASBIG])) return;
+    fill_serial_body(masks, lay, ws);
 }
 
 // ---------------------------------------------------------------------------
@@ -1207,9 +1265,376 @@ __global__ void k_rec_write(const uint8_t *__restrict__ cm, int max_rec, cpx_rec
     atomicMax(&counts[blockIdx.y], v);
 }
 
+// ===========================================================================
+// the fused chain of cpx_compute_masks (round 4): 22 launches where the stage-wise sequence needs 38
+// ===========================================================================
+// What made the chain long was never the pixel work (a 2 MB pass is ~5 us of dispatch) but its per-tile global dependencies:
+// a stage's per-label tables must be complete before its "light" step (rank the labels by first appearance, apply the size
+// filter, write the records) and that step before the next pixel pass -- each a launch of its own, each stage preceded by
+// an initialisation launch and followed by a relabel pass.  Here:
+//   * ONE initialisation: every stage has its own copy of the per-label tables (lay_set), all cleared by k_prep_flow<INIT>;
+//   * no relabel passes: labels are mapped through the previous stage's table on load by the NEXT stage's first pixel pass and
+//     written back; removals (too-big labels, size-filtered labels) are entries 0 of that table, so k_big_first and
+//     k_first<true> are gone too (the counting pass collects the first raster index itself);
+//   * the Euler loop feeds the histogram (k_hist); the size filter's flags and the ranks are one light launch, not two;
+//   * the class map, the uint16 id map and the per-cell statistics of cpx_instance_records leave in one final pass.
+// Results are bit-identical to the stage-wise entry points (same arithmetic, same tie rules; tests/test_gpu_postproc.py).
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The light per-tile step behind a pixel pass ("tail": rank the labels, apply the size filter, write the records) is the
+// SAME kernel launched a second time with tail = 1 on a (1, nT) grid.  A first version let the last workgroup of the pixel
+// pass run it (a ticket behind __threadfence): bit-identical, 16 launches -- and 1 181 us per batch against 347 us, because an
+// agent-scope release on this part writes back the XCD's whole L2 (the eight L2s are not coherent with each other) and every
+// workgroup of every pass paid for one: k_fill 689 us, the class vote 139 us (profiles/r04_post_fused_first_build.csv).
+// A launch boundary is the cheap device-wide release here (~5 us); what the fused chain keeps is everything else.
+#define TAIL_LDS 6144        // labels whose first-appearance index fits the tail's LDS copy (256^2 tiles: L = 5 959)
+// remap[v] = 1 + #{kept j : first[j] < first[v]} for kept v in 1..vmax, 0 otherwise (fastremap.renumber on the map with the
+// removed labels zeroed); *nlab = number of kept labels.  One workgroup (NTHR threads); `removed(v)` decides per label.
+template <typename R>
+__device__ __forceinline__ void tail_rank(int vmax, const int *first, int *remap, int *nlab_slot, int *scratch, R &&removed) {
+    __shared__ int s_first[TAIL_LDS];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    const bool lds = vmax < TAIL_LDS;
+    int *tab = lds ? s_first : scratch;                      // (scratch: the stage's unused `rank` table, any tile size)
+    for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+        int f = ld_agent(&first[v]);
+        if (f != 0x7FFFFFFF && removed(v)) f = 0x7FFFFFFF;
+        if (lds) tab[v] = f; else atomicExch(&tab[v], f);
+    }
+    __syncthreads();
+    int kept = 0;
+    for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+        const int f = lds ? tab[v] : ld_agent(&tab[v]);
+        if (f == 0x7FFFFFFF) { remap[v] = 0; continue; }
+        int r = 1;
+        if (lds) { for (int j = 1; j <= vmax; ++j) r += tab[j] < f; }
+        else { for (int j = 1; j <= vmax; ++j) r += ld_agent(&tab[j]) < f; }
+        remap[v] = r;
+        ++kept;
+    }
+    if (kept) atomicAdd(&s_n, kept);
+    __syncthreads();
+    if (threadIdx.x == 0) *nlab_slot = s_n;
+}
+
+// a12 tail: label gather + per-label count + first raster index; the last workgroup removes the too-big labels and ranks
+// (k_gather + k_big_first + k_renumber_rank; the relabel rides on k_lab_stats_r)
+__global__ void __launch_bounds__(NTHR) k_gather_f(const int32_t *__restrict__ p_final, int32_t *__restrict__ masks, double big,
+                                                   int tail, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vadd[LH_SLOTS], vmin[LH_SLOTS];
+    if (tail) {
+        int *scal = WS(int, off_scal), *cnt = WS(int, off_cnt);
+        const int vmax = min(scal[SC_NSEEDS], lay.L - 1);          // labels are the seed ranks 1..nseeds
+        tail_rank(vmax, WS(int, off_first), WS(int, off_remap), &scal[SC_NLAB], WS(int, off_rank),
+                  [&](int v) { return (double)cnt[v] > big; });
+        return;
+    }
+    key[threadIdx.x] = 0; vadd[threadIdx.x] = 0; vmin[threadIdx.x] = 0x7FFFFFFF;
+    __syncthreads();
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
+    const size_t t = blockIdx.y;
+    int *cnt = WS(int, off_cnt), *first = WS(int, off_first);
+    if (base < lay.HW) {
+        const int *M1 = WS(int, off_M1);
+        int lab[RUN_PX];
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) {
+            lab[i] = 0;
+            if (base + i < lay.HW) {
+                const int p = p_final[t * lay.HW + base + i];
+                if (p != -1) {
+                    int py = (p >> 16) + RPAD, px = (int)(short)(p & 0xFFFF) + RPAD;
+                    py = min(max(py, 0), lay.H + RPAD - 1); px = min(max(px, 0), lay.W + RPAD - 1);
+                    lab[i] = M1[py * lay.Wp + px];
+                }
+                masks[t * lay.HW + base + i] = lab[i];
+            }
+        }
+        label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int idx, int n, int, int) {
+            const int sl = lh_slot(key, l);
+            if (sl >= 0) { atomicAdd(&vadd[sl], n); atomicMin(&vmin[sl], idx); }
+            else { atomicAdd(&cnt[l], n); atomicMin(&first[l], idx); }
+        });
+    }
+    __syncthreads();
+    if (key[threadIdx.x]) { atomicAdd(&cnt[key[threadIdx.x]], vadd[threadIdx.x]); atomicMin(&first[key[threadIdx.x]], vmin[threadIdx.x]); }
+}
+
+// loads RUN_PX labels of the map; with `remap` the labels are first mapped through the previous stage's table and written back
+__device__ __forceinline__ void load_labels(int32_t *__restrict__ m, int base, int HW, const int *__restrict__ remap,
+                                            int32_t *__restrict__ copy_to, int (&lab)[RUN_PX]) {
+    if (base + RUN_PX <= HW && (reinterpret_cast<size_t>(m + base) & 15) == 0) {
+        const int4 a = *reinterpret_cast<const int4 *>(m + base), b = *reinterpret_cast<const int4 *>(m + base + 4);
+        lab[0] = a.x; lab[1] = a.y; lab[2] = a.z; lab[3] = a.w; lab[4] = b.x; lab[5] = b.y; lab[6] = b.z; lab[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) lab[i] = base + i < HW ? m[base + i] : 0;
+    }
+    if (remap) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i)
+            if (lab[i] > 0) { const int n = remap[lab[i]]; changed |= n != lab[i]; lab[i] = n; }
+        if (changed) {
+#pragma unroll
+            for (int i = 0; i < RUN_PX; ++i)
+                if (base + i < HW) m[base + i] = lab[i];
+        }
+    }
+    if (copy_to) {
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i)
+            if (base + i < HW) copy_to[base + i] = lab[i];
+    }
+}
+
+// k_relabel of the previous stage (through `prev`'s remap table) + k_lab_stats of this one (+ the pre-fill copy)
+__global__ void __launch_bounds__(NTHR) k_lab_stats_r(int32_t *__restrict__ masks, int copy_to_tmp, PPLayout prev, PPLayout lay, void *ws) {
+    __shared__ LabStatsLds L;
+    const int i = threadIdx.x;
+    L.key[i] = 0; L.ymin[i] = 0x7FFFFFFF; L.xmin[i] = 0x7FFFFFFF; L.ymax[i] = -1; L.xmax[i] = -1; L.cnt[i] = 0;
+    L.first[i] = 0x7FFFFFFF; L.sy[i] = 0; L.sx[i] = 0;
+    __syncthreads();
+    char *tb = (char *)ws + (size_t)blockIdx.y * lay.per_tile;
+    if (blockIdx.x == 0 && i == 0) WS(int, off_scal)[SC_NLAB] = ((const int *)(tb + prev.off_scal))[SC_NLAB];
+    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
+    unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
+    int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const int base = (blockIdx.x * NTHR + i) * RUN_PX;
+    if (base < lay.HW) {
+        int lab[RUN_PX];
+        load_labels(m, base, lay.HW, (const int *)(tb + prev.off_remap), copy_to_tmp ? WS(int32_t, off_tmp) : nullptr, lab);
+        label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int, int n, int y, int x) {
+            const unsigned long long ay = (unsigned long long)n * y;
+            const unsigned long long ax = (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2);
+            const int sl = lh_slot(L.key, l);
+            if (sl >= 0) {
+                atomicMin(&L.ymin[sl], y); atomicMin(&L.xmin[sl], x); atomicMax(&L.ymax[sl], y); atomicMax(&L.xmax[sl], x + n - 1);
+                atomicAdd(&L.cnt[sl], n);
+                atomicAdd(&L.sy[sl], (unsigned)ay); atomicAdd(&L.sx[sl], (unsigned)ax);
+            } else {
+                int *bb = bbox + 4 * l;
+                atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
+                atomicAdd(&cnt[l], n);
+                atomicAdd(&sumy[l], ay); atomicAdd(&sumx[l], ax);
+            }
+        });
+    }
+    __syncthreads();
+    const int l = L.key[i];
+    if (l) {
+        int *bb = bbox + 4 * l;
+        atomicMin(&bb[0], L.ymin[i]); atomicMin(&bb[1], L.xmin[i]); atomicMax(&bb[2], L.ymax[i]); atomicMax(&bb[3], L.xmax[i]);
+        atomicAdd(&cnt[l], L.cnt[i]);
+        atomicAdd(&sumy[l], (unsigned long long)L.sy[i]); atomicAdd(&sumx[l], (unsigned long long)L.sx[i]);
+    }
+}
+
+// the size filter in one launch: count + first index per label (with the flow-error filter's removals applied on the way:
+// `errs` = that stage's error table), then in the last workgroup the positional size filter (k_size_filter) and the
+// first-appearance ranks with the flagged labels removed (k_first<true> + k_renumber_rank); nlabels_out: the label count
+__global__ void __launch_bounds__(NTHR) k_count_labels_f(int32_t *__restrict__ masks, PPLayout errs, int err_thr_on, double err_thr,
+                                                         int min_size, int32_t *__restrict__ nlabels_out, int tail, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vadd[LH_SLOTS], vmin[LH_SLOTS], s_max, s_bg;
+    if (!tail) {
+    key[threadIdx.x] = 0; vadd[threadIdx.x] = 0; vmin[threadIdx.x] = 0x7FFFFFFF;
+    if (threadIdx.x == 0) { s_max = 0; s_bg = 0; }
+    __syncthreads();
+    char *tb = (char *)ws + (size_t)blockIdx.y * lay.per_tile;
+    int *cnt = WS(int, off_cnt), *first = WS(int, off_first), *scal = WS(int, off_scal);
+    int32_t *m = masks + (size_t)blockIdx.y * lay.HW;
+    const int base = (blockIdx.x * NTHR + threadIdx.x) * RUN_PX;
+    int vmax = 0;
+    bool bg = false;
+    if (base < lay.HW) {
+        int lab[RUN_PX];
+        bool changed = false;
+        const double *err = (const double *)(tb + errs.off_err);
+#pragma unroll
+        for (int i = 0; i < RUN_PX; ++i) {
+            lab[i] = base + i < lay.HW ? m[base + i] : 0;
+            if (err_thr_on && lab[i] > 0 && err[lab[i]] > err_thr) { lab[i] = 0; changed = true; }
+        }
+        if (changed) {
+#pragma unroll
+            for (int i = 0; i < RUN_PX; ++i)
+                if (base + i < lay.HW) m[base + i] = lab[i];
+        }
+        bg = label_runs(lab, base, lay.HW, lay.W, 0x7FFFFFFF, [&](int l, int idx, int n, int, int) {
+            const int s = lh_slot(key, l);
+            if (s >= 0) { atomicAdd(&vadd[s], n); atomicMin(&vmin[s], idx); }
+            else { atomicAdd(&cnt[l], n); atomicMin(&first[l], idx); }
+            vmax = max(vmax, l);
+        });
+    }
+    if (vmax > 0) atomicMax(&s_max, vmax);
+    if (bg) s_bg = 1;
+    __syncthreads();
+    if (key[threadIdx.x]) { atomicAdd(&cnt[key[threadIdx.x]], vadd[threadIdx.x]); atomicMin(&first[key[threadIdx.x]], vmin[threadIdx.x]); }
+    if (threadIdx.x == 0) {
+        if (s_max > 0) atomicMax(&scal[SC_VMAX], s_max);
+        if (s_bg) atomicExch(&scal[SC_HASBG], 1);
+    }
+    return;
+    }
+    int *cnt = WS(int, off_cnt), *first = WS(int, off_first), *scal = WS(int, off_scal);
+    // ---- counts = unique(masks, return_counts=True)[1][1:]; remove label VALUE (i + 1) where counts[i] < min_size: positional
+    // indexing, the reference's quirk (oracle/dynamics.py).  Ranks by a prefix over per-thread label slices.
+    __shared__ int s_part[NTHR];
+    const int vm = min(ld_agent(&scal[SC_VMAX]), lay.L - 1);
+    const int hasbg = ld_agent(&scal[SC_HASBG]);
+    int *flag = WS(int, off_flag);
+    const int per = (vm + NTHR) / NTHR;
+    const int lo = 1 + (int)threadIdx.x * per, hi = min(lo + per - 1, vm);
+    int c = 0;
+    for (int v = lo; v <= hi; ++v) c += ld_agent(&cnt[v]) > 0;
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < NTHR; o <<= 1) {
+        const int tv = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += tv;
+        __syncthreads();
+    }
+    int rank = s_part[threadIdx.x] - c;
+    for (int v = lo; v <= hi; ++v) {
+        const int n = ld_agent(&cnt[v]);
+        if (n <= 0) continue;
+        ++rank;
+        const int pos = hasbg ? rank - 1 : rank - 2;
+        if (pos >= 0 && n < min_size) atomicExch(&flag[pos + 1], 1);
+    }
+    __threadfence();
+    __syncthreads();
+    tail_rank(vm, first, WS(int, off_remap), &scal[SC_NLAB], WS(int, off_rank), [&](int v) { return ld_agent(&flag[v]) != 0; });
+    if (nlabels_out && threadIdx.x == 0) nlabels_out[blockIdx.y] = scal[SC_NLAB];
+}
+
+// class vote with the size filter's relabel on the way (labels -> `prev`'s remap, written back), then in the last workgroup
+// the per-label arg-max (k_relabel + k_class_count + k_class_pick)
+__global__ void __launch_bounds__(NTHR) k_class_count_f(int32_t *__restrict__ masks, const float *__restrict__ logits, int ncls,
+                                                        PPLayout prev, PPLayout lay, void *ws) {
+    __shared__ int key[LH_SLOTS], vadd[LH_SLOTS];           // key = label * PP_MAXCLS + class + 1
+    key[threadIdx.x] = 0; vadd[threadIdx.x] = 0;
+    __syncthreads();
+    char *tb = (char *)ws + (size_t)blockIdx.y * lay.per_tile;
+    const int idx = blockIdx.x * NTHR + threadIdx.x;
+    const size_t t = blockIdx.y;
+    int *cls = WS(int, off_cls);
+    int lab = 0;
+    if (idx < lay.HW) {
+        lab = masks[t * lay.HW + idx];
+        if (lab > 0) {
+            const int n = ((const int *)(tb + prev.off_remap))[lab];
+            if (n != lab) masks[t * lay.HW + idx] = n;
+            lab = n;
+        }
+    }
+    if (lab > 0 && logits) {
+        const float *lg = logits + t * ncls * lay.HW + idx;
+        float best = lg[0];
+        int bi = 0;
+        for (int c = 1; c < ncls; ++c) {
+            float v = lg[(size_t)c * lay.HW];
+            if (v > best) { best = v; bi = c; }        // first maximum wins (np.argmax)
+        }
+        const int k = lab * PP_MAXCLS + bi;
+        const int sl = lh_slot(key, k + 1);
+        if (sl >= 0) atomicAdd(&vadd[sl], 1); else atomicAdd(&cls[k], 1);
+    }
+    __syncthreads();
+    if (key[threadIdx.x]) atomicAdd(&cls[key[threadIdx.x] - 1], vadd[threadIdx.x]);
+}
+
+// the chain's last pass: class map + uint16 id map per pixel (k_class_write) and, with `rec`, the per-label statistics of
+// cpx_instance_records (k_rec_stats) whose records the last workgroup writes (k_rec_write).  `pick` = the stage table whose
+// remap holds the class of every label (null: no vote -> class 0); with REMAP the labels still go through `prev`'s table.
+__global__ void __launch_bounds__(NTHR) k_finish_f(int32_t *__restrict__ masks, uint8_t *__restrict__ cm, uint16_t *__restrict__ masks_u16,
+                                                   int has_pick, PPLayout pick, int has_prev, PPLayout prev, int max_rec,
+                                                   cpx_record *__restrict__ rec, int32_t *__restrict__ counts, int tail, PPLayout lay, void *ws) {
+    __shared__ LabStatsLds L;
+    const int i = threadIdx.x;
+    if (tail) {
+        // records at slot label - 1 (labels are contiguous after the renumbering); counts[tile] = the largest label
+        char *tb = (char *)ws + (size_t)blockIdx.y * lay.per_tile;
+        const int *clsmap = has_pick ? (const int *)(tb + pick.off_remap) : nullptr;
+        const int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt);
+        const unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
+        const int vm = min(WS(int, off_scal)[SC_VMAX], lay.L - 1);
+        for (int v = 1 + i; v <= vm; v += NTHR) {
+            const int n = cnt[v];
+            if (n <= 0 || v - 1 >= max_rec) continue;
+            cpx_record r;
+            r.tile = blockIdx.y; r.label = v;
+            r.cls = (cm && clsmap) ? (int)(uint8_t)clsmap[v] : 0;
+            r.area = n;
+            r.y0 = bbox[4 * v]; r.x0 = bbox[4 * v + 1]; r.y1 = bbox[4 * v + 2] + 1; r.x1 = bbox[4 * v + 3] + 1;
+            r.sum_y = (int64_t)sumy[v];
+            r.sum_x = (int64_t)sumx[v];
+            rec[(size_t)blockIdx.y * max_rec + v - 1] = r;
+        }
+        if (i == 0) counts[blockIdx.y] = vm;
+        return;
+    }
+    L.key[i] = 0; L.ymin[i] = 0x7FFFFFFF; L.xmin[i] = 0x7FFFFFFF; L.ymax[i] = -1; L.xmax[i] = -1; L.cnt[i] = 0;
+    L.first[i] = 0x7FFFFFFF; L.sy[i] = 0; L.sx[i] = 0;
+    if (i == 0) L.vmax = 0;
+    __syncthreads();
+    char *tb = (char *)ws + (size_t)blockIdx.y * lay.per_tile;
+    const int *clsmap = has_pick ? (const int *)(tb + pick.off_remap) : nullptr;
+    int *bbox = WS(int, off_bbox), *cnt = WS(int, off_cnt), *scal = WS(int, off_scal);
+    unsigned long long *sumy = WS(unsigned long long, off_sumy), *sumx = WS(unsigned long long, off_sumx);
+    const size_t t = blockIdx.y;
+    int32_t *m = masks + t * lay.HW;
+    const int base = (blockIdx.x * NTHR + i) * RUN_PX;
+    int vmax = 0;
+    if (base < lay.HW) {
+        int lab[RUN_PX];
+        load_labels(m, base, lay.HW, has_prev ? (const int *)(tb + prev.off_remap) : nullptr, nullptr, lab);
+#pragma unroll
+        for (int k = 0; k < RUN_PX; ++k)
+            if (base + k < lay.HW) {
+                if (cm) cm[t * lay.HW + base + k] = (lab[k] > 0 && clsmap) ? (uint8_t)clsmap[lab[k]] : 0;
+                masks_u16[t * lay.HW + base + k] = (uint16_t)lab[k];
+            }
+        if (rec) {
+            label_runs(lab, base, lay.HW, lay.W, lay.L, [&](int l, int, int n, int y, int x) {
+                const unsigned long long ay = (unsigned long long)n * y;
+                const unsigned long long ax = (unsigned long long)n * x + (unsigned long long)(n * (n - 1) / 2);
+                const int sl = lh_slot(L.key, l);
+                if (sl >= 0) {
+                    atomicMin(&L.ymin[sl], y); atomicMin(&L.xmin[sl], x); atomicMax(&L.ymax[sl], y); atomicMax(&L.xmax[sl], x + n - 1);
+                    atomicAdd(&L.cnt[sl], n);
+                    atomicAdd(&L.sy[sl], (unsigned)ay); atomicAdd(&L.sx[sl], (unsigned)ax);
+                } else {
+                    int *bb = bbox + 4 * l;
+                    atomicMin(&bb[0], y); atomicMin(&bb[1], x); atomicMax(&bb[2], y); atomicMax(&bb[3], x + n - 1);
+                    atomicAdd(&cnt[l], n);
+                    atomicAdd(&sumy[l], ay); atomicAdd(&sumx[l], ax);
+                }
+                vmax = max(vmax, l);
+            });
+        }
+    }
+    if (!rec) return;
+    if (vmax > 0) atomicMax(&L.vmax, vmax);
+    __syncthreads();
+    const int l = L.key[i];
+    if (l) {
+        int *bb = bbox + 4 * l;
+        atomicMin(&bb[0], L.ymin[i]); atomicMin(&bb[1], L.xmin[i]); atomicMax(&bb[2], L.ymax[i]); atomicMax(&bb[3], L.xmax[i]);
+        atomicAdd(&cnt[l], L.cnt[i]);
+        atomicAdd(&sumy[l], (unsigned long long)L.sy[i]); atomicAdd(&sumx[l], (unsigned long long)L.sx[i]);
+    }
+    if (i == 0 && L.vmax > 0) atomicMax(&scal[SC_VMAX], L.vmax);
+}
+
 // ---------------------------------------------------------------------------
 // host-side launch sequences (C ABI)
 // ---------------------------------------------------------------------------
+extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *class_masks, int nT, int H, int W, int max_rec,
+                                    cpx_record *records, int32_t *counts, void *ws, void *stream);
 #define GRID_PIX(lay, nT) dim3(cpx_cdiv((lay).HW, NTHR), nT)
 #define GRID_PAD(lay, nT) dim3(cpx_cdiv((lay).HWp, NTHR), nT)
 #define GRID_LAB(lay, nT) dim3(cpx_cdiv((lay).L, NTHR), nT)
@@ -1233,8 +1658,8 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
     float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
-    PP_LAUNCH(k_prep_flow, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
-    PP_LAUNCH(k_follow, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
+    PP_LAUNCH(k_prep_flow<false>, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
+    PP_LAUNCH(k_follow<false>, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
                        (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
                        p_float, lay, ws, g_follow_early);
     CPX_CHECK_LAUNCH();
@@ -1373,19 +1798,22 @@ extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks,
     return CPX_OK;
 }
 
-extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const float *logits, int nT,
-                                 int ncls, int H, int W, float cellprob_threshold,
-                                 double flow_threshold, int niter, int min_size,
-                                 double max_size_fraction, uint16_t *masks_u16,
-                                 uint8_t *class_masks, int32_t *nlabels, void *ws, void *stream) {
-    int rc = pp_check(nT, H, W); if (rc) return rc;
-    CPX_REQUIRE(dP && cellprob && masks_u16 && ws);
-    CPX_REQUIRE(min_size > 0);
+CPX_SWITCH(g_pp_fused, 1);          // 1 = the 16-launch fused chain (production), 0 = the stage-wise sequence (38 launches; A/B)
+#ifdef CPX_DEBUG
+extern "C" void cpx_postproc_set_fused(int on) { g_pp_fused = on; }
+#endif
+
+// stage-wise sequence: the entry points of a11-a15 one after the other (what cpx_compute_masks was until round 3)
+static int compute_masks_staged(const float *dP, const float *cellprob, const float *logits, int nT,
+                                int ncls, int H, int W, float cellprob_threshold,
+                                double flow_threshold, int niter, int min_size,
+                                double max_size_fraction, uint16_t *masks_u16,
+                                uint8_t *class_masks, int32_t *nlabels, void *ws, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)nT * H * W;
     int32_t *masks = (int32_t *)ws;
     int32_t *p_final = (int32_t *)((char *)ws + cpx_align_up(sizeof(int) * n, 256));
-    rc = cpx_follow_flows(dP, cellprob, nT, H, W, cellprob_threshold, niter, p_final, nullptr, ws, stream);
+    int rc = cpx_follow_flows(dP, cellprob, nT, H, W, cellprob_threshold, niter, p_final, nullptr, ws, stream);
     if (rc) return rc;
     rc = cpx_get_masks(p_final, nT, H, W, max_size_fraction, masks, nullptr, ws, stream);
     if (rc) return rc;
@@ -1406,6 +1834,89 @@ extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const f
     }
     CPX_CHECK_LAUNCH();
     return CPX_OK;
+}
+
+// the fused chain (see "the fused chain of cpx_compute_masks" above): 22 launches with the class vote and the records (the
+// stage-wise sequence: 38), 21 without records, 19 without the vote, 4 fewer without the flow-error filter
+static int compute_masks_fused(const float *dP, const float *cellprob, const float *logits, int nT,
+                               int ncls, int H, int W, float thr, double flow_threshold, int niter, int min_size,
+                               double max_size_fraction, uint16_t *masks_u16, uint8_t *class_masks, int32_t *nlabels,
+                               int max_rec, cpx_record *records, int32_t *rec_counts, void *ws0, hipStream_t s) {
+    const size_t n = (size_t)nT * H * W;
+    int32_t *masks = (int32_t *)ws0;
+    int32_t *p_final = (int32_t *)((char *)ws0 + cpx_align_up(sizeof(int) * n, 256));
+    const PPLayout lay = pp_layout(H, W);
+    void *ws = pp_tiles(ws0, nT, H, W);
+    const PPLayout L0 = lay, L1 = lay_set(lay, 1), L2 = lay_set(lay, 2), L3 = lay_set(lay, 3), L4 = lay_set(lay, 4), L5 = lay_set(lay, 5);
+    // a11: flow field + foreground list + the chain's one initialisation pass; Euler loop + histogram
+    const float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
+    PP_LAUNCH(k_prep_flow<true>, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, (float *)nullptr, lay, ws);
+    PP_LAUNCH(k_follow<true>, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
+              (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final, (float *)nullptr, lay, ws, g_follow_early);
+    // a12: seeds, growth, gather (+ big-label removal and ranks in its last workgroup)
+    PP_LAUNCH(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, L0, ws);
+    PP_LAUNCH(k_seed_grow, dim3(SEED_WGS, nT), dim3(NTHR), 0, s, L0, ws);
+    const double big = (double)((long long)H * W) * max_size_fraction;
+    PP_LAUNCH(k_gather_f, GRID_RUN(lay, nT), dim3(NTHR), 0, s, p_final, masks, big, 0, L0, ws);
+    PP_LAUNCH(k_gather_f, dim3(1, nT), dim3(NTHR), 0, s, p_final, masks, big, 1, L0, ws);             // too-big labels out, ranks
+    // a13: flow-error filter on the relabelled map (the flagged labels are removed by the size filter's counting pass)
+    PP_LAUNCH(k_lab_stats_r, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 0, L0, L1, ws);              // (relabel through set 0 on the way)
+    if (flow_threshold > 0) {
+        PP_LAUNCH(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, L1, ws);
+        PP_LAUNCH(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, L1, ws);
+        PP_LAUNCH(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, L1, ws);
+        PP_LAUNCH(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, dP, flow_threshold, (double *)nullptr, L1, ws);
+    }
+    // a14: size filter, hole fill, size filter
+    PP_LAUNCH(k_count_labels_f, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, L1, flow_threshold > 0 ? 1 : 0, flow_threshold, min_size, (int32_t *)nullptr, 0, L2, ws);
+    PP_LAUNCH(k_count_labels_f, dim3(1, nT), dim3(NTHR), 0, s, masks, L1, 0, 0.0, min_size, (int32_t *)nullptr, 1, L2, ws);
+    PP_LAUNCH(k_lab_stats_r, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 1, L2, L3, ws);
+    PP_LAUNCH(k_fill_parallel, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, L3, ws);
+    PP_LAUNCH(k_fill_serial, dim3(1, nT), dim3(NTHR), 0, s, masks, L3, ws);
+    PP_LAUNCH(k_count_labels_f, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, L3, 0, 0.0, min_size, (int32_t *)nullptr, 0, L4, ws);
+    PP_LAUNCH(k_count_labels_f, dim3(1, nT), dim3(NTHR), 0, s, masks, L3, 0, 0.0, min_size, nlabels, 1, L4, ws);
+    // a15 + records
+    const bool vote = class_masks && logits && ncls > 1;
+    if (vote) {
+        PP_LAUNCH(k_class_count_f, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, logits, ncls, L4, L5, ws);
+        PP_LAUNCH(k_class_pick, GRID_LAB(lay, nT), dim3(NTHR), 0, s, ncls, L5, ws);
+        PP_LAUNCH(k_finish_f, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, 1, L5, 0, L5, max_rec, records, rec_counts, 0, L5, ws);
+        if (records) PP_LAUNCH(k_finish_f, dim3(1, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, 1, L5, 0, L5, max_rec, records, rec_counts, 1, L5, ws);
+    } else {
+        PP_LAUNCH(k_finish_f, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, 0, L5, 1, L4, max_rec, records, rec_counts, 0, L5, ws);
+        if (records) PP_LAUNCH(k_finish_f, dim3(1, nT), dim3(NTHR), 0, s, masks, class_masks, masks_u16, 0, L5, 1, L4, max_rec, records, rec_counts, 1, L5, ws);
+    }
+    CPX_CHECK_LAUNCH();
+    return CPX_OK;
+}
+
+extern "C" int cpx_compute_masks_records(const float *dP, const float *cellprob, const float *logits, int nT,
+                                         int ncls, int H, int W, float cellprob_threshold,
+                                         double flow_threshold, int niter, int min_size,
+                                         double max_size_fraction, uint16_t *masks_u16,
+                                         uint8_t *class_masks, int32_t *nlabels, int max_rec, cpx_record *records,
+                                         int32_t *rec_counts, void *ws, void *stream) {
+    int rc = pp_check(nT, H, W); if (rc) return rc;
+    CPX_REQUIRE(dP && cellprob && masks_u16 && ws);
+    CPX_REQUIRE(min_size > 0);
+    CPX_REQUIRE((records == nullptr) == (rec_counts == nullptr) && (!records || max_rec > 0));
+    if (!g_pp_fused) {
+        rc = compute_masks_staged(dP, cellprob, logits, nT, ncls, H, W, cellprob_threshold, flow_threshold, niter, min_size,
+                                  max_size_fraction, masks_u16, class_masks, nlabels, ws, stream);
+        if (rc || !records) return rc;
+        return cpx_instance_records(masks_u16, class_masks, nT, H, W, max_rec, records, rec_counts, ws, stream);
+    }
+    return compute_masks_fused(dP, cellprob, logits, nT, ncls, H, W, cellprob_threshold, flow_threshold, niter, min_size,
+                               max_size_fraction, masks_u16, class_masks, nlabels, max_rec, records, rec_counts, ws, (hipStream_t)stream);
+}
+
+extern "C" int cpx_compute_masks(const float *dP, const float *cellprob, const float *logits, int nT,
+                                 int ncls, int H, int W, float cellprob_threshold,
+                                 double flow_threshold, int niter, int min_size,
+                                 double max_size_fraction, uint16_t *masks_u16,
+                                 uint8_t *class_masks, int32_t *nlabels, void *ws, void *stream) {
+    return cpx_compute_masks_records(dP, cellprob, logits, nT, ncls, H, W, cellprob_threshold, flow_threshold, niter, min_size,
+                                     max_size_fraction, masks_u16, class_masks, nlabels, 0, nullptr, nullptr, ws, stream);
 }
 
 extern "C" int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *class_masks, int nT,

@@ -434,14 +434,13 @@ class Engine:
                                         C.byref(self.tiling), ptr(self.taper), ptr(sl.dP),
                                         ptr(sl.cellprob), ptr(sl.logits), sp), "blend")
         dP, cp, lg = (sl.dP, sl.cellprob, sl.logits) if inject is None else inject
-        check(self.L.cpx_compute_masks(ptr(dP), ptr(cp), ptr(lg) if ncls > 1 else None, n, ncls,
-                                       self.H, self.W, self.cp_thr, self.flow_thr, self.niter,
-                                       self.min_size, self.max_frac, ptr(sl.masks), ptr(sl.class_masks),
-                                       ptr(sl.nlabels), ptr(sl.pp_ws), sp), "compute_masks")
-        if records:
-            check(self.L.cpx_instance_records(ptr(sl.masks), ptr(sl.class_masks), n, self.H, self.W,
-                                              self.max_rec, ptr(sl.records), ptr(sl.rec_counts),
-                                              ptr(sl.pp_ws), sp), "instance_records")
+        # one fused chain: ids, classes and (when asked for) the per-cell records leave in its last pass
+        check(self.L.cpx_compute_masks_records(ptr(dP), ptr(cp), ptr(lg) if ncls > 1 else None, n, ncls,
+                                               self.H, self.W, self.cp_thr, self.flow_thr, self.niter,
+                                               self.min_size, self.max_frac, ptr(sl.masks), ptr(sl.class_masks),
+                                               ptr(sl.nlabels), self.max_rec if records else 0,
+                                               ptr(sl.records) if records else None, ptr(sl.rec_counts) if records else None,
+                                               ptr(sl.pp_ws), sp), "compute_masks")
         sl.has_polygons = polygons is not None
         if polygons is not None:
             assert records, "polygons need the per-cell records"

@@ -335,6 +335,7 @@ int cpx_compute_masks(const float *dP, const float *cellprob, const float *logit
                       int niter, int min_size, double max_size_fraction, uint16_t *masks_u16,
                       uint8_t *class_masks, int32_t *nlabels, void *workspace, void *stream);
 
+
 /* Compact per-instance records: what leaves the device in place of the pickled
  * (masks, class_masks) arrays of predict_wsi.py:757-763 / :595-652.          */
 typedef struct cpx_record {
@@ -348,6 +349,18 @@ typedef struct cpx_record {
 int cpx_instance_records(const uint16_t *masks_u16, const uint8_t *class_masks, int nT, int H,
                          int W, int max_records_per_tile, cpx_record *records,
                          int32_t *counts, void *workspace, void *stream);
+/* The same chain with the per-cell records of cpx_instance_records produced by its last pass (records / rec_counts / max_rec
+ * as there; both NULL: exactly cpx_compute_masks).  One launch sequence of 22 kernels per batch of tiles (the stage-wise
+ * entry points above, called one after the other, need 38): one initialisation for all stages, relabelling rides on the next
+ * stage's pixel pass, removals go through the rank table, the records leave with the final pass.  Bit-identical outputs.
+ * Replaces: dynamics.resize_and_compute_masks + compute_class_masks (models.py:750-768) and the (masks, class_masks) ->
+ * per-cell table step of PostProcessor.__call__ (predict_wsi.py:595-652) for one batch of tiles.                        */
+int cpx_compute_masks_records(const float *dP, const float *cellprob, const float *logits, int nT,
+                              int ncls, int H, int W, float cellprob_threshold,
+                              double flow_threshold, int niter, int min_size,
+                              double max_size_fraction, uint16_t *masks_u16,
+                              uint8_t *class_masks, int32_t *nlabels, int max_rec, cpx_record *records,
+                              int32_t *rec_counts, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------
  * a17  polygonisation (HOST function: all pointers are host pointers)

@@ -268,3 +268,114 @@ def test_compute_masks_equals_reference_eval_golden(cuda):
         assert np.array_equal(ops.masks_to_numpy(m)[0], g[f"ev_{k}_masks"])
         assert np.array_equal(cm[0].cpu().numpy(), g[f"ev_{k}_class_masks"])
         assert int(nl[0]) == int(g[f"ev_{k}_masks"].max())
+
+
+def _chain(L, dP, cp, lg, want_records=True, flow_threshold=0.4):
+    """cpx_compute_masks_records through the raw ABI of library L -> (masks u16, class map, nlabels, records, counts, launches)"""
+    import ctypes as C
+    from classpose_amd import _lib
+    nT, _, H, W = dP.shape
+    dev = dP.device
+    ncls = 0 if lg is None else lg.shape[1]
+    max_rec = min(L.cpx_postproc_max_labels(H, W), 65535)
+    masks = torch.zeros((nT, H, W), dtype=torch.int16, device=dev)
+    cm = torch.full((nT, H, W), 255, dtype=torch.uint8, device=dev)
+    nlab = torch.full((nT,), -7, dtype=torch.int32, device=dev)
+    rec = torch.zeros(nT * max_rec * C.sizeof(_lib.CpxRecord), dtype=torch.uint8, device=dev)
+    cnt = torch.full((nT,), -7, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.cpx_postproc_workspace_bytes(nT, H, W), dtype=torch.uint8, device=dev)
+    n0 = L.cpx_postproc_launch_count()
+    _lib.check(L.cpx_compute_masks_records(dP.data_ptr(), cp.data_ptr(), lg.data_ptr() if lg is not None else None, nT, ncls, H, W,
+                                           0.0, flow_threshold, 200, 15, 0.4, masks.data_ptr(), cm.data_ptr(), nlab.data_ptr(),
+                                           max_rec if want_records else 0, rec.data_ptr() if want_records else None,
+                                           cnt.data_ptr() if want_records else None, ws.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream), "compute_masks_records")
+    launches = int(L.cpx_postproc_launch_count() - n0)
+    torch.cuda.synchronize(dev)
+    recs = []
+    if want_records:
+        r = rec.cpu().numpy().view(np.dtype([("tile", "<i4"), ("label", "<i4"), ("cls", "<i4"), ("area", "<i4"), ("y0", "<i4"), ("x0", "<i4"),
+                                              ("y1", "<i4"), ("x1", "<i4"), ("sum_y", "<i8"), ("sum_x", "<i8")])).reshape(nT, max_rec)
+        recs = [r[t, :int(cnt[t])].copy() for t in range(nT)]
+    return ops.masks_to_numpy(masks), cm.cpu().numpy(), nlab.cpu().numpy(), recs, cnt.cpu().numpy(), launches
+
+
+@pytest.mark.parametrize("vote,flow_thr", [(True, 0.4), (False, 0.4), (True, 0.0)])
+def test_fused_chain_equals_stagewise_chain(cuda, vote, flow_thr):
+    """The 22-launch fused chain of cpx_compute_masks_records (one initialisation, relabel on the next stage's pass, removals
+    through the rank table, histogram in the Euler loop, records in the final pass) against the stage-wise sequence it replaces
+    (38 launches; cpx_postproc_set_fused(0) in the debug library): ids, class maps, label counts and per-cell records
+    bit-identical on analytic, noisy and random fields incl. an empty tile, both equal to the oracle."""
+    from classpose_amd import _lib
+    tiles = [_fields(k, 256, 256, s) for k, s in (("discs", 21), ("noisy_discs", 22), ("random", 23), ("discs", 24),
+                                                   ("noisy_discs", 25), ("random", 26))]
+    dP = torch.from_numpy(np.stack([t[0] for t in tiles] + [np.zeros((2, 256, 256), np.float32)])).to(cuda)
+    cp = torch.from_numpy(np.stack([t[1] for t in tiles] + [np.full((256, 256), -1.0, np.float32)])).to(cuda)
+    lg = torch.from_numpy(np.stack([t[2] for t in tiles] + [np.zeros((7, 256, 256), np.float32)])).to(cuda) if vote else None
+    product = _chain(_lib.lib(), dP, cp, lg, flow_threshold=flow_thr)
+    assert product[5] == (22 if vote else 20) - (0 if flow_thr > 0 else 4)
+    with _lib.use_debug_library() as L:
+        L.cpx_postproc_set_fused(0)
+        try:
+            staged = _chain(L, dP, cp, lg, flow_threshold=flow_thr)
+        finally:
+            L.cpx_postproc_set_fused(1)
+        fused_dbg = _chain(L, dP, cp, lg, flow_threshold=flow_thr)
+    assert staged[5] >= (34 if flow_thr > 0 else 28)
+    for got in (product, fused_dbg):
+        assert np.array_equal(got[0], staged[0]) and np.array_equal(got[1], staged[1]) and np.array_equal(got[2], staged[2])
+        assert np.array_equal(got[4], staged[4])
+        for a, b in zip(got[3], staged[3]):
+            assert a.tobytes() == b.tobytes()
+    for i, (a, b, c) in enumerate(tiles):
+        ref = dynamics.compute_masks(a, b, flow_threshold=flow_thr if flow_thr > 0 else None)
+        assert np.array_equal(product[0][i], ref), i
+        if vote:
+            cref_, _ = classmask.compute_class_masks(ref, c)
+            assert np.array_equal(product[1][i], cref_.astype(np.uint8)), i
+            exp = classmask.instance_records(ref, cref_)
+            r = product[3][i]
+            assert len(r) == ref.max() and np.array_equal(r["area"], exp["area"]) and np.array_equal(r["cls"], exp["cls"])
+            assert np.array_equal(r["sum_y"], exp["sum_y"]) and np.array_equal(r["sum_x"], exp["sum_x"])
+        else:
+            assert product[1][i].max() == 0
+        assert int(product[2][i]) == ref.max()
+    assert product[0][6].max() == 0 and int(product[4][6]) == 0 and int(product[2][6]) == 0
+    # without records: same maps, the record buffers untouched
+    norec = _chain(_lib.lib(), dP, cp, lg, want_records=False, flow_threshold=flow_thr)
+    assert np.array_equal(norec[0], product[0]) and np.array_equal(norec[1], product[1]) and int(norec[4][0]) == -7
+
+
+def test_fused_chain_repeatable_under_load_and_odd_sizes(cuda):
+    """race screen of the fused chain (per-stage table copies, relabel-on-load with write-back): 20 runs on an 8-tile batch
+    beside a GEMM stream, and odd tile sizes, always the same bits as the stage-wise chain"""
+    from classpose_amd import _lib, synth
+    f = [synth.analytic_fields(777, 224 * i, 448, 256, 256, 7) for i in range(8)]
+    dP, cp, lg = (torch.from_numpy(np.stack([a[k] for a in f])).to(cuda) for k in range(3))
+    side = torch.cuda.Stream(device=cuda)
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(8192, 1024, generator=g).to(torch.bfloat16).to(cuda)
+    Wt = torch.randn(4096, 1024, generator=g).to(torch.bfloat16).to(cuda)
+    with _lib.use_debug_library() as L:
+        L.cpx_postproc_set_fused(0)
+        staged = _chain(L, dP, cp, lg)
+        L.cpx_postproc_set_fused(1)
+    for it in range(20):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                ops.gemm(A, Wt, "gelu")
+        got = _chain(_lib.lib(), dP, cp, lg)
+        assert np.array_equal(got[0], staged[0]) and np.array_equal(got[1], staged[1]) and np.array_equal(got[4], staged[4]), it
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(got[3], staged[3])), it
+    torch.cuda.synchronize()
+    for H, W in ((97, 131), (200, 312), (64, 64)):
+        t = [_fields("noisy_discs", H, W, 31), _fields("random", H, W, 32)]
+        d, c, l = (torch.from_numpy(np.stack([x[k] for x in t])).to(cuda) for k in range(3))
+        with _lib.use_debug_library() as L:
+            L.cpx_postproc_set_fused(0)
+            st = _chain(L, d, c, l)
+            L.cpx_postproc_set_fused(1)
+        got = _chain(_lib.lib(), d, c, l)
+        assert np.array_equal(got[0], st[0]) and np.array_equal(got[1], st[1]) and np.array_equal(got[2], st[2])
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(got[3], st[3]))
+        assert np.array_equal(got[0][0], dynamics.compute_masks(t[0][0], t[0][1]))
