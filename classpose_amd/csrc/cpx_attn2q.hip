@@ -13,6 +13,11 @@
 //   * with one workgroup per CU nothing hides an item seam (G = Q table^T, ring refill, pipeline fill: 5.4 k cycles, epilogue
 //     2.9 k of 52 k per item even with the ring and the Q rows prefetched across the seam) nor the per-tile barrier + DMA /
 //     LDS-read issue (~250 of ~1 150 cycles per 64 x 32 tile) -- the three co-resident workgroups of k_attention4p do.
+//   * a second form (variant 4, GL) drops the LDS ring altogether -- every wave loads its K / V^T fragments straight from global
+//     memory one tile ahead, no LDS-DMA requests, no per-tile barrier, no ds_read, the waves never synchronise -- and is bitwise
+//     equal and 1.7 % faster (219.8 against 223.5 us): the per-tile staging was not where the time goes; the half step is.
+//     What remains above the 330-cycle issue bound of a half step is the overflow vote (v_cmp -> scalar branch: ~70 cycles of
+//     exposed latency per half step, tools/micro/mfma_fill.hip "half step as in k_attention2q" 450 against 382 without it).
 //   So the bound for head dim 64 with this bias and a bf16 P is ~(2 x 330 + 150) cycles per (64 queries x 32 keys) per SIMD
 //   = 0.39 of the MFMA peak at the clock held, before seams; the kernel reaches 0.26, the production kernel 0.27-0.28.
 //
@@ -124,6 +129,15 @@ __device__ __forceinline__ unsigned V_or3(unsigned a, unsigned b, unsigned c) {
     unsigned r; asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
 
+// GL variant: a K / V^T fragment straight from global memory (L2 / the CU's vector L1: the four waves of a workgroup read the
+// same 8 KB per tile within a few hundred cycles of each other) into the registers the MFMAs read -- no LDS ring, no
+// LDS-DMA requests, no per-tile barrier, no ds_read; the request goes out one whole tile before its first use
+template <int OFF>
+__device__ __forceinline__ u32x4 g_load128(const unsigned short *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+    return v;
+}
 #define A2_THREADS 256
 #define A2_SLOT 8192                    // K tile (32 keys x 64 d) + V^T tile (64 d x 32 keys), halves
 #define A2_G_LD 68                      // padded row of the G scratch (fp16): [wave][chain][32 q][68]: 8-byte aligned rows,
@@ -160,7 +174,7 @@ __device__ __forceinline__ void A_zero16(f32x16 &acc) {
 // workgroups of an XCD are on 8 (sub-tile, head) pairs at a time (2 MB of K / V^T in its 4 MB L2).  Across an item seam the
 // K / V^T ring keeps running (the last three tiles of an item request the first three of the next), the next item's Q rows
 // are requested before the epilogue's stores go out, and the rel-pos tables stay in AGPRs for the whole launch.
-template <bool F16, bool DBG = false, int ABL = 0>
+template <bool F16, bool DBG = false, int ABL = 0, bool GL = false>
 __global__ void __launch_bounds__(A2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__restrict__ vT,
               const unsigned short *__restrict__ relh, const unsigned short *__restrict__ relw,
@@ -207,7 +221,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
     coords(l, s, head, q4);
     const unsigned short *ksrc = qkv + (size_t)s * 1024 * 3072 + head * 64 + koff;
     const unsigned short *vsrc = vT + ((size_t)s * 16 + head) * 64 * 1024 + voff;
-    issue(ksrc, vsrc, 0); issue(ksrc, vsrc, 1); issue(ksrc, vsrc, 2);
+    if constexpr (!GL) { issue(ksrc, vsrc, 0); issue(ksrc, vsrc, 1); issue(ksrc, vsrc, 2); }
 
     // ---- Q fragments (MFMA B operand) of both chains of the first item
     u32x4 qf[2][4];
@@ -235,6 +249,19 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             va[db * 2 + st] = lds0 + 4096u + (unsigned)(d * 64 + (((2 * st + h2) ^ ((d >> 2) & 3)) * 16));
         }
     _Float16 *Gbase = reinterpret_cast<_Float16 *>(a2_smem + 4 * A2_SLOT) + wave * 2 * 32 * A2_G_LD;
+    // GL: this lane's fragment origins inside a (sub-tile, head) pair: K row pi(r), d 8 h2 (+ 16 ks by immediate);
+    // V^T rows r and 32 + r, key 8 h2 (+ 16 st by immediate); tile t adds 32 rows of qkv / 32 keys
+    const int klane = krow * 3072 + 1024 + 8 * h2, vlane = r * 1024 + 8 * h2;
+    auto kptr = [&](int s_, int head_, int t) { return qkv + (size_t)s_ * 1024 * 3072 + head_ * 64 + klane + (size_t)t * 32 * 3072; };
+    auto vptr = [&](int s_, int head_, int t) { return vT + ((size_t)s_ * 16 + head_) * 64 * 1024 + vlane + t * 32; };
+    auto load_k = [&](u32x4 (&dst)[4], const unsigned short *p) {
+        dst[0] = g_load128<0>(p); dst[1] = g_load128<32>(p); dst[2] = g_load128<64>(p); dst[3] = g_load128<96>(p);
+    };
+    auto load_v = [&](u32x4 (&dst)[4], const unsigned short *p) {          // [db * 2 + st]
+        dst[0] = g_load128<0>(p); dst[1] = g_load128<32>(p);
+        const unsigned short *p1 = p + 32 * 1024;
+        dst[2] = g_load128<0>(p1); dst[3] = g_load128<32>(p1);
+    };
 
     const float cexp = 0.125f * 1.44269504088896340736f;
     const f32x2 cexp2 = {cexp, cexp};
@@ -255,6 +282,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
     unsigned ghb[2], gaddr[2];
     f32x2 off2[2];
     using std::integral_constant;
+    if constexpr (GL) { load_k(kf[0], kptr(s, head, 0)); load_k(kf[1], kptr(s, head, 1)); load_v(vf[0], vptr(s, head, 0)); }
 
     for (;;) {
         const int l_next = l + l_stride;
@@ -304,12 +332,14 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             // Gh[q][qh - kh + 31] of chain c: address for kh = 0, minus 2 bytes per tile
             gaddr[c] = lds0 + 4u * A2_SLOT + (unsigned)(((wave * 2 + c) * 32 * A2_G_LD + r * A2_G_LD + qh0 + c + 31) * 2);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tiles 0..2 and this wave's G rows have landed
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tiles 0..2 (GL: K(0), K(1), V(0)) and this wave's G rows have landed
+        if constexpr (!GL) __builtin_amdgcn_s_barrier();                 // (GL: the waves never touch each other's data)
 
         // pipeline fill: K(0) fragments, gh of tile 0 for both chains, S[0] = K(0) Q0^T + Gw0
-        kf[0][0] = a2_read128<0>(ka[0]); kf[0][1] = a2_read128<0>(ka[1]);
-        kf[0][2] = a2_read128<0>(ka[2]); kf[0][3] = a2_read128<0>(ka[3]);
+        if constexpr (!GL) {
+            kf[0][0] = a2_read128<0>(ka[0]); kf[0][1] = a2_read128<0>(ka[1]);
+            kf[0][2] = a2_read128<0>(ka[2]); kf[0][3] = a2_read128<0>(ka[3]);
+        }
         asm volatile("ds_read_u16 %0, %1" : "=v"(ghb[0]) : "v"(gaddr[0]));
         asm volatile("ds_read_u16 %0, %1" : "=v"(ghb[1]) : "v"(gaddr[1]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -422,6 +452,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
         // one key tile = two half steps.  SL = ring slot of tile kh, SN = slot of tile kh + 1, PAR = kh & 1.
         auto tile = [&](const int kh, auto slot_tag, auto next_tag, auto par_tag) {
             constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value, PAR = decltype(par_tag)::value;
+            if constexpr (!GL) {
             // tile kh + 1 (this thread's part) has landed; behind the barrier every part has, and every wave is done with
             // slot (kh - 1) & 3 (its K and V fragments went to registers a tile ago), which the next request overwrites
             if (kh < 30 || has_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -435,6 +466,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             kf[PAR ^ 1][2] = a2_read128<SN * A2_SLOT>(ka[2]); kf[PAR ^ 1][3] = a2_read128<SN * A2_SLOT>(ka[3]);
             vf[PAR][0] = a2_read128<SL * A2_SLOT>(va[0]); vf[PAR][1] = a2_read128<SL * A2_SLOT>(va[1]);
             vf[PAR][2] = a2_read128<SL * A2_SLOT>(va[2]); vf[PAR][3] = a2_read128<SL * A2_SLOT>(va[3]);
+            }
             unsigned ghn[2];
             asm volatile("ds_read_u16 %0, %1" : "=v"(ghn[0]) : "v"(gaddr[0] - 2u * (unsigned)(kh + 1)));
             asm volatile("ds_read_u16 %0, %1" : "=v"(ghn[1]) : "v"(gaddr[1] - 2u * (unsigned)(kh + 1)));
@@ -443,6 +475,17 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             // half step A: softmax of chain 0 (tile kh) | S[1] = K(kh) Q1^T + Gw1, P.V and row sums of chain 1's tile kh - 1
             half_step(integral_constant<int, 0>{}, kf[PAR], vf[PAR ^ 1], ghb[0], ghb[1]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the ten reads above: long since landed
+            if constexpr (GL) {
+                // K(kh + 1) and V(kh), requested one tile ago, are what this half step's MFMAs read; then the requests for
+                // K(kh + 2) (into the registers half step A just finished with) and V(kh + 1); past the item's last tile:
+                // the next item's first tiles (its pipeline fill finds K(0), K(1), V(0) in place) or a harmless re-read
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int tk = kh + 2, tv = kh + 1;
+                const unsigned short *pk_ = tk < 32 ? kptr(s, head, tk) : (has_next ? kptr(s_n, head_n, tk - 32) : kptr(s, head, 31));
+                const unsigned short *pv_ = tv < 32 ? vptr(s, head, tv) : (has_next ? vptr(s_n, head_n, tv - 32) : vptr(s, head, 31));
+                load_k(kf[PAR], pk_);
+                load_v(vf[PAR ^ 1], pv_);
+            }
             __builtin_amdgcn_sched_barrier(0);
             A2_STAMP(2);
             // half step B: softmax of chain 1 (tile kh) | S[0] = K(kh + 1) Q0^T + Gw0, P.V and row sums of chain 0's tile kh
@@ -535,13 +578,27 @@ static int a2_grid(int n_subtiles) {
     return items < n_cu ? items : n_cu;
 }
 int cpx_attention2q_launch(int dtype, const void *qkv, const void *vT, const void *rel_h, const void *rel_w,
-                           int n_subtiles, void *out, hipStream_t s) {
+                           int n_subtiles, void *out, int gl, hipStream_t s) {
     static CpxOncePerDevice once;
     once([] {
         (void)hipFuncSetAttribute((const void *)k_attention2q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)k_attention2q<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_attention2q<true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
     });
     const dim3 grid(a2_grid(n_subtiles));
+    if (gl) {
+        if (dtype == CPX_DT_F16)
+            hipLaunchKernelGGL((k_attention2q<true, false, 0, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+                               (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
+                               16 * n_subtiles, (unsigned *)nullptr);
+        else
+            hipLaunchKernelGGL((k_attention2q<false, false, 0, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+                               (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
+                               16 * n_subtiles, (unsigned *)nullptr);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
     if (dtype == CPX_DT_F16)
         hipLaunchKernelGGL((k_attention2q<true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
                            (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
@@ -564,7 +621,13 @@ extern "C" int cpx_attention2q_debug(const void *qkv, const void *vT, const void
     hipLaunchKernelGGL((k_attention2q<false, true, ABL_>), dim3(a2_grid(n_subtiles)), dim3(A2_THREADS), A2_LDS_BYTES, (hipStream_t)stream, \
                        (const unsigned short *)qkv, (const unsigned short *)vT, (const unsigned short *)rel_h,                   \
                        (const unsigned short *)rel_w, (unsigned short *)out, 16 * n_subtiles, dbg); } while (0)
-    if (g_a2_abl == 1) A2_DBG_LAUNCH(1); else if (g_a2_abl == 2) A2_DBG_LAUNCH(2); else A2_DBG_LAUNCH(0);
+    if (g_a2_abl == 1) A2_DBG_LAUNCH(1); else if (g_a2_abl == 2) A2_DBG_LAUNCH(2);
+    else if (g_a2_abl == 4) {        // the GL variant (fragments straight from global memory), stamped
+        (void)hipFuncSetAttribute((const void *)k_attention2q<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        hipLaunchKernelGGL((k_attention2q<false, true, 0, true>), dim3(a2_grid(n_subtiles)), dim3(A2_THREADS), A2_LDS_BYTES, (hipStream_t)stream,
+                           (const unsigned short *)qkv, (const unsigned short *)vT, (const unsigned short *)rel_h,
+                           (const unsigned short *)rel_w, (unsigned short *)out, 16 * n_subtiles, dbg);
+    } else A2_DBG_LAUNCH(0);
 #undef A2_DBG_LAUNCH
     CPX_CHECK_LAUNCH();
     return CPX_OK;

@@ -59,7 +59,7 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
 int cpx_attention_trv_enabled(void);
 // round-4 attention kernel (cpx_attn2q.hip): one wave per SIMD, two query rows per wave; vT holds V^T already
 int cpx_attention2q_launch(int dtype, const void *qkv, const void *vT, const void *rel_h, const void *rel_w,
-                           int n_subtiles, void *out, hipStream_t s);
+                           int n_subtiles, void *out, int gl, hipStream_t s);
 
 // float32 kernels (exact-f32 MFMA): cpx_net_f32.hip
 int cpx_gemm_f32(const float *A, const float *Wt, int M, int N, int K, int epilogue, const float *bias,

@@ -291,7 +291,12 @@ class NetWeights:
             t = block(p, cur, fid, seq[i], fc, seq[i + 1], h, last_relu=(i != len(fts) - 1))
             cur = add(2, t, -1, seq[i + 1], 0, seq[i + 1], h, False, p + "upconv")
             h *= 2
-        assert h == 32 and out_ch % 8 == 0
+        if h != 32:
+            raise ValueError(f"UNet head: {len(fts)} levels do not end on the 32 x 32 token grid (reached {h})")
+        if out_ch % 8 != 0:
+            # the last layer writes 16-byte chunks of out_ch columns (8 x 8 pixel shuffle per class): a checkpoint whose
+            # class count breaks that must be rejected here, not reach the device kernels unpadded (asserts vanish under -O)
+            raise ValueError(f"UNet head: out_ch = {out_ch} is not a multiple of 8")
         self.unet_ops = (CpxConvOp * len(ops))(*ops)
         self.c.n_unet_ops = len(ops)
         self.c.unet_ops = C.cast(self.unet_ops, C.POINTER(CpxConvOp))

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classpose_amd import _lib, ops
 dev = torch.device("cuda:0"); L = _lib.lib()
+VARIANTS = (2, 3, 4)      # 2 production (k_attention4p), 3 k_attention2q with the LDS ring, 4 k_attention2q with fragments straight from global memory
 nS = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 def rel_l2(a, b): return float((a - b).norm() / b.norm())
 def ref64(qkv, rel, s0=0):
@@ -21,7 +22,7 @@ for dt in (torch.bfloat16, torch.float16):
     qkv = (torch.randn(nS * 1024, 3072, generator=g) * 0.7).to(dt).to(dev)
     rel = (torch.randn(64, 64, generator=g) * 0.8).to(dt).to(dev); rel[63] = 0
     outs = {}
-    for v in (2, 3):
+    for v in VARIANTS:
         L.cpx_attention_set_variant(v)
         outs[v] = ops.attention(qkv, rel, rel)
         for i in range(10):
@@ -29,13 +30,13 @@ for dt in (torch.bfloat16, torch.float16):
     torch.cuda.synchronize()
     for s0 in (0, nS - 1):
         r = ref64(qkv, rel, s0)
-        print(f"{dt}: sub-tile {s0}: rel-L2 vs float64  variant 2 {rel_l2(outs[2][s0*1024:(s0+1)*1024].double(), r):.3e}   variant 3 {rel_l2(outs[3][s0*1024:(s0+1)*1024].double(), r):.3e}   "
-              f"max|3 - 2| {float((outs[3].float() - outs[2].float()).abs().max()):.3e}  finite {bool(torch.isfinite(outs[3].float()).all())}")
+        print(f"{dt}: sub-tile {s0}: rel-L2 vs float64  " + "   ".join(f"variant {v} {rel_l2(outs[v][s0*1024:(s0+1)*1024].double(), r):.3e}" for v in VARIANTS) +
+              f"   4 == 3 bitwise: {bool(torch.equal(outs[4], outs[3]))}  finite {bool(torch.isfinite(outs[4].float()).all())}")
     # spiked rows: the rescale path
     q2 = (torch.randn(1024, 3072, generator=g) * 0.1); q2[:, :1024] = 1.0; q2[700, 1024:2048] = 30.0
     q2 = q2.to(dt).to(dev); z = torch.zeros(64, 64, dtype=dt, device=dev)
     r2 = ref64(q2, z)
-    for v in (2, 3):
+    for v in VARIANTS:
         L.cpx_attention_set_variant(v)
         o = ops.attention(q2, z, z)
         print(f"{dt}: spiked key: variant {v} max |err| {float((o.double() - r2).abs().max()):.3e}")
@@ -50,7 +51,7 @@ q3[:, 1024:2048] += (u[None] * ramp).reshape(1024, 1024)
 for dt in (torch.bfloat16, torch.float16):
     qq = q3.to(dt).to(dev); z = torch.zeros(64, 64, dtype=dt, device=dev)
     r3 = ref64(qq, z)
-    for v in (2, 3):
+    for v in VARIANTS:
         L.cpx_attention_set_variant(v)
         o = ops.attention(qq, z, z)
         print(f"{dt}: ramp (repeated rescale): variant {v} rel-L2 vs float64 {rel_l2(o.double(), r3):.3e}  finite {bool(torch.isfinite(o.float()).all())}")
@@ -60,9 +61,9 @@ qkv = (torch.randn(nS * 1024, 3072, generator=g) * 0.7).to(torch.bfloat16).to(de
 rel = (torch.randn(64, 64, generator=g) * 0.8).to(torch.bfloat16).to(dev); rel[63] = 0
 vt = torch.empty((nS * 1024, 1024), dtype=torch.bfloat16, device=dev); out = torch.empty_like(vt)
 st = torch.cuda.current_stream().cuda_stream
-t = {2: [], 3: []}
+t = {v: [] for v in VARIANTS}
 for rnd in range(8):
-    for v in (2, 3):
+    for v in VARIANTS:
         L.cpx_attention_set_variant(v)
         for _ in range(3): ops.attention(qkv, rel, rel)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,6 +72,6 @@ for rnd in range(8):
         e1.record(); torch.cuda.synchronize()
         t[v].append(e0.elapsed_time(e1) / 20 * 1e3)
 L.cpx_attention_set_variant(2)
-for v in (2, 3):
+for v in VARIANTS:
     m = np.median(t[v])
     print(f"variant {v}: median {m:7.1f} us  min {min(t[v]):7.1f}  (incl. the V transpose kernel)  {4.43e9 * nS / m / 1e6:7.1f} TFLOP/s = {4.43e9 * nS / m / 1e6 / 2500:.3f} of 2.5 PF")

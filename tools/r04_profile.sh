@@ -2,8 +2,8 @@
 # Round-4 profile collection (run on the GPU box from the repo root): kernel-trace stats of the bench command and
 # separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA utilisation).  The program itself follows `--` (no wrapper).
 set -u
-cd /tmp && export TMPDIR=/tmp
 R=$(cd "$(dirname "$0")/.." && pwd)     # the repo root, from the script's own location (works outside the harness)
+cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/r04prof
 mkdir -p $O
 B="python3 $R/bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-side-lines --no-live-traffic"
