@@ -418,8 +418,11 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
     if keep is None:
         st: dict = {}
         keep = geojson.dedup_exact(cen, cells["area"], stats=st)
+        import resource
         logger.info(f"De-duplication (scipy KDTree pair set, the reference's own order): {st.get('n_pairs', 0)} neighbour pairs, "
-                    f"{st.get('n_order_dependent', 0)} cells in order-dependent clusters (>= 3 neighbours), {time.time() - t_dd:.2f} s")
+                    f"{st.get('n_order_dependent', 0)} cells in order-dependent clusters (>= 3 neighbours), {time.time() - t_dd:.2f} s, "
+                    f"peak RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576:.1f} GiB "
+                    "(the pair set is a Python set of tuples: CLASSPOSE_DEDUP_BACKEND=device is the option for slides of many millions of cells)")
     logger.info(f"Number of cells after de-duplication: {len(keep)}")
 
     def filter_within(keep, polys):          # STRtree.query(points, "within"): one hit per containing polygon
