@@ -13,11 +13,17 @@
 //   * with one workgroup per CU nothing hides an item seam (G = Q table^T, ring refill, pipeline fill: 5.4 k cycles, epilogue
 //     2.9 k of 52 k per item even with the ring and the Q rows prefetched across the seam) nor the per-tile barrier + DMA /
 //     LDS-read issue (~250 of ~1 150 cycles per 64 x 32 tile) -- the three co-resident workgroups of k_attention4p do.
-//   * a second form (variant 4, GL) drops the LDS ring altogether -- every wave loads its K / V^T fragments straight from global
-//     memory one tile ahead, no LDS-DMA requests, no per-tile barrier, no ds_read, the waves never synchronise -- and is bitwise
-//     equal and 1.7 % faster (219.8 against 223.5 us): the per-tile staging was not where the time goes; the half step is.
-//     What remains above the 330-cycle issue bound of a half step is the overflow vote (v_cmp -> scalar branch: ~70 cycles of
-//     exposed latency per half step, tools/micro/mfma_fill.hip "half step as in k_attention2q" 450 against 382 without it).
+//   * two more forms, both bitwise equal to the first and neither faster: variant 4 (GL) drops the LDS ring -- every wave loads
+//     its K / V^T fragments straight from global memory one tile ahead, no LDS-DMA requests, no per-tile barrier, no ds_read, the
+//     waves never synchronise -- 218.0 against 218.9 us (its stamps show the loads of one tile ahead still ~800 cycles away when
+//     they are needed: L2 latency under this load exceeds a tile); variant 5 (NV) additionally drops the per-half-step overflow
+//     vote (tile 0 excepted; the row sums are checked once per item and the wave re-runs the item in the exact mode if they read
+//     >= 2^100 / inf / NaN, which the spiked-key test exercises) -- 217.7 us;
+//   * the decisive measurement is the wall time of the STAMPED kernel with its streams ablated (tools/attn2q_stamps.py 0..3):
+//     245.9 us as built, 196.7 without its MFMAs, 189.9 without its vector instructions, 122.4 with NEITHER -- the two pipes
+//     overlap well (their removal saves 49 / 56 us), and half of the launch is the skeleton around them: staging, waits,
+//     barrier, item seams (and, in that build, ~125 cycles per s_memtime stamp, four per tile).  One workgroup per CU has
+//     nothing to run beside that skeleton; the production kernel's three co-resident workgroups per CU do.
 //   So the bound for head dim 64 with this bias and a bf16 P is ~(2 x 330 + 150) cycles per (64 queries x 32 keys) per SIMD
 //   = 0.39 of the MFMA peak at the clock held, before seams; the kernel reaches 0.26, the production kernel 0.27-0.28.
 //
@@ -174,7 +180,7 @@ __device__ __forceinline__ void A_zero16(f32x16 &acc) {
 // workgroups of an XCD are on 8 (sub-tile, head) pairs at a time (2 MB of K / V^T in its 4 MB L2).  Across an item seam the
 // K / V^T ring keeps running (the last three tiles of an item request the first three of the next), the next item's Q rows
 // are requested before the epilogue's stores go out, and the rel-pos tables stay in AGPRs for the whole launch.
-template <bool F16, bool DBG = false, int ABL = 0, bool GL = false>
+template <bool F16, bool DBG = false, int ABL = 0, bool GL = false, bool NV = false>
 __global__ void __launch_bounds__(A2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__restrict__ vT,
               const unsigned short *__restrict__ relh, const unsigned short *__restrict__ relw,
@@ -294,11 +300,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
         const int qh0 = q4 * 8 + wave * 2;                     // image rows of this wave's two chains: qh0, qh0 + 1
         const size_t tok0 = (size_t)s * 1024;
 
-        // ---- seam: clear the accumulators, G = Q table^T -> Gw (C operand of S, registers) and Gh (fp16 LDS scratch)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { A_zero16(O0[c]); A_zero16(O1[c]); A_zero4(L[c]); }
-        pf[0][0] = pf[0][1] = pf[1][0] = pf[1][1] = zero4;
-        m_run[0] = m_run[1] = -1e30f;
+        // ---- seam: G = Q table^T -> Gw (C operand of S, registers) and Gh (fp16 LDS scratch)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             _Float16 *G = Gbase + c * 32 * A2_G_LD;
@@ -331,6 +333,21 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             compute_G(tfh);
             // Gh[q][qh - kh + 31] of chain c: address for kh = 0, minus 2 bytes per tile
             gaddr[c] = lds0 + 4u * A2_SLOT + (unsigned)(((wave * 2 + c) * 32 * A2_G_LD + r * A2_G_LD + qh0 + c + 31) * 2);
+        }
+        // NV (no-vote mode, GL only): the key loop runs WITHOUT the per-half-step overflow vote (tile 0, whose reference is still
+        // -inf, excepted).  That is exact as long as nothing overflows: the softmax is shift-invariant, a probability formed
+        // against a reference that a later, larger score overtakes is simply a large finite number (bf16 carries the exponent
+        // range of f32), and the accumulators are f32.  Only a score that beats the first tile's maximum by more than ~120
+        // octaves (83 nats) can overflow; the row sums then read inf / NaN (or >= 2^100) at the end of the item and THIS WAVE
+        // re-runs the item in the exact mode (vote + rescale every half step, the behaviour of the other variants).
+        bool safe = !NV, redo = false;
+      for (;;) {                           // passes over this item (NV: at most two)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { A_zero16(O0[c]); A_zero16(O1[c]); A_zero4(L[c]); }
+        pf[0][0] = pf[0][1] = pf[1][0] = pf[1][1] = zero4;
+        m_run[0] = m_run[1] = -1e30f;
+        if constexpr (GL && NV) {
+            if (redo) { load_k(kf[0], kptr(s, head, 0)); load_k(kf[1], kptr(s, head, 1)); load_v(vf[0], vptr(s, head, 0)); }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tiles 0..2 (GL: K(0), K(1), V(0)) and this wave's G rows have landed
         if constexpr (!GL) __builtin_amdgcn_s_barrier();                 // (GL: the waves never touch each other's data)
@@ -389,21 +406,22 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
         // other chain from the K fragments `kx` and adds chain X's PREVIOUS P (pf[X]) times the V fragments `vx` to O[X] / L[X].
         // 10 MFMAs, each followed by <= 28 issue cycles of vector work (v_fma 4, v_exp 8, v_cvt_pk 4).  Afterwards the
         // exponent offset of chain X's NEXT softmax is prepared from gh_next_x.
-        auto half_step = [&](auto chain_tag, const u32x4 (&kx)[4], const u32x4 (&vx)[4], unsigned gh_c, unsigned gh_next_x) {
+        auto half_step = [&](auto chain_tag, auto vote_tag, const u32x4 (&kx)[4], const u32x4 (&vx)[4], unsigned gh_c, unsigned gh_next_x) {
             constexpr int C = decltype(chain_tag)::value, X = 1 - C;
+            constexpr bool VOTE = decltype(vote_tag)::value;
             unsigned pk[8];
             f32x2 a0, a1, a2, a3, a4, a5, a6, a7;
             float e0, e1, e2, e3;
             const f32x2 of = off2[C];
             // ABL (stamped debug build, timing only): 1 = this stream without its MFMAs, 2 = without its vector instructions
-#define MF_init if constexpr (ABL != 1) MF_init
-#define MF_accv if constexpr (ABL != 1) MF_accv
-#define MF_acca if constexpr (ABL != 1) MF_acca
-#define MF_rowsum if constexpr (ABL != 1) MF_rowsum
-#define V_pkfma(A_, B_, C_) (ABL == 2 ? (f32x2){0.f, 0.f} : V_pkfma(A_, B_, C_))
-#define V_exp(A_) (ABL == 2 ? 0.f : V_exp(A_))
-#define V_or3(A_, B_, C_) (ABL == 2 ? 0u : V_or3(A_, B_, C_))
-#define V_cvtx(A_, B_) (ABL == 2 ? 0u : V_cvt<F16>(A_, B_))
+#define MF_init if constexpr (ABL != 1 && ABL != 3) MF_init
+#define MF_accv if constexpr (ABL != 1 && ABL != 3) MF_accv
+#define MF_acca if constexpr (ABL != 1 && ABL != 3) MF_acca
+#define MF_rowsum if constexpr (ABL != 1 && ABL != 3) MF_rowsum
+#define V_pkfma(A_, B_, C_) (ABL >= 2 ? (f32x2){0.f, 0.f} : V_pkfma(A_, B_, C_))
+#define V_exp(A_) (ABL >= 2 ? 0.f : V_exp(A_))
+#define V_or3(A_, B_, C_) (ABL >= 2 ? 0u : V_or3(A_, B_, C_))
+#define V_cvtx(A_, B_) (ABL >= 2 ? 0u : V_cvt<F16>(A_, B_))
 #define SV(j) ((f32x2){S[C][2 * (j)], S[C][2 * (j) + 1]})
             // (MFMAs on one accumulator sit >= 4 gaps apart, the S chain 2 gaps: a dependent 32x32x16 needs ~70 cycles)
             MF_init<F16>(S[X], kx[0], qf[X][0], GW[X]);
@@ -422,14 +440,17 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             a7 = V_pkfma(SV(7), cexp2, of); e0 = V_exp(a6.x); e1 = V_exp(a6.y); pk[5] = V_cvtx(e2, e3);
             MF_acca<F16>(O0[X], vx[1], pf[X][1]);
             e2 = V_exp(a7.x); e3 = V_exp(a7.y); pk[6] = V_cvtx(e0, e1);
-            unsigned u0 = V_or3(pk[0], pk[1], pk[2]);
+            unsigned u0 = 0, u1 = 0;
+            if constexpr (VOTE) u0 = V_or3(pk[0], pk[1], pk[2]);
             MF_acca<F16>(O1[X], vx[3], pf[X][1]);
-            unsigned u1 = V_or3(pk[3], pk[4], pk[5]);
+            if constexpr (VOTE) u1 = V_or3(pk[3], pk[4], pk[5]);
             pk[7] = V_cvtx(e2, e3);
-            u0 = V_or3(u0, u1, pk[6]);
             // the overflow vote: compare BEFORE the last MFMA, branch (scalar) behind it
-            unsigned long long vote;
-            asm volatile("v_or_b32 %1, %1, %2\n\tv_and_b32 %1, 0x40004000, %1\n\tv_cmp_ne_u32 %0, 0, %1" : "=s"(vote), "+v"(u0) : "v"(pk[7]));
+            unsigned long long vote = 0;
+            if constexpr (VOTE) {
+                u0 = V_or3(u0, u1, pk[6]);
+                asm volatile("v_or_b32 %1, %1, %2\n\tv_and_b32 %1, 0x40004000, %1\n\tv_cmp_ne_u32 %0, 0, %1" : "=s"(vote), "+v"(u0) : "v"(pk[7]));
+            }
             MF_rowsum<F16>(L[X], ones, pf[X][1]);
 #undef SV
 #undef MF_init
@@ -445,7 +466,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
                 off2[X] = (f32x2){o, o};
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (__builtin_expect(vote != 0, 0)) softmax_exact(chain_tag, gh_c, pk);
+            if constexpr (VOTE) { if (__builtin_expect(vote != 0, 0)) softmax_exact(chain_tag, gh_c, pk); }
             pf[C][0] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
             pf[C][1] = (u32x4){pk[4], pk[5], pk[6], pk[7]};
         };
@@ -473,7 +494,9 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             __builtin_amdgcn_sched_barrier(0);
             A2_STAMP(1);
             // half step A: softmax of chain 0 (tile kh) | S[1] = K(kh) Q1^T + Gw1, P.V and row sums of chain 1's tile kh - 1
-            half_step(integral_constant<int, 0>{}, kf[PAR], vf[PAR ^ 1], ghb[0], ghb[1]);
+            const bool v = safe || kh == 0;        // (NV: votes only in tile 0 -- the reference starts at -inf -- and in a re-run)
+            if (!NV || v) half_step(integral_constant<int, 0>{}, std::true_type{}, kf[PAR], vf[PAR ^ 1], ghb[0], ghb[1]);
+            else half_step(integral_constant<int, 0>{}, integral_constant<bool, !NV>{}, kf[PAR], vf[PAR ^ 1], ghb[0], ghb[1]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the ten reads above: long since landed
             if constexpr (GL) {
                 // K(kh + 1) and V(kh), requested one tile ago, are what this half step's MFMAs read; then the requests for
@@ -489,7 +512,8 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             __builtin_amdgcn_sched_barrier(0);
             A2_STAMP(2);
             // half step B: softmax of chain 1 (tile kh) | S[0] = K(kh + 1) Q0^T + Gw0, P.V and row sums of chain 0's tile kh
-            half_step(integral_constant<int, 1>{}, kf[PAR ^ 1], vf[PAR], ghb[1], ghn[0]);
+            if (!NV || v) half_step(integral_constant<int, 1>{}, std::true_type{}, kf[PAR ^ 1], vf[PAR], ghb[1], ghn[0]);
+            else half_step(integral_constant<int, 1>{}, integral_constant<bool, !NV>{}, kf[PAR ^ 1], vf[PAR], ghb[1], ghn[0]);
             ghb[0] = ghn[0]; ghb[1] = ghn[1];
             A2_STAMP(3);
         };
@@ -506,6 +530,19 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
         MF_acca<F16>(O1[1], vf[1][3], pf[1][1]);
         MF_rowsum<F16>(L[1], ones, pf[1][0]);
         MF_rowsum<F16>(L[1], ones, pf[1][1]);
+        if constexpr (NV) {
+            if (!safe) {
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // row sums (AGPRs) -> vector pipe
+                const float l00 = L[0][0], l01 = L[0][1], l10 = L[1][0], l11 = L[1][1];
+                // exponent field >= 227: >= 2^100, inf or NaN (an integer test: this file is built with -fno-honor-nans)
+                const unsigned em = 0x7F800000u, lim = 0x71800000u;
+                const bool bad = (__float_as_uint(l00) & em) >= lim || (__float_as_uint(l01) & em) >= lim ||
+                                 (__float_as_uint(l10) & em) >= lim || (__float_as_uint(l11) & em) >= lim;
+                if (__any(bad)) { safe = true; redo = true; continue; }
+            }
+        }
+        break;
+      }
         // the next item's Q rows: requested now, consumed by the next seam's G products (behind the stores below)
         if (has_next) {
             const int qh0n = q4_n * 8 + wave * 2;
@@ -587,6 +624,15 @@ int cpx_attention2q_launch(int dtype, const void *qkv, const void *vT, const voi
         (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
     });
     const dim3 grid(a2_grid(n_subtiles));
+    if (gl == 2 && dtype != CPX_DT_F16) {          // no-vote mode (bf16 only: fp16 probabilities overflow at 2^16, far too soon)
+        static CpxOncePerDevice once_nv;
+        once_nv([] { (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES); });
+        hipLaunchKernelGGL((k_attention2q<false, false, 0, true, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+                           (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
+                           16 * n_subtiles, (unsigned *)nullptr);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
     if (gl) {
         if (dtype == CPX_DT_F16)
             hipLaunchKernelGGL((k_attention2q<true, false, 0, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
@@ -621,7 +667,7 @@ extern "C" int cpx_attention2q_debug(const void *qkv, const void *vT, const void
     hipLaunchKernelGGL((k_attention2q<false, true, ABL_>), dim3(a2_grid(n_subtiles)), dim3(A2_THREADS), A2_LDS_BYTES, (hipStream_t)stream, \
                        (const unsigned short *)qkv, (const unsigned short *)vT, (const unsigned short *)rel_h,                   \
                        (const unsigned short *)rel_w, (unsigned short *)out, 16 * n_subtiles, dbg); } while (0)
-    if (g_a2_abl == 1) A2_DBG_LAUNCH(1); else if (g_a2_abl == 2) A2_DBG_LAUNCH(2);
+    if (g_a2_abl == 1) A2_DBG_LAUNCH(1); else if (g_a2_abl == 2) A2_DBG_LAUNCH(2); else if (g_a2_abl == 3) A2_DBG_LAUNCH(3);
     else if (g_a2_abl == 4) {        // the GL variant (fragments straight from global memory), stamped
         (void)hipFuncSetAttribute((const void *)k_attention2q<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
         hipLaunchKernelGGL((k_attention2q<false, true, 0, true>), dim3(a2_grid(n_subtiles)), dim3(A2_THREADS), A2_LDS_BYTES, (hipStream_t)stream,

@@ -25,6 +25,12 @@ for nS in (32,):
     for _ in range(3):
         _lib.check(L.cpx_attention2q_debug(qkv.data_ptr(), vt.data_ptr(), rel.data_ptr(), rel.data_ptr(), nS, out.data_ptr(), dbg.data_ptr(), st))
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        _lib.check(L.cpx_attention2q_debug(qkv.data_ptr(), vt.data_ptr(), rel.data_ptr(), rel.data_ptr(), nS, out.data_ptr(), dbg.data_ptr(), st))
+    e1.record(); torch.cuda.synchronize()
+    print(f"   wall time of the stamped launch: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")
     d = dbg.cpu().numpy().astype(np.int64).reshape(-1, 8)
     d = d[d[:, 7] > 0]                 # only the first min(#CUs, 64 nS) workgroups exist
     items = d[:, 7:8]
