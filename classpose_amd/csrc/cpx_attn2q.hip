@@ -18,7 +18,10 @@
 //     waves never synchronise -- 218.0 against 218.9 us (its stamps show the loads of one tile ahead still ~800 cycles away when
 //     they are needed: L2 latency under this load exceeds a tile); variant 5 (NV) additionally drops the per-half-step overflow
 //     vote (tile 0 excepted; the row sums are checked once per item and the wave re-runs the item in the exact mode if they read
-//     >= 2^100 / inf / NaN, which the spiked-key test exercises) -- 217.7 us;
+//     >= 2^100 / inf / NaN, which the spiked-key test exercises) -- 217.7 us; variant 6 requests the fragments TWO tiles ahead
+//     into four rotating sets that live in AGPRs (loads straight into the accumulator file, MFMA A operands read from it) so
+//     that no load is waited for -- 229.7 against 226.9 (variant 4) / 228.9 (variant 3) / 223.2 us (production) on a slower
+//     lease: every form of the staging lands on the same time, i.e. the staging is not what bounds this structure;
 //   * the decisive measurement is the wall time of the STAMPED kernel with its streams ablated (tools/attn2q_stamps.py 0..3):
 //     245.9 us as built, 196.7 without its MFMAs, 189.9 without its vector instructions, 122.4 with NEITHER -- the two pipes
 //     overlap well (their removal saves 49 / 56 us), and half of the launch is the skeleton around them: staging, waits,
@@ -80,13 +83,24 @@ __device__ __forceinline__ int pi_perm(int r) { return (r & ~12) | ((r & 4) << 1
 // Hazards the compiler cannot see through inline asm, all kept by construction: an MFMA result is read by the vector pipe
 // no earlier than half a tile after it was issued; a v_exp_f32 result is consumed >= 2 instructions later; VALU results
 // that feed an MFMA (P) are written >= 4 instructions before it.
-template <bool F16> __device__ __forceinline__ void MF_init(f32x16 &d, const u32x4 &a, const u32x4 &b, const f32x16 &c) {
-    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+// (AF: the A operand -- a K / V^T fragment -- lives in AGPRs: the GL = 2 form loads its fragments straight into them)
+template <bool F16, bool AF = false> __device__ __forceinline__ void MF_init(f32x16 &d, const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+    if constexpr (AF) {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "v"(b), "v"(c));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "v"(b), "v"(c));
+    } else {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    }
 }
-template <bool F16> __device__ __forceinline__ void MF_accv(f32x16 &d, const u32x4 &a, const u32x4 &b) {
-    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+template <bool F16, bool AF = false> __device__ __forceinline__ void MF_accv(f32x16 &d, const u32x4 &a, const u32x4 &b) {
+    if constexpr (AF) {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+    } else {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    }
 }
 // row sums of P on the HALF-size matrix instruction: D (16 x 16, AGPRs) += SEL (16 x 32) . P^T-fragment read as a (32 x 16) B
 // operand.  The fragment was built for the 32x32x16 shape (lane (r, h2): query r, keys 8 h2 .. 8 h2 + 7); read as a 16x16x32 B
@@ -111,9 +125,14 @@ __device__ __forceinline__ void A_scale16(f32x16 &acc, float alpha) {
         acc[i] = x;
     }
 }
-template <bool F16> __device__ __forceinline__ void MF_acca(f32x16 &d, const u32x4 &a, const u32x4 &b) {
-    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+template <bool F16, bool AF = false> __device__ __forceinline__ void MF_acca(f32x16 &d, const u32x4 &a, const u32x4 &b) {
+    if constexpr (AF) {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
+    } else {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+    }
 }
 // a = s * c + off on a register pair: TWO scalar FMAs -- a v_pk_fma_f32 beside MFMAs in flight costs ~30 cycles (the packed
 // f32 unit and the matrix pipe get in each other's way; profiles/r04_attn2q_stamps.txt, MI355X_MICROARCH "price of one
@@ -142,6 +161,12 @@ template <int OFF>
 __device__ __forceinline__ u32x4 g_load128(const unsigned short *p) {
     u32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 g_load128a(const unsigned short *p) {          // destination in AGPRs
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(v) : "v"(p), "n"(OFF));
     return v;
 }
 #define A2_THREADS 256
@@ -180,7 +205,9 @@ __device__ __forceinline__ void A_zero16(f32x16 &acc) {
 // workgroups of an XCD are on 8 (sub-tile, head) pairs at a time (2 MB of K / V^T in its 4 MB L2).  Across an item seam the
 // K / V^T ring keeps running (the last three tiles of an item request the first three of the next), the next item's Q rows
 // are requested before the epilogue's stores go out, and the rel-pos tables stay in AGPRs for the whole launch.
-template <bool F16, bool DBG = false, int ABL = 0, bool GL = false, bool NV = false>
+// GL: 0 = LDS-DMA ring; 1 = fragments straight from global memory, requested one tile ahead into VGPRs; 2 = two tiles ahead, four
+// rotating fragment sets in AGPRs (the MFMA A operand may be an AGPR)
+template <bool F16, bool DBG = false, int ABL = 0, int GL = 0, bool NV = false>
 __global__ void __launch_bounds__(A2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__restrict__ vT,
               const unsigned short *__restrict__ relh, const unsigned short *__restrict__ relw,
@@ -202,8 +229,10 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            tfw[jb][ks] = *reinterpret_cast<const u32x4 *>(relw + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
-            tfh[jb][ks] = *reinterpret_cast<const u32x4 *>(relh + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+            if constexpr (GL != 2) {      // (GL = 2 needs the AGPRs for its four fragment sets: it re-reads the tables, L2-hot, at every seam)
+                tfw[jb][ks] = *reinterpret_cast<const u32x4 *>(relw + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+                tfh[jb][ks] = *reinterpret_cast<const u32x4 *>(relh + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+            }
         }
 
     // ---- ring requests: thread -> 16 bytes of K (key tid>>3, position tid&7) and of V^T (d tid>>2, position tid&3)
@@ -227,6 +256,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
     coords(l, s, head, q4);
     const unsigned short *ksrc = qkv + (size_t)s * 1024 * 3072 + head * 64 + koff;
     const unsigned short *vsrc = vT + ((size_t)s * 16 + head) * 64 * 1024 + voff;
+    constexpr bool AF = GL == 2;
     if constexpr (!GL) { issue(ksrc, vsrc, 0); issue(ksrc, vsrc, 1); issue(ksrc, vsrc, 2); }
 
     // ---- Q fragments (MFMA B operand) of both chains of the first item
@@ -261,12 +291,13 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
     auto kptr = [&](int s_, int head_, int t) { return qkv + (size_t)s_ * 1024 * 3072 + head_ * 64 + klane + (size_t)t * 32 * 3072; };
     auto vptr = [&](int s_, int head_, int t) { return vT + ((size_t)s_ * 16 + head_) * 64 * 1024 + vlane + t * 32; };
     auto load_k = [&](u32x4 (&dst)[4], const unsigned short *p) {
-        dst[0] = g_load128<0>(p); dst[1] = g_load128<32>(p); dst[2] = g_load128<64>(p); dst[3] = g_load128<96>(p);
+        if constexpr (AF) { dst[0] = g_load128a<0>(p); dst[1] = g_load128a<32>(p); dst[2] = g_load128a<64>(p); dst[3] = g_load128a<96>(p); }
+        else { dst[0] = g_load128<0>(p); dst[1] = g_load128<32>(p); dst[2] = g_load128<64>(p); dst[3] = g_load128<96>(p); }
     };
     auto load_v = [&](u32x4 (&dst)[4], const unsigned short *p) {          // [db * 2 + st]
-        dst[0] = g_load128<0>(p); dst[1] = g_load128<32>(p);
         const unsigned short *p1 = p + 32 * 1024;
-        dst[2] = g_load128<0>(p1); dst[3] = g_load128<32>(p1);
+        if constexpr (AF) { dst[0] = g_load128a<0>(p); dst[1] = g_load128a<32>(p); dst[2] = g_load128a<0>(p1); dst[3] = g_load128a<32>(p1); }
+        else { dst[0] = g_load128<0>(p); dst[1] = g_load128<32>(p); dst[2] = g_load128<0>(p1); dst[3] = g_load128<32>(p1); }
     };
 
     const float cexp = 0.125f * 1.44269504088896340736f;
@@ -282,13 +313,14 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
     f32x16 S[2], O0[2], O1[2], GW[2];
     f32x4 L[2];
     float m_run[2];
-    u32x4 kf[2][4], vf[2][4], pf[2][2];
+    u32x4 kf[4][4], vf[4][4], pf[2][2];          // fragment sets: 2 in use (by tile parity) for GL < 2, 4 (tile & 3) for GL = 2
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { vf[1][i] = zero4; vf[0][i] = zero4; kf[1][i] = zero4; kf[0][i] = zero4; }
+    for (int i = 0; i < 4; ++i) { vf[1][i] = zero4; vf[0][i] = zero4; kf[1][i] = zero4; kf[0][i] = zero4; vf[3][i] = zero4; }
     unsigned ghb[2], gaddr[2];
     f32x2 off2[2];
     using std::integral_constant;
     if constexpr (GL) { load_k(kf[0], kptr(s, head, 0)); load_k(kf[1], kptr(s, head, 1)); load_v(vf[0], vptr(s, head, 0)); }
+    if constexpr (GL == 2) { load_k(kf[2], kptr(s, head, 2)); load_v(vf[1], vptr(s, head, 1)); }
 
     for (;;) {
         const int l_next = l + l_stride;
@@ -304,8 +336,26 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             _Float16 *G = Gbase + c * 32 * A2_G_LD;
-            auto compute_G = [&](const u32x4 (&tf)[2][4]) {
+            auto compute_G = [&](const u32x4 (&tf_)[2][4], const unsigned short *table) {
                 f32x16 acc[2];
+                if constexpr (GL == 2) {
+                    u32x4 tl[2][4];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) tl[jb][ks] = *reinterpret_cast<const u32x4 *>(table + (jb * 32 + r) * 64 + 16 * ks + 8 * h2);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[jb]) : "v"(tl[jb][0]), "v"(qf[c][0]));
+                        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[jb]) : "v"(tl[jb][0]), "v"(qf[c][0]));
+#pragma unroll
+                        for (int ks = 1; ks < 4; ++ks) {
+                            if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[jb]) : "v"(tl[jb][ks]), "v"(qf[c][ks]));
+                            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[jb]) : "v"(tl[jb][ks]), "v"(qf[c][ks]));
+                        }
+                    }
+                } else {
+                const u32x4 (&tf)[2][4] = tf_;
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
                     if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[jb]) : "a"(tf[jb][0]), "v"(qf[c][0]));
@@ -315,6 +365,7 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
                         if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[jb]) : "a"(tf[jb][ks]), "v"(qf[c][ks]));
                         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[jb]) : "a"(tf[jb][ks]), "v"(qf[c][ks]));
                     }
+                }
                 }
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> vector pipe
 #pragma unroll
@@ -327,10 +378,10 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
                         *reinterpret_cast<uint2 *>(G + r * A2_G_LD + jb * 32 + 8 * g4 + 4 * h2) = w;
                     }
             };
-            compute_G(tfw);
+            compute_G(tfw, relw);
 #pragma unroll
             for (int i = 0; i < 16; ++i) GW[c][i] = (float)G[r * A2_G_LD + (r - pi_perm((i & 3) + 8 * (i >> 2) + 4 * h2) + 31)];
-            compute_G(tfh);
+            compute_G(tfh, relh);
             // Gh[q][qh - kh + 31] of chain c: address for kh = 0, minus 2 bytes per tile
             gaddr[c] = lds0 + 4u * A2_SLOT + (unsigned)(((wave * 2 + c) * 32 * A2_G_LD + r * A2_G_LD + qh0 + c + 31) * 2);
         }
@@ -361,10 +412,10 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
         asm volatile("ds_read_u16 %0, %1" : "=v"(ghb[1]) : "v"(gaddr[1]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        MF_init<F16>(S[0], kf[0][0], qf[0][0], GW[0]);
-        MF_accv<F16>(S[0], kf[0][1], qf[0][1]);
-        MF_accv<F16>(S[0], kf[0][2], qf[0][2]);
-        MF_accv<F16>(S[0], kf[0][3], qf[0][3]);
+        MF_init<F16, AF>(S[0], kf[0][0], qf[0][0], GW[0]);
+        MF_accv<F16, AF>(S[0], kf[0][1], qf[0][1]);
+        MF_accv<F16, AF>(S[0], kf[0][2], qf[0][2]);
+        MF_accv<F16, AF>(S[0], kf[0][3], qf[0][3]);
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");       // S[0] is read by the vector pipe below
         // exponent offset of the FIRST softmax of each chain: (gh - m_run) * cexp, as a broadcast pair
 #pragma unroll
@@ -424,25 +475,25 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
 #define V_cvtx(A_, B_) (ABL >= 2 ? 0u : V_cvt<F16>(A_, B_))
 #define SV(j) ((f32x2){S[C][2 * (j)], S[C][2 * (j) + 1]})
             // (MFMAs on one accumulator sit >= 4 gaps apart, the S chain 2 gaps: a dependent 32x32x16 needs ~70 cycles)
-            MF_init<F16>(S[X], kx[0], qf[X][0], GW[X]);
+            MF_init<F16, AF>(S[X], kx[0], qf[X][0], GW[X]);
             a0 = V_pkfma(SV(0), cexp2, of); a1 = V_pkfma(SV(1), cexp2, of); e0 = V_exp(a0.x); e1 = V_exp(a0.y);
             MF_rowsum<F16>(L[X], ones, pf[X][0]);
             a2 = V_pkfma(SV(2), cexp2, of); e2 = V_exp(a1.x); e3 = V_exp(a1.y); pk[0] = V_cvtx(e0, e1);
-            MF_accv<F16>(S[X], kx[1], qf[X][1]);
+            MF_accv<F16, AF>(S[X], kx[1], qf[X][1]);
             a3 = V_pkfma(SV(3), cexp2, of); e0 = V_exp(a2.x); e1 = V_exp(a2.y); pk[1] = V_cvtx(e2, e3);
-            MF_acca<F16>(O0[X], vx[0], pf[X][0]);
+            MF_acca<F16, AF>(O0[X], vx[0], pf[X][0]);
             a4 = V_pkfma(SV(4), cexp2, of); e2 = V_exp(a3.x); e3 = V_exp(a3.y); pk[2] = V_cvtx(e0, e1);
-            MF_accv<F16>(S[X], kx[2], qf[X][2]);
+            MF_accv<F16, AF>(S[X], kx[2], qf[X][2]);
             a5 = V_pkfma(SV(5), cexp2, of); e0 = V_exp(a4.x); e1 = V_exp(a4.y); pk[3] = V_cvtx(e2, e3);
-            MF_acca<F16>(O1[X], vx[2], pf[X][0]);
+            MF_acca<F16, AF>(O1[X], vx[2], pf[X][0]);
             a6 = V_pkfma(SV(6), cexp2, of); e2 = V_exp(a5.x); e3 = V_exp(a5.y); pk[4] = V_cvtx(e0, e1);
-            MF_accv<F16>(S[X], kx[3], qf[X][3]);
+            MF_accv<F16, AF>(S[X], kx[3], qf[X][3]);
             a7 = V_pkfma(SV(7), cexp2, of); e0 = V_exp(a6.x); e1 = V_exp(a6.y); pk[5] = V_cvtx(e2, e3);
-            MF_acca<F16>(O0[X], vx[1], pf[X][1]);
+            MF_acca<F16, AF>(O0[X], vx[1], pf[X][1]);
             e2 = V_exp(a7.x); e3 = V_exp(a7.y); pk[6] = V_cvtx(e0, e1);
             unsigned u0 = 0, u1 = 0;
             if constexpr (VOTE) u0 = V_or3(pk[0], pk[1], pk[2]);
-            MF_acca<F16>(O1[X], vx[3], pf[X][1]);
+            MF_acca<F16, AF>(O1[X], vx[3], pf[X][1]);
             if constexpr (VOTE) u1 = V_or3(pk[3], pk[4], pk[5]);
             pk[7] = V_cvtx(e2, e3);
             // the overflow vote: compare BEFORE the last MFMA, branch (scalar) behind it
@@ -495,10 +546,12 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             A2_STAMP(1);
             // half step A: softmax of chain 0 (tile kh) | S[1] = K(kh) Q1^T + Gw1, P.V and row sums of chain 1's tile kh - 1
             const bool v = safe || kh == 0;        // (NV: votes only in tile 0 -- the reference starts at -inf -- and in a re-run)
-            if (!NV || v) half_step(integral_constant<int, 0>{}, std::true_type{}, kf[PAR], vf[PAR ^ 1], ghb[0], ghb[1]);
-            else half_step(integral_constant<int, 0>{}, integral_constant<bool, !NV>{}, kf[PAR], vf[PAR ^ 1], ghb[0], ghb[1]);
+            // fragment sets: K(kh), V(kh - 1) for half step A; K(kh + 1), V(kh) for half step B
+            constexpr int KA = GL == 2 ? SL : PAR, VA = GL == 2 ? (SL + 3) & 3 : PAR ^ 1, KB = GL == 2 ? SN : PAR ^ 1, VB = GL == 2 ? SL : PAR;
+            if (!NV || v) half_step(integral_constant<int, 0>{}, std::true_type{}, kf[KA], vf[VA], ghb[0], ghb[1]);
+            else half_step(integral_constant<int, 0>{}, integral_constant<bool, !NV>{}, kf[KA], vf[VA], ghb[0], ghb[1]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the ten reads above: long since landed
-            if constexpr (GL) {
+            if constexpr (GL == 1) {
                 // K(kh + 1) and V(kh), requested one tile ago, are what this half step's MFMAs read; then the requests for
                 // K(kh + 2) (into the registers half step A just finished with) and V(kh + 1); past the item's last tile:
                 // the next item's first tiles (its pipeline fill finds K(0), K(1), V(0) in place) or a harmless re-read
@@ -509,11 +562,21 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
                 load_k(kf[PAR], pk_);
                 load_v(vf[PAR ^ 1], pv_);
             }
+            if constexpr (GL == 2) {
+                // two tiles ahead: K(kh + 1) and V(kh) were requested two half-step-B's ago -- everything but the youngest
+                // eight requests has landed -- then K(kh + 3) and V(kh + 2) go into the sets last used by tiles kh - 1 / kh - 2
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                const int tk = kh + 3, tv = kh + 2;
+                const unsigned short *pk_ = tk < 32 ? kptr(s, head, tk) : (has_next ? kptr(s_n, head_n, tk - 32) : kptr(s, head, 31));
+                const unsigned short *pv_ = tv < 32 ? vptr(s, head, tv) : (has_next ? vptr(s_n, head_n, tv - 32) : vptr(s, head, 31));
+                load_k(kf[(SL + 3) & 3], pk_);
+                load_v(vf[(SL + 2) & 3], pv_);
+            }
             __builtin_amdgcn_sched_barrier(0);
             A2_STAMP(2);
             // half step B: softmax of chain 1 (tile kh) | S[0] = K(kh + 1) Q0^T + Gw0, P.V and row sums of chain 0's tile kh
-            if (!NV || v) half_step(integral_constant<int, 1>{}, std::true_type{}, kf[PAR ^ 1], vf[PAR], ghb[1], ghn[0]);
-            else half_step(integral_constant<int, 1>{}, integral_constant<bool, !NV>{}, kf[PAR ^ 1], vf[PAR], ghb[1], ghn[0]);
+            if (!NV || v) half_step(integral_constant<int, 1>{}, std::true_type{}, kf[KB], vf[VB], ghb[1], ghn[0]);
+            else half_step(integral_constant<int, 1>{}, integral_constant<bool, !NV>{}, kf[KB], vf[VB], ghb[1], ghn[0]);
             ghb[0] = ghn[0]; ghb[1] = ghn[1];
             A2_STAMP(3);
         };
@@ -524,10 +587,11 @@ k_attention2q(const unsigned short *__restrict__ qkv, const unsigned short *__re
             tile(kh0 + 3, integral_constant<int, 3>{}, integral_constant<int, 0>{}, integral_constant<int, 1>{});
         }
         // pipeline drain: P.V and row sums of chain 1's last tile (V(31) sits in vf[1])
-        MF_acca<F16>(O0[1], vf[1][0], pf[1][0]);
-        MF_acca<F16>(O1[1], vf[1][2], pf[1][0]);
-        MF_acca<F16>(O0[1], vf[1][1], pf[1][1]);
-        MF_acca<F16>(O1[1], vf[1][3], pf[1][1]);
+        constexpr int VD = GL == 2 ? 3 : 1;                  // the set holding V(31)
+        MF_acca<F16, AF>(O0[1], vf[VD][0], pf[1][0]);
+        MF_acca<F16, AF>(O1[1], vf[VD][2], pf[1][0]);
+        MF_acca<F16, AF>(O0[1], vf[VD][1], pf[1][1]);
+        MF_acca<F16, AF>(O1[1], vf[VD][3], pf[1][1]);
         MF_rowsum<F16>(L[1], ones, pf[1][0]);
         MF_rowsum<F16>(L[1], ones, pf[1][1]);
         if constexpr (NV) {
@@ -620,14 +684,31 @@ int cpx_attention2q_launch(int dtype, const void *qkv, const void *vT, const voi
     once([] {
         (void)hipFuncSetAttribute((const void *)k_attention2q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)k_attention2q<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)k_attention2q<true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_attention2q<true, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
     });
     const dim3 grid(a2_grid(n_subtiles));
+    if (gl == 3) {                                  // two tiles ahead, fragment sets in AGPRs
+        static CpxOncePerDevice once_g2;
+        once_g2([] {
+            (void)hipFuncSetAttribute((const void *)k_attention2q<true, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        });
+        if (dtype == CPX_DT_F16)
+            hipLaunchKernelGGL((k_attention2q<true, false, 0, 2>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+                               (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
+                               16 * n_subtiles, (unsigned *)nullptr);
+        else
+            hipLaunchKernelGGL((k_attention2q<false, false, 0, 2>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+                               (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
+                               16 * n_subtiles, (unsigned *)nullptr);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
     if (gl == 2 && dtype != CPX_DT_F16) {          // no-vote mode (bf16 only: fp16 probabilities overflow at 2^16, far too soon)
         static CpxOncePerDevice once_nv;
-        once_nv([] { (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES); });
-        hipLaunchKernelGGL((k_attention2q<false, false, 0, true, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+        once_nv([] { (void)hipFuncSetAttribute((const void *)k_attention2q<false, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES); });
+        hipLaunchKernelGGL((k_attention2q<false, false, 0, 1, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
                            (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
                            16 * n_subtiles, (unsigned *)nullptr);
         CPX_CHECK_LAUNCH();
@@ -635,11 +716,11 @@ int cpx_attention2q_launch(int dtype, const void *qkv, const void *vT, const voi
     }
     if (gl) {
         if (dtype == CPX_DT_F16)
-            hipLaunchKernelGGL((k_attention2q<true, false, 0, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+            hipLaunchKernelGGL((k_attention2q<true, false, 0, 1>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
                                (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
                                16 * n_subtiles, (unsigned *)nullptr);
         else
-            hipLaunchKernelGGL((k_attention2q<false, false, 0, true>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
+            hipLaunchKernelGGL((k_attention2q<false, false, 0, 1>), grid, dim3(A2_THREADS), A2_LDS_BYTES, s, (const unsigned short *)qkv,
                                (const unsigned short *)vT, (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out,
                                16 * n_subtiles, (unsigned *)nullptr);
         CPX_CHECK_LAUNCH();
@@ -669,8 +750,8 @@ extern "C" int cpx_attention2q_debug(const void *qkv, const void *vT, const void
                        (const unsigned short *)rel_w, (unsigned short *)out, 16 * n_subtiles, dbg); } while (0)
     if (g_a2_abl == 1) A2_DBG_LAUNCH(1); else if (g_a2_abl == 2) A2_DBG_LAUNCH(2); else if (g_a2_abl == 3) A2_DBG_LAUNCH(3);
     else if (g_a2_abl == 4) {        // the GL variant (fragments straight from global memory), stamped
-        (void)hipFuncSetAttribute((const void *)k_attention2q<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
-        hipLaunchKernelGGL((k_attention2q<false, true, 0, true>), dim3(a2_grid(n_subtiles)), dim3(A2_THREADS), A2_LDS_BYTES, (hipStream_t)stream,
+        (void)hipFuncSetAttribute((const void *)k_attention2q<false, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
+        hipLaunchKernelGGL((k_attention2q<false, true, 0, 1>), dim3(a2_grid(n_subtiles)), dim3(A2_THREADS), A2_LDS_BYTES, (hipStream_t)stream,
                            (const unsigned short *)qkv, (const unsigned short *)vT, (const unsigned short *)rel_h,
                            (const unsigned short *)rel_w, (unsigned short *)out, 16 * n_subtiles, dbg);
     } else A2_DBG_LAUNCH(0);

@@ -1052,7 +1052,7 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
     }
 #endif
 #ifdef CPX_DEBUG
-    if (g_att_v8 >= 3 && g_att_v8 <= 5) return cpx_attention2q_launch(dtype, qkv, vT_ws, rel_h, rel_w, n_subtiles, out, g_att_v8 - 3, s);   // round-4 experiments
+    if (g_att_v8 >= 3 && g_att_v8 <= 6) return cpx_attention2q_launch(dtype, qkv, vT_ws, rel_h, rel_w, n_subtiles, out, g_att_v8 - 3, s);   // round-4 experiments
 #endif
     const dim3 grid4(8, 16, n_subtiles);
     static CpxOncePerDevice once4;

@@ -25,7 +25,7 @@ int cpx_gemm_pingpong_occupancy(void);      /* workgroups of the ping-pong kerne
 void cpx_gemm_set_reverse(int on);          /* 0 (default): mlp.lin2 walks M backwards when 1            */
 void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */
 void cpx_attention_set_xcd_order(int on);   /* 1 (default): (sub-tile, head) pairs pinned to one XCD     */
-void cpx_attention_set_variant(int v);      /* 2: 4-wave, LDS-DMA ring + pipelined S; 0: 4-wave register ring; 1: 8-wave ping-pong; 3: one wave per SIMD, two query rows per wave (LDS ring); 4: the same with fragments straight from global memory; 5: 4 without the per-half-step overflow vote (bf16) */
+void cpx_attention_set_variant(int v);      /* 2: 4-wave, LDS-DMA ring + pipelined S; 0: 4-wave register ring; 1: 8-wave ping-pong; 3: one wave per SIMD, two query rows per wave (LDS ring); 4: the same with fragments straight from global memory; 5: 4 without the per-half-step overflow vote (bf16); 6: fragments two tiles ahead in AGPR sets */
 void cpx_attention_set_lsum(int on);        /* 0 (default): 1 = softmax denominators by an all-ones MFMA (experiment)           */
 void cpx_attention_set_trv(int on);         /* 0 (default): V through ds_read_b64_tr_b16                  */
 void cpx_postproc_set_fused(int on);        /* 1 (default): the 16-launch fused chain of cpx_compute_masks; 0: the stage-wise sequence (38 launches) */

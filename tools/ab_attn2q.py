@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classpose_amd import _lib, ops
 dev = torch.device("cuda:0"); L = _lib.lib()
-VARIANTS = (2, 3, 4, 5)   # 2 production (k_attention4p), 3 k_attention2q with the LDS ring, 4 with fragments straight from global memory,
+VARIANTS = (2, 3, 4, 5, 6)   # 2 production (k_attention4p), 3 k_attention2q with the LDS ring, 4 with fragments straight from global memory,
+                          # 6 = fragments requested TWO tiles ahead into four rotating AGPR sets;
                           # 5 = 4 without the per-half-step overflow vote (per-item check + exact re-run; bf16 only, fp16 falls back to 4)
 nS = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 def rel_l2(a, b): return float((a - b).norm() / b.norm())
