@@ -41,8 +41,6 @@ struct PPLayout {
 #define SC_HASBIG 4
 #define SC_HASBG 5
 #define SC_VMAX 6
-#define SC_TICKET 8         // "last workgroup of this launch" counter (fused chain)
-#define SC_TICKET2 9
 #define PP_MAXCLS 32
 
 #define FG_BLOCK 1024       // k_prep_flow workgroup = one segment of the foreground list

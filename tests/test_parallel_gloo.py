@@ -87,6 +87,46 @@ def test_gather_to_root_world4():
         assert r[3].shape == (3 + 4 + 5 + 6, 48) and r[4] == 4.0 and r[5] == 10.0
 
 
+def _cells_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    from classpose_amd.entrypoints import predict_wsi as pw
+    n = 3 + 2 * rank                                   # cells of this rank, 4 vertices each
+    cells = np.zeros(n, pw.CELL_ROW)
+    cells["area"] = 100 * rank + np.arange(n); cells["n_pts"] = 4; cells["cls"] = rank + 1
+    xy = (np.arange(n * 4 * 2, dtype=np.float64).reshape(-1, 2) + 1000 * rank)
+    tiles = np.arange(n, dtype=np.int64) * world + rank
+    c, v, t = pw.gather_cells(cells, xy, torch.device("cpu"), tiles)
+    parallel.barrier()
+    q.put((rank, c.copy(), None if v is None else v.copy(), t.copy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_gather_cells_rows_everywhere_vertices_on_rank0_only():
+    """the CLI's exchange (predict_wsi.gather_cells) over gloo, world 3: cell rows + tile indices on every rank in rank order,
+    the vertex pool on rank 0 only"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cells_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    n_tot = 3 + 5 + 7
+    for r, c, v, t in res:
+        assert len(c) == n_tot and len(t) == n_tot
+        assert list(c["cls"]) == [1] * 3 + [2] * 5 + [3] * 7
+        assert np.array_equal(c.view(np.uint8), res[0][1].view(np.uint8)) and np.array_equal(t, res[0][3])
+        if r == 0:
+            assert v.shape == (n_tot * 4, 2) and v[0, 0] == 0 and v[12, 0] == 1000 and v[12 + 20, 0] == 2000
+        else:
+            assert v is None
+
+
 def test_single_process_passthrough():
     rec = torch.zeros((4, 48), dtype=torch.uint8)
     assert parallel.all_gather_records(rec) is rec
