@@ -384,6 +384,29 @@ __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][
                 acc[mb][nb] = mfma16v<F16>(fw[nb][ks], fx[mb][ks], (FIRST && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][nb]);
     __builtin_amdgcn_s_setprio(0);
 }
+// SPLIT (experiment, round 4): fragment reads ordered k-substep 0 first, so that the first eight MFMAs of a phase can start
+// behind a COUNTED lgkmcnt while the k-substep-1 fragments are still landing
+template <int HM>
+__device__ __forceinline__ void g2_read_x_ks(u32x4 (&fx)[4][2], unsigned b0, unsigned b1) {
+    fx[0][0] = lds_read128<HM * G2_HALF + 0 * 2048>(b0); fx[1][0] = lds_read128<HM * G2_HALF + 1 * 2048>(b0);
+    fx[2][0] = lds_read128<HM * G2_HALF + 2 * 2048>(b0); fx[3][0] = lds_read128<HM * G2_HALF + 3 * 2048>(b0);
+    fx[0][1] = lds_read128<HM * G2_HALF + 0 * 2048>(b1); fx[1][1] = lds_read128<HM * G2_HALF + 1 * 2048>(b1);
+    fx[2][1] = lds_read128<HM * G2_HALF + 2 * 2048>(b1); fx[3][1] = lds_read128<HM * G2_HALF + 3 * 2048>(b1);
+}
+template <int HN>
+__device__ __forceinline__ void g2_read_w_ks(u32x4 (&fw)[2][2], unsigned b0, unsigned b1) {
+    fw[0][0] = lds_read128<(2 + HN) * G2_HALF + 0 * 2048>(b0); fw[1][0] = lds_read128<(2 + HN) * G2_HALF + 1 * 2048>(b0);
+    fw[0][1] = lds_read128<(2 + HN) * G2_HALF + 0 * 2048>(b1); fw[1][1] = lds_read128<(2 + HN) * G2_HALF + 1 * 2048>(b1);
+}
+template <bool F16, bool FIRST, int KS>
+__device__ __forceinline__ void g2_mma_ks(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][2], const u32x4 (&fw)[2][2]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = mfma16v<F16>(fw[nb][KS], fx[mb][KS], (FIRST && KS == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][nb]);
+}
+#define G2_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define G2_BAR() __builtin_amdgcn_s_barrier()
 #define G2_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -394,6 +417,7 @@ __device__ __forceinline__ void g2_mma(f32x4 (&acc)[4][2], const u32x4 (&fx)[4][
 #define G2F_STATS 2
 #define G2F_DBG 4
 #define G2F_Q4 8          // persistent kernel: quarter-tile epilogue (experiment, debug build)
+#define G2F_SPLIT 16      // persistent kernel: counted LDS waits inside a phase (experiment, round 4)
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16 && EPI != CPX_EPI_POS_BF16;
@@ -842,7 +866,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
 
         f32x4 acc[2][2][4][2];                       // not cleared: K tile 0 is peeled and starts every accumulator with C = 0
         u32x4 fx[4][2], fw[2][2];
-#define G2_TILE(T, B, FIRST)                                                                       \
+#define G2_TILE_PLAIN(T, B, FIRST)                                                                       \
     {                                                                                       \
         const int t_ = (T);                                                                 \
         g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
@@ -868,6 +892,57 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         g2_mma<F16, FIRST>(acc[1][0], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
     }
+#define G2_TILE_SPLIT(T, B, FIRST)                                                                 \
+    {                                                                                       \
+        const int t_ = (T);                                                                 \
+        /* p1: W0 + X0 -> (0,0): ks 0 operands = the first 6 of the 12 reads */             \
+        fw[0][0] = lds_read128<2 * G2_HALF>(wb[B][0]); fw[1][0] = lds_read128<2 * G2_HALF + 2048>(wb[B][0]); \
+        fx[0][0] = lds_read128<0>(xb[B][0]); fx[1][0] = lds_read128<2048>(xb[B][0]);        \
+        fx[2][0] = lds_read128<4096>(xb[B][0]); fx[3][0] = lds_read128<6144>(xb[B][0]);     \
+        fw[0][1] = lds_read128<2 * G2_HALF>(wb[B][1]); fw[1][1] = lds_read128<2 * G2_HALF + 2048>(wb[B][1]); \
+        fx[0][1] = lds_read128<0>(xb[B][1]); fx[1][1] = lds_read128<2048>(xb[B][1]);        \
+        fx[2][1] = lds_read128<4096>(xb[B][1]); fx[3][1] = lds_read128<6144>(xb[B][1]);     \
+        if (t_ + 1 < nk) stage(1, t_ + 1);                                                  \
+        G2_BAR(); G2_LGKM(6);                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                      \
+        g2_mma_ks<F16, FIRST, 0>(acc[0][0], fx, fw);                                        \
+        G2_LGKM(0);                                                                         \
+        g2_mma_ks<F16, FIRST, 1>(acc[0][0], fx, fw);                                        \
+        __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        /* p2: W1 -> (0,1) */                                                               \
+        g2_read_w_ks<1>(fw, wb[B][0], wb[B][1]);                                            \
+        if (t_ + 1 < nk) stage(2, t_ + 1);                                                  \
+        G2_BAR(); G2_LGKM(2);                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                      \
+        g2_mma_ks<F16, FIRST, 0>(acc[0][1], fx, fw);                                        \
+        G2_LGKM(0);                                                                         \
+        g2_mma_ks<F16, FIRST, 1>(acc[0][1], fx, fw);                                        \
+        __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        /* p3: X1 -> (1,1) */                                                               \
+        g2_read_x_ks<1>(fx, xb[B][0], xb[B][1]);                                            \
+        if (t_ + 2 < nk) stage(0, t_ + 2);                                                  \
+        G2_BAR(); G2_LGKM(4);                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                      \
+        g2_mma_ks<F16, FIRST, 0>(acc[1][1], fx, fw);                                        \
+        G2_LGKM(0);                                                                         \
+        g2_mma_ks<F16, FIRST, 1>(acc[1][1], fx, fw);                                        \
+        __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        /* p4: W0 -> (1,0) */                                                               \
+        g2_read_w_ks<0>(fw, wb[B][0], wb[B][1]);                                            \
+        if (t_ + 2 < nk) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+        else if (t_ + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+        G2_BAR(); G2_LGKM(2);                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                      \
+        g2_mma_ks<F16, FIRST, 0>(acc[1][0], fx, fw);                                        \
+        G2_LGKM(0);                                                                         \
+        g2_mma_ks<F16, FIRST, 1>(acc[1][0], fx, fw);                                        \
+        __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+    }
+#define G2_TILE(T, B, FIRST) { if constexpr ((FLAGS & G2F_SPLIT) != 0) G2_TILE_SPLIT(T, B, FIRST) else G2_TILE_PLAIN(T, B, FIRST) }
         G2_TILE(0, 0, true)
         G2_TILE(1, 1, false)
         for (int t = 2; t < nk; t += 2) {
@@ -875,6 +950,8 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
             G2_TILE(t + 1, 1, false)
         }
 #undef G2_TILE
+#undef G2_TILE_PLAIN
+#undef G2_TILE_SPLIT
         if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
         __builtin_amdgcn_sched_barrier(0);
 
@@ -1415,6 +1492,7 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 // 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
+CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
 CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
 CPX_SWITCH(g_gemm_pp_persist, 1);   // ping-pong kernel: 1 = two persistent workgroups per CU walk the tiles, 0 = one workgroup per tile
@@ -1428,6 +1506,7 @@ extern "C" void cpx_gemm_set_l2_block(int on) { g_gemm_l2 = on; }
 extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 extern "C" void cpx_gemm_set_epi4(int on) { g_gemm_epi4 = on; }
+extern "C" void cpx_gemm_set_split(int on) { g_gemm_split = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
 extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
@@ -1535,6 +1614,13 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                     else launch_gemm256_flags<EPI, F16, G2F_DBG>(a, s);
                     return true;
                 }
+            }
+#endif
+#ifdef CPX_DEBUG
+            if (g_gemm_split) {
+                if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_SPLIT>(a, s);
+                else launch_gemm256_flags<EPI, F16, G2F_SPLIT>(a, s);
+                return true;
             }
 #endif
 #ifdef CPX_DEBUG
