@@ -783,15 +783,25 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         if (g.rev_m) tile_m = tiles_m - 1 - tile_m;
         m0_ = tile_m * 256; n0_ = tile_n * 256; tn_ = tile_n;
     };
-    const size_t k64 = (size_t)64 * K, k128 = (size_t)128 * K;
     char *sdst = smem + wave * 1024;
-    auto stage_at = [&](const unsigned short *pX_, const unsigned short *pW_, int which, int t) {
-        const unsigned short *p = (which < 2 ? pX_ : pW_) + (which & 1) * k128 + (size_t)t * 64;
+    // LDS-DMA requests as BUFFER loads (round 4): the per-lane part of the source address is ONE 32-bit offset register per operand for
+    // the whole launch (row tid >> 3 of a 64-row piece, swizzled chunk), everything that changes -- tile origin, half-tile, K tile,
+    // second piece -- is a scalar offset, so a request costs no vector instruction (the flat-pointer form recomputed a 64-bit lane
+    // address with 2-3 VALU instructions per request, 16 requests per wave and K-tile pair, all in the read phase the loop is bound by).
+    // (A and W are < 2^31 bytes: 32 768 x 4 096 bf16 = 268 MB.)
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned k64b = (unsigned)K * 128u, k128b = (unsigned)K * 256u;         // 64 / 128 rows, in bytes
+    auto stage_at = [&](unsigned voff, unsigned sX, unsigned sW, int which, int t) {
+        const unsigned so = (which < 2 ? sX : sW) + (which & 1) * k128b + (unsigned)t * 128u;
         char *d = sdst + (t & 1) * G2_BUF + which * G2_HALF;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                         (__attribute__((address_space(3))) void *)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p + k64),
-                                         (__attribute__((address_space(3))) void *)(d + 8192), 16, 0, 0);
+        if (which < 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)d, 16, voff, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(d + 8192), 16, voff, so + k64b, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void *)d, 16, voff, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void *)(d + 8192), 16, voff, so + k64b, 0, 0);
+        }
     };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     int v = blockIdx.x, m0, n0, tile_n;
@@ -818,9 +828,9 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
             xb[1][ks] = xb[0][ks] + G2_BUF;
             wb[1][ks] = wb[0][ks] + G2_BUF;
         }
-        const unsigned short *pX = g.A + (size_t)(m0 + srow) * K + kc * 8;
-        const unsigned short *pW = g.W + (size_t)(n0 + srow) * K + kc * 8;
-        auto stage = [&](int which, int t) { stage_at(pX, pW, which, t); };
+        const unsigned voff = ((unsigned)srow * (unsigned)K + (unsigned)kc * 8u) * 2u;     // this lane inside a 64-row piece (bytes)
+        const unsigned sX = (unsigned)m0 * (unsigned)K * 2u, sW = (unsigned)n0 * (unsigned)K * 2u;   // tile origins (scalar)
+        auto stage = [&](int which, int t) { if (!(DBG && (g.dbg & 64) && t > 1)) stage_at(voff, sX, sW, which, t); };
         // per-tile vectors, requested BEFORE this tile's DMAs (in-order vmcnt): LayerNorm row statistics by
         // threads 0..255, bias and column sums of the tile's 256 columns by threads 256..511
         float4 st_a = make_float4(0.f, 0.f, 0.f, 0.f), st_b = st_a;
@@ -866,31 +876,34 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
 
         f32x4 acc[2][2][4][2];                       // not cleared: K tile 0 is peeled and starts every accumulator with C = 0
         u32x4 fx[4][2], fw[2][2];
+// timing-only ablations of the main loop (DBG instantiation, results are garbage): g.dbg & 64 = no LDS-DMA requests inside the loop,
+// & 128 = no fragment reads (the MFMAs run on whatever the registers hold), & 256 = no barriers
+#define G2_BARX() do { if (!(DBG && (g.dbg & 256))) G2_BAR(); } while (0)
 #define G2_TILE_PLAIN(T, B, FIRST)                                                                       \
     {                                                                                       \
         const int t_ = (T);                                                                 \
-        g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
-        g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                               \
+        if (!(DBG && (g.dbg & 128))) g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
+        if (!(DBG && (g.dbg & 128))) g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                               \
         if (t_ + 1 < nk) stage(1, t_ + 1);                                                  \
-        G2_BAR(); G2_LGKM0();                                                               \
+        G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[0][0], fx, fw);                                                     \
-        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
-        g2_read_w<1>(fw, wb[B][0], wb[B][1]);                                               \
+        __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
+        if (!(DBG && (g.dbg & 128))) g2_read_w<1>(fw, wb[B][0], wb[B][1]);                                               \
         if (t_ + 1 < nk) stage(2, t_ + 1);                                                  \
-        G2_BAR(); G2_LGKM0();                                                               \
+        G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[0][1], fx, fw);                                                     \
-        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
-        g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                               \
+        __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
+        if (!(DBG && (g.dbg & 128))) g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                               \
         if (t_ + 2 < nk) stage(0, t_ + 2);                                                  \
-        G2_BAR(); G2_LGKM0();                                                               \
+        G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[1][1], fx, fw);                                                     \
-        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
-        g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
+        __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
+        if (!(DBG && (g.dbg & 128))) g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
         if (t_ + 2 < nk) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
         else if (t_ + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
-        G2_BAR(); G2_LGKM0();                                                               \
+        G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[1][0], fx, fw);                                                     \
-        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
+        __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
     }
 #define G2_TILE_SPLIT(T, B, FIRST)                                                                 \
     {                                                                                       \
@@ -950,6 +963,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
             G2_TILE(t + 1, 1, false)
         }
 #undef G2_TILE
+#undef G2_BARX
 #undef G2_TILE_PLAIN
 #undef G2_TILE_SPLIT
         if (wm == 0) G2_BAR();                       // re-balance the barrier count of the two wave rows
@@ -959,10 +973,9 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;
         const bool main_only = DBG && (g.dbg & 4);
         bool next_issued = false;
-        const unsigned short *pXn = g.A + (size_t)(m0n + srow) * K + kc * 8;
-        const unsigned short *pWn = g.W + (size_t)(n0n + srow) * K + kc * 8;
+        const unsigned sXn = (unsigned)m0n * (unsigned)K * 2u, sWn = (unsigned)n0n * (unsigned)K * 2u;
         auto prefetch_next = [&]() {                 // K-tile 0 of the next tile -> buffer 0 (free since K-tile nk - 2)
-            stage_at(pXn, pWn, 0, 0); stage_at(pXn, pWn, 2, 0); stage_at(pXn, pWn, 3, 0); stage_at(pXn, pWn, 1, 0);
+            stage_at(voff, sXn, sWn, 0, 0); stage_at(voff, sXn, sWn, 2, 0); stage_at(voff, sXn, sWn, 3, 0); stage_at(voff, sXn, sWn, 1, 0);
             next_issued = true;
         };
         if (main_only) {
