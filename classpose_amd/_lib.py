@@ -148,6 +148,7 @@ _PRIVATE = {
     "cpx_attention2q_set_ablation": (None, [_i]),
     "cpx_postproc_set_fused": (None, [_i]),
     "cpx_gemm_set_split": (None, [_i]),
+    "cpx_gemm_set_direct": (None, [_i]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),
     "cpx_gemm_set_pingpong": (None, [_i]),

@@ -418,6 +418,7 @@ __device__ __forceinline__ void g2_mma_ks(f32x4 (&acc)[4][2], const u32x4 (&fx)[
 #define G2F_DBG 4
 #define G2F_Q4 8          // persistent kernel: quarter-tile epilogue (experiment, debug build)
 #define G2F_SPLIT 16      // persistent kernel: counted LDS waits inside a phase (experiment, round 4)
+#define G2F_DIRECT 32     // persistent kernel: epilogue stores straight from the accumulator registers (v_permlane16_swap -> 16-byte rows), no LDS staging
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
     constexpr bool LN_IN = (FLAGS & G2F_LN) != 0 && EPI != CPX_EPI_RESID_BF16 && EPI != CPX_EPI_POS_BF16;
@@ -1103,6 +1104,73 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 G2_BAR();
             }
+        } else if constexpr (EPI != CPX_EPI_RESID_BF16 && (FLAGS & G2F_DIRECT) != 0) {
+            // ---- direct epilogue: no LDS staging, no barriers between the halves.  After packing, a lane holds 4 consecutive channels
+            // (8 bytes) of token row fr for each of the wave's two 16-channel blocks nb; v_permlane16_swap (vdst = block 0, src = block 1:
+            // lane rows 1 / 3 of block 0 <-> lane rows 0 / 2 of block 1) leaves every lane with 8 CONSECUTIVE channels -- lane row fq holds
+            // channels (fq & 1) * 16 + (fq >> 1) * 8 ... + 7 of the wave's 32 -- so one 16-byte buffer store per (half, column half, row
+            // block) writes 16 token rows x 64 contiguous bytes; the neighbouring wave column writes the other half of each 128-byte line.
+            // Store addresses: one 32-bit lane offset + scalar offsets.  The stores leave along the vector stream instead of in two bursts.
+            if (has_next) prefetch_next();
+            const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc((void *)g.out, 0, 0x7FFFFFFF, 0x00020000);
+            const unsigned ldb = (unsigned)g.ld_out * 2u;
+            const unsigned ovoff = (unsigned)(wm * 64 + fr) * ldb + (unsigned)(wn * 32 + ((fq & 1) << 4) + ((fq >> 1) << 3)) * 2u;
+            const unsigned so0 = (unsigned)m0 * ldb + (unsigned)n0 * 2u;
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm) {
+                float ln_rs[4], ln_nm[4];
+                if constexpr (LN_IN) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const float2 pr = *reinterpret_cast<const float2 *>(smem + G2P_TAIL + (hm * 128 + wm * 64 + mb * 16 + fr) * 8);
+                        ln_rs[mb] = pr.x; ln_nm[mb] = pr.y;
+                    }
+                }
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn) {
+                    float4 b[2], cs[2];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int nl = hn * 128 + wn * 32 + nb * 16 + fq * 4;
+                        b[nb] = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 2048 + nl * 4);
+                        cs[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (LN_IN) cs[nb] = *reinterpret_cast<const float4 *>(smem + G2P_TAIL + 3072 + nl * 4);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            f32x4 vv = acc[hm][hn][mb][nb];
+                            if constexpr (LN_IN) {
+                                const float nm = ln_nm[mb], rs = ln_rs[mb];
+                                vv[0] = fmaf(vv[0], rs, fmaf(nm, cs[nb].x, b[nb].x)); vv[1] = fmaf(vv[1], rs, fmaf(nm, cs[nb].y, b[nb].y));
+                                vv[2] = fmaf(vv[2], rs, fmaf(nm, cs[nb].z, b[nb].z)); vv[3] = fmaf(vv[3], rs, fmaf(nm, cs[nb].w, b[nb].w));
+                            } else {
+                                vv[0] += b[nb].x; vv[1] += b[nb].y; vv[2] += b[nb].z; vv[3] += b[nb].w;
+                            }
+                            if constexpr (EPI == CPX_EPI_GELU_BF16) {
+                                if (!DBG || !(g.dbg & 2)) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
+                                }
+                            } else if constexpr (EPI == CPX_EPI_RELU_BF16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
+                            }
+                            pk[nb][0] = pack2<F16>(vv[0], vv[1]);
+                            pk[nb][1] = pack2<F16>(vv[2], vv[3]);
+                        }
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        if (!DBG || !(g.dbg & 1) || o[0] == 0x12345678u)
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(hm * 128 + mb * 16) * ldb + (unsigned)hn * 256u, 0);
+                    }
+                }
+            }
+            // the next tile's top rewrites the LDS tail (row parameters, bias, column sums) every wave has just read from
+            G2_BAR();
         } else {
             if constexpr (EPI != CPX_EPI_RESID_BF16) {
                 if (has_next) prefetch_next();       // no global load result is consumed from here to the next tile top
@@ -1506,6 +1574,7 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
+CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
 CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
 CPX_SWITCH(g_gemm_pp_persist, 1);   // ping-pong kernel: 1 = two persistent workgroups per CU walk the tiles, 0 = one workgroup per tile
@@ -1520,6 +1589,7 @@ extern "C" void cpx_gemm_set_reverse(int on) { g_gemm_rev = on; }
 extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 extern "C" void cpx_gemm_set_epi4(int on) { g_gemm_epi4 = on; }
 extern "C" void cpx_gemm_set_split(int on) { g_gemm_split = on; }
+extern "C" void cpx_gemm_set_direct(int on) { g_gemm_direct = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
 extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
@@ -1543,7 +1613,9 @@ static void launch_gemm256_flags(const GemmArgs &a, hipStream_t s) {
     // the qkv projection keeps one workgroup per tile: a third of its tiles (the V^T ones) cannot overlap their
     // epilogue with the next prefetch and cost more, and a static tile list cannot balance that (measured +3 %)
     const bool qkv_balanced = EPI == CPX_EPI_QKV_BF16 && g_gemm_persist_qkv && (a.n_blocks / a.tiles_n) % 64 == 0 && a.tiles_n == 12;
-    if (g_gemm_persist && (EPI != CPX_EPI_QKV_BF16 || qkv_balanced)) {
+    // (the persistent kernel addresses its operands through 32-bit buffer offsets)
+    const bool fits32 = (size_t)a.M * (size_t)a.K * 2 < ((size_t)1 << 31) && (size_t)a.N * (size_t)a.K * 2 < ((size_t)1 << 31);
+    if (g_gemm_persist && fits32 && (EPI != CPX_EPI_QKV_BF16 || qkv_balanced)) {
         static CpxOncePerDevice once_p;
         static int n_cu = 0;
         once_p([] {
@@ -1623,6 +1695,13 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
 #ifdef CPX_DEBUG
             if constexpr (!F16) {
                 if (a.dbg) {
+                    if constexpr (EPI == CPX_EPI_GELU_BF16) {        // the ablations time the epilogue form production uses
+                        if (g_gemm_direct) {
+                            if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DBG | G2F_DIRECT>(a, s);
+                            else launch_gemm256_flags<EPI, F16, G2F_DBG | G2F_DIRECT>(a, s);
+                            return true;
+                        }
+                    }
                     if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DBG>(a, s);
                     else launch_gemm256_flags<EPI, F16, G2F_DBG>(a, s);
                     return true;
@@ -1645,6 +1724,20 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                 }
             }
 #endif
+            // direct-store epilogue (G2F_DIRECT): production for the GELU epilogue (mlp.lin1 -3.5 %, bitwise equal); the lighter epilogues
+            // measured equal or slower with it (qkv +1.2 %) and keep the staged rows -- cpx_gemm_set_direct(2) in the debug build forces it
+            constexpr bool DIRECT_OK = EPI == CPX_EPI_GELU_BF16
+#ifdef CPX_DEBUG
+                                       || EPI != CPX_EPI_RESID_BF16
+#endif
+                ;
+            if constexpr (DIRECT_OK) {
+                if ((EPI == CPX_EPI_GELU_BF16 ? g_gemm_direct != 0 : g_gemm_direct == 2) && (size_t)a.M * (size_t)a.ld_out * 2 < ((size_t)1 << 31)) {
+                    if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DIRECT>(a, s);
+                    else launch_gemm256_flags<EPI, F16, G2F_DIRECT>(a, s);
+                    return true;
+                }
+            }
             if (f1) launch_gemm256_flags<EPI, F16, F1>(a, s);
             else launch_gemm256_flags<EPI, F16, 0>(a, s);
             return true;
