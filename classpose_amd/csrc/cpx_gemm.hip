@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
             wb[1][ks] = wb[0][ks] + G2_BUF;
         }
         const unsigned voff = ((unsigned)srow * (unsigned)K + (unsigned)kc * 8u) * 2u;     // this lane inside a 64-row piece (bytes)
-        const unsigned sX = (unsigned)m0 * (unsigned)K * 2u, sW = (unsigned)n0 * (unsigned)K * 2u;   // tile origins (scalar)
+        const unsigned sX = (DBG && (g.dbg & 512)) ? 0u : (unsigned)m0 * (unsigned)K * 2u, sW = (unsigned)n0 * (unsigned)K * 2u;   // tile origins (scalar); dbg & 512: every tile reads the FIRST 256 activation rows (cache-resident operand, timing only)
         auto stage = [&](int which, int t) { if (!(DBG && (g.dbg & 64) && t > 1)) stage_at(voff, sX, sW, which, t); };
         // per-tile vectors, requested BEFORE this tile's DMAs (in-order vmcnt): LayerNorm row statistics by
         // threads 0..255, bias and column sums of the tile's 256 columns by threads 256..511
@@ -878,7 +878,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         f32x4 acc[2][2][4][2];                       // not cleared: K tile 0 is peeled and starts every accumulator with C = 0
         u32x4 fx[4][2], fw[2][2];
 // timing-only ablations of the main loop (DBG instantiation, results are garbage): g.dbg & 64 = no LDS-DMA requests inside the loop,
-// & 128 = no fragment reads (the MFMAs run on whatever the registers hold), & 256 = no barriers
+// & 128 = no fragment reads (the MFMAs run on whatever the registers hold), & 256 = no barriers, & 512 = all tiles read activation rows 0..255
 #define G2_BARX() do { if (!(DBG && (g.dbg & 256))) G2_BAR(); } while (0)
 #define G2_TILE_PLAIN(T, B, FIRST)                                                                       \
     {                                                                                       \
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         const bool vt_tile = (EPI == CPX_EPI_QKV_BF16) && n0 >= 2048;
         const bool main_only = DBG && (g.dbg & 4);
         bool next_issued = false;
-        const unsigned sXn = (unsigned)m0n * (unsigned)K * 2u, sWn = (unsigned)n0n * (unsigned)K * 2u;
+        const unsigned sXn = (DBG && (g.dbg & 512)) ? 0u : (unsigned)m0n * (unsigned)K * 2u, sWn = (unsigned)n0n * (unsigned)K * 2u;
         auto prefetch_next = [&]() {                 // K-tile 0 of the next tile -> buffer 0 (free since K-tile nk - 2)
             stage_at(voff, sXn, sWn, 0, 0); stage_at(voff, sXn, sWn, 2, 0); stage_at(voff, sXn, sWn, 3, 0); stage_at(voff, sXn, sWn, 1, 0);
             next_issued = true;

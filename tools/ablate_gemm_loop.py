@@ -10,7 +10,7 @@ dev = torch.device("cuda:0"); L = _lib.lib()
 M = 32768
 g = torch.Generator().manual_seed(0)
 CASES = ((4, "main loop only (no epilogue)"), (4 | 64, "  ... without LDS-DMA requests"), (4 | 128, "  ... without fragment reads"),
-         (4 | 64 | 128, "  ... without both (MFMAs + barriers)"), (4 | 256, "  ... without barriers"), (4 | 64 | 128 | 256, "  ... MFMAs alone"), (32, "full kernel"))
+         (4 | 64 | 128, "  ... without both (MFMAs + barriers)"), (4 | 256, "  ... without barriers"), (4 | 512, "  ... every tile reads activation rows 0..255 (cache-resident)"), (4 | 64 | 128 | 256, "  ... MFMAs alone"), (32, "full kernel"), (32 | 512, "full kernel, activation rows 0..255 for every tile"))
 for name, N, K, epi in (("mlp.lin1", 4096, 1024, "gelu"), ("mlp.lin2-like", 1024, 4096, "bf16")):
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
