@@ -553,11 +553,13 @@ def post_stage(L, eng, fields0, bt, dev, reps=20):
     ms = sorted(dev_b2b)[reps // 2]
     gbs = POST_BYTES_PER_TILE * bt / (ms * 1e-3) / 1e9
     prof_sum = None
-    try:                                               # rocprofv3 kernel-time sum of the same chain (tools/r03_post_profile.sh)
-        with open(os.path.join(ROOT, "profiles", "r03_post_kernel_sum.json")) as f:
-            prof_sum = json.load(f)
-    except Exception:
-        pass
+    for name in ("r04_post_kernel_sum.json", "r03_post_kernel_sum.json"):    # rocprofv3 kernel-time sum of the same chain (tools/r04_profile.sh)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                prof_sum = json.load(f)
+            break
+        except Exception:
+            pass
     return {"bound": "hbm", "ms_per_batch": round(ms, 4), "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_tile": POST_BYTES_PER_TILE,
             "launches_per_batch": launches, "reps": reps,

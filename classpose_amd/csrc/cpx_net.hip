@@ -931,16 +931,19 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     else l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     unsigned short *orow = out + (tok0 + qh * 32 + r) * 1024 + head * 64;
+    // a lane holds 4 consecutive channels (8 bytes) per group g4, its partner lane + 32 the next 4: one v_permlane32_swap per dword and
+    // group pair (vdst = group g4, src = group g4 + 1) leaves the lower half-wave with channels 8 g4 .. + 7 and the upper one with
+    // 8 (g4 + 1) .. + 7 -> four 16-byte stores per lane instead of eight 8-byte ones
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d = db * 32 + 8 * g4 + 4 * h2;
+        for (int g4 = 0; g4 < 4; g4 += 2) {
             const f32x16 &O = db ? O1 : O0;
-            uint2 o;
-            o.x = pack2<F16>(O[4 * g4 + 0] * inv, O[4 * g4 + 1] * inv);
-            o.y = pack2<F16>(O[4 * g4 + 2] * inv, O[4 * g4 + 3] * inv);
-            *reinterpret_cast<uint2 *>(orow + d) = o;
+            unsigned ax = pack2<F16>(O[4 * g4 + 0] * inv, O[4 * g4 + 1] * inv), ay = pack2<F16>(O[4 * g4 + 2] * inv, O[4 * g4 + 3] * inv);
+            unsigned bx = pack2<F16>(O[4 * g4 + 4] * inv, O[4 * g4 + 5] * inv), by = pack2<F16>(O[4 * g4 + 6] * inv, O[4 * g4 + 7] * inv);
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            *reinterpret_cast<uint4 *>(orow + db * 32 + 8 * g4 + 8 * h2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
         }
     if constexpr (DBG) {
         unsigned long long t_;
