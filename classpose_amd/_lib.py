@@ -21,7 +21,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 DTYPE_CODE = {"bf16": DT_BF16, "fp16": DT_F16, "fp32": DT_F32}
 PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2")
 # the kernel behind kind "fc1" (the dominant launch of the network; its name as rocprofv3 prints it)
-FC1_KERNEL_NAME = "k_gemm256p<GELU> = void k_gemm256p<1, false, 1>(GemmArgs)"
+FC1_KERNEL_NAME = "k_gemm256p<GELU, folded LayerNorm, direct-store epilogue> = void k_gemm256p<1, false, 33>(GemmArgs)"
 
 
 class CpxTiling(C.Structure):

@@ -15,7 +15,7 @@ gemm_flops = lambda n, k: 2.0 * M * n * k
 gemm_bytes = lambda n, k, extra=0: 2.0 * (M * k + n * k + M * n) + extra
 # kernel-name prefix -> (what, algorithmic flops per launch, algorithmic bytes per launch)
 KERNELS = [
-    ("void k_gemm256p<1, false, 1>", "mlp.lin1 (fc1, GELU + folded LayerNorm)", gemm_flops(HID, C), gemm_bytes(HID, C)),
+    ("void k_gemm256p<1, false, 33>", "mlp.lin1 (fc1, GELU + folded LayerNorm, direct-store epilogue)", gemm_flops(HID, C), gemm_bytes(HID, C)),
     ("void k_gemm256p<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), persistent with the balanced tile list", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
     ("void k_gemm256<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), one workgroup per tile", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
     ("void k_gemm256p<2, false, 2>", "attn.proj and mlp.lin2 (residual + row statistics), average of both",
@@ -89,7 +89,7 @@ traffic = {
              "counts 64 B per 128-B request for wide coalesced / LDS-DMA reads -> doubled. FETCH_SIZE is the L2's fabric-side "
              "traffic and includes Infinity-Cache hits (the W panels, 8.4 MB, and most of the 67 MB activation panel stay "
              "resident in the 256 MiB MALL), so it bounds HBM traffic from above."),
-    "dominant_kernel": "k_gemm256p<GELU> (mlp.lin1, M=32768 N=4096 K=1024), persistent form",
+    "dominant_kernel": "k_gemm256p<GELU, direct-store epilogue> (mlp.lin1, M=32768 N=4096 K=1024), persistent form",
     "fetch_bytes_per_launch_corrected": fetch,
     "write_bytes_per_launch": write,
     "traffic_bytes_per_launch": fetch + write,
