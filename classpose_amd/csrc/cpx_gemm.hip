@@ -418,6 +418,7 @@ __device__ __forceinline__ void g2_mma_ks(f32x4 (&acc)[4][2], const u32x4 (&fx)[
 #define G2F_DBG 4
 #define G2F_Q4 8          // persistent kernel: quarter-tile epilogue (experiment, debug build)
 #define G2F_SPLIT 16      // persistent kernel: counted LDS waits inside a phase (experiment, round 4)
+#define G2F_BAL 64        // persistent kernel: balanced fragment-read schedule (W0 of the next K tile pre-read in phase 4, no W0 re-read, every operand item 6 phases ahead)
 #define G2F_DIRECT 32     // persistent kernel: epilogue stores straight from the accumulator registers (v_permlane16_swap -> 16-byte rows), no LDS staging
 template <int EPI, bool F16, int FLAGS>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256(GemmArgs g) {
@@ -859,49 +860,54 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                 *reinterpret_cast<float *>(smem + G2P_TAIL + 3072 + (tid - 256) * 4) = csum_v;
             }
         };
+        constexpr bool BAL = (FLAGS & G2F_BAL) != 0;          // (launcher: nk >= 4)
         if (prefetched) {
             // K-tile 0 was requested an epilogue ago: consuming the small loads first costs only their own latency,
             // and K-tile 1's DMAs are issued AFTER that wait so that they are not drained by it
             park_tile_vectors();
-            if (nk > 1) { stage(0, 1); stage(3, 1); }
+            if (nk > 1) { stage(0, 1); stage(3, 1); if constexpr (BAL) stage(2, 1); }
         } else {
             stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-            if (nk > 1) { stage(0, 1); stage(3, 1); }
+            if (nk > 1) { stage(0, 1); stage(3, 1); if constexpr (BAL) stage(2, 1); }
             park_tile_vectors();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (BAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G2_BAR();
         if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
 
         f32x4 acc[2][2][4][2];                       // not cleared: K tile 0 is peeled and starts every accumulator with C = 0
-        u32x4 fx[4][2], fw[2][2];
+        u32x4 fx[4][2], fw[2][2], fw2[2][2];
 // timing-only ablations of the main loop (DBG instantiation, results are garbage): g.dbg & 64 = no LDS-DMA requests inside the loop,
 // & 128 = no fragment reads (the MFMAs run on whatever the registers hold), & 256 = no barriers, & 512 = all tiles read activation rows 0..255
 #define G2_BARX() do { if (!(DBG && (g.dbg & 256))) G2_BAR(); } while (0)
-#define G2_TILE_PLAIN(T, B, FIRST)                                                                       \
+// KIND -1: run-time end conditions (production); 2: steady state (t + 2 < nk), 3 / 4: the last two K tiles of nk >= 4 (no scalar branch
+// inside those bodies; available for experiments)
+#define G2_TILE_PLAIN(T, B, FIRST, KIND)                                                                 \
     {                                                                                       \
         const int t_ = (T);                                                                 \
+        const bool c1_ = (KIND) == -1 ? t_ + 1 < nk : (KIND) != 4, c2_ = (KIND) == -1 ? t_ + 2 < nk : (KIND) == 2; \
         if (!(DBG && (g.dbg & 128))) g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
         if (!(DBG && (g.dbg & 128))) g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                               \
-        if (t_ + 1 < nk) stage(1, t_ + 1);                                                  \
+        if (c1_) stage(1, t_ + 1);                                                  \
         G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[0][0], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
         if (!(DBG && (g.dbg & 128))) g2_read_w<1>(fw, wb[B][0], wb[B][1]);                                               \
-        if (t_ + 1 < nk) stage(2, t_ + 1);                                                  \
+        if (c1_) stage(2, t_ + 1);                                                  \
         G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[0][1], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
         if (!(DBG && (g.dbg & 128))) g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                               \
-        if (t_ + 2 < nk) stage(0, t_ + 2);                                                  \
+        if (c2_) stage(0, t_ + 2);                                                  \
         G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[1][1], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
         if (!(DBG && (g.dbg & 128))) g2_read_w<0>(fw, wb[B][0], wb[B][1]);                                               \
-        if (t_ + 2 < nk) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
-        else if (t_ + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+        if (c2_) { stage(3, t_ + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+        else if (c1_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
         G2_BARX(); G2_LGKM0();                                                               \
         g2_mma<F16, FIRST>(acc[1][0], fx, fw);                                                     \
         __builtin_amdgcn_sched_barrier(0); G2_BARX();                                        \
@@ -956,14 +962,70 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);                                                      \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                        \
     }
-#define G2_TILE(T, B, FIRST) { if constexpr ((FLAGS & G2F_SPLIT) != 0) G2_TILE_SPLIT(T, B, FIRST) else G2_TILE_PLAIN(T, B, FIRST) }
-        G2_TILE(0, 0, true)
-        G2_TILE(1, 1, false)
+// ---- balanced schedule (G2F_BAL).  The plain schedule reads 12 fragments in phase 1 (W0 + X0: 48 KB per wave row against a 256-cycle
+// MFMA slot of the partner row), re-reads W0 in phase 4 (28 reads per K tile) and requests W-lo only 3 phases before its first read.
+// Here the two W fragment sets swap roles every K tile: W0 of tile t sits in FA, phase 2 reads W1 into FB, phase 4 (which multiplies with
+// FA) pre-reads W0 of tile t + 1 into FB -- 8 / 4 / 8 / 4 reads, 24 per K tile, no re-read.  Requests: phase 1 X-hi(t+1), phase 2
+// W-lo(t+2), phase 3 X-lo(t+2), phase 4 W-hi(t+2): every item is refilled two phases after its region's last read (the partner row reads
+// it one barrier later) and 6 phases before its own; after its request every phase waits for the item of the NEXT phase with a counted
+// vmcnt (10 = five younger items in the steady state) in front of its mid barrier, which both rows pass before either reads the item.
+// K tile 0 reads its W0 in phase 1 (nothing pre-read it) and therefore requests W-lo(2) in phase 3; KIND 0 / 1 = the two peeled K tiles.
+#define G2_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define G2_TILE_BAL(T, B, FIRST, KIND, FA, FB)                                                       \
+    {   /* KIND 0 / 1: K tiles 0 / 1; 2: steady state (t + 2 < nk); 3 / 4: the last two K tiles -- no run-time condition in here */ \
+        const int t_ = (T);                                                                         \
+        /* p1: X0 (+ W0 for K tile 0) -> (0,0) */                                                   \
+        if ((KIND) == 0) g2_read_w<0>(FA, wb[B][0], wb[B][1]);                                      \
+        g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                                       \
+        if ((KIND) != 4) stage(1, t_ + 1);                                                          \
+        if ((KIND) == 4) G2_VM(2); else if ((KIND) != 0) G2_VM(10);                                 \
+        G2_BAR(); G2_LGKM0();                                                                       \
+        g2_mma<F16, FIRST>(acc[0][0], fx, FA);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
+        /* p2: W1 -> (0,1) */                                                                       \
+        g2_read_w<1>(FB, wb[B][0], wb[B][1]);                                                       \
+        if ((KIND) == 1 || (KIND) == 2) stage(2, t_ + 2);                                           \
+        if ((KIND) == 4) G2_VM(0); else if ((KIND) == 3) G2_VM(8); else if ((KIND) != 0) G2_VM(10); \
+        G2_BAR(); G2_LGKM0();                                                                       \
+        g2_mma<F16, FIRST>(acc[0][1], fx, FB);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
+        /* p3: X1 -> (1,1) */                                                                       \
+        g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                                       \
+        if ((KIND) <= 2) { stage(0, t_ + 2); if ((KIND) == 0) stage(2, t_ + 2); }                   \
+        if ((KIND) == 0 || (KIND) == 3) G2_VM(6); else if ((KIND) == 1) G2_VM(8); else if ((KIND) == 2) G2_VM(10); \
+        G2_BAR(); G2_LGKM0();                                                                       \
+        g2_mma<F16, FIRST>(acc[1][1], fx, FB);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
+        /* p4: pre-read W0 of K tile t + 1 (other buffer) into the set phase 3 just finished with; (1,0) multiplies with W0 = FA */ \
+        if ((KIND) != 4) g2_read_w<0>(FB, wb[(B) ^ 1][0], wb[(B) ^ 1][1]);                          \
+        if ((KIND) <= 2) stage(3, t_ + 2);                                                          \
+        if ((KIND) == 3) G2_VM(4); else if ((KIND) != 4) G2_VM(10);                                 \
+        G2_BAR(); G2_LGKM0();                                                                       \
+        g2_mma<F16, FIRST>(acc[1][0], fx, FA);                                                      \
+        __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
+    }
+        if constexpr (BAL) {
+            G2_TILE_BAL(0, 0, true, 0, fw, fw2)
+            G2_TILE_BAL(1, 1, false, 1, fw2, fw)
+            for (int t = 2; t + 2 < nk; t += 2) {
+                G2_TILE_BAL(t, 0, false, 2, fw, fw2)
+                G2_TILE_BAL(t + 1, 1, false, 2, fw2, fw)
+            }
+            G2_TILE_BAL(nk - 2, 0, false, 3, fw, fw2)
+            G2_TILE_BAL(nk - 1, 1, false, 4, fw2, fw)
+        } else {
+#define G2_TILE(T, B, FIRST, KIND) { if constexpr ((FLAGS & G2F_SPLIT) != 0) G2_TILE_SPLIT(T, B, FIRST) else G2_TILE_PLAIN(T, B, FIRST, KIND) }
+        // (peeling the last two K tiles here as well -- KIND 2 / 3 / 4 -- measured no gain for this schedule: 1.000 of the run-time form)
+        G2_TILE(0, 0, true, -1)
+        G2_TILE(1, 1, false, -1)
         for (int t = 2; t < nk; t += 2) {
-            G2_TILE(t, 0, false)
-            G2_TILE(t + 1, 1, false)
+            G2_TILE(t, 0, false, -1)
+            G2_TILE(t + 1, 1, false, -1)
         }
 #undef G2_TILE
+        }
+#undef G2_TILE_BAL
+#undef G2_VM
 #undef G2_BARX
 #undef G2_TILE_PLAIN
 #undef G2_TILE_SPLIT
@@ -1573,6 +1635,7 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 // 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
+CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of the persistent main loop (G2F_BAL; K >= 256) for the residual epilogues, 2 (debug build) = everywhere, 0 = plain
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
@@ -1590,6 +1653,7 @@ extern "C" void cpx_gemm_set_big(int on) { g_gemm_big = on; }
 extern "C" void cpx_gemm_set_epi4(int on) { g_gemm_epi4 = on; }
 extern "C" void cpx_gemm_set_split(int on) { g_gemm_split = on; }
 extern "C" void cpx_gemm_set_direct(int on) { g_gemm_direct = on; }
+extern "C" void cpx_gemm_set_balanced(int on) { g_gemm_bal = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
 extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
@@ -1731,10 +1795,33 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                                        || EPI != CPX_EPI_RESID_BF16
 #endif
                 ;
+            // balanced fragment-read schedule (G2F_BAL): production for the residual epilogues (proj 0.986, mlp.lin2 0.983 of the plain
+            // schedule in two one-process A/Bs, bitwise equal); qkv / mlp.lin1 measured 0.995-1.007 and keep the plain one
+            // (cpx_gemm_set_balanced(2) in the debug build forces it everywhere)
+            constexpr bool BAL_OK = EPI == CPX_EPI_RESID_BF16
+#ifdef CPX_DEBUG
+                                    || true
+#endif
+                ;
+            const bool bal = BAL_OK && (EPI == CPX_EPI_RESID_BF16 ? g_gemm_bal != 0 : g_gemm_bal == 2) && a.K >= 256;
             if constexpr (DIRECT_OK) {
                 if ((EPI == CPX_EPI_GELU_BF16 ? g_gemm_direct != 0 : g_gemm_direct == 2) && (size_t)a.M * (size_t)a.ld_out * 2 < ((size_t)1 << 31)) {
+#ifdef CPX_DEBUG
+                    if (bal) {
+                        if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DIRECT | G2F_BAL>(a, s);
+                        else launch_gemm256_flags<EPI, F16, G2F_DIRECT | G2F_BAL>(a, s);
+                        return true;
+                    }
+#endif
                     if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DIRECT>(a, s);
                     else launch_gemm256_flags<EPI, F16, G2F_DIRECT>(a, s);
+                    return true;
+                }
+            }
+            if constexpr (BAL_OK) {
+                if (bal) {
+                    if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_BAL>(a, s);
+                    else launch_gemm256_flags<EPI, F16, G2F_BAL>(a, s);
                     return true;
                 }
             }
