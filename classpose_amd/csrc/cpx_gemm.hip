@@ -876,10 +876,11 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
         else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G2_BAR();
-        if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
-
         f32x4 acc[2][2][4][2];                       // not cleared: K tile 0 is peeled and starts every accumulator with C = 0
         u32x4 fx[4][2], fw[2][2], fw2[2][2];
+        if constexpr (BAL) g2_read_w<0>(fw, wb[0][0], wb[0][1]);    // W0 of K tile 0, in front of the stagger barrier ("phase 4 of tile -1")
+        if (wm == 1) G2_BAR();                       // stagger the second wave row by one barrier
+
 // timing-only ablations of the main loop (DBG instantiation, results are garbage): g.dbg & 64 = no LDS-DMA requests inside the loop,
 // & 128 = no fragment reads (the MFMAs run on whatever the registers hold), & 256 = no barriers, & 512 = all tiles read activation rows 0..255
 #define G2_BARX() do { if (!(DBG && (g.dbg & 256))) G2_BAR(); } while (0)
@@ -969,30 +970,30 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
 // W-lo(t+2), phase 3 X-lo(t+2), phase 4 W-hi(t+2): every item is refilled two phases after its region's last read (the partner row reads
 // it one barrier later) and 6 phases before its own; after its request every phase waits for the item of the NEXT phase with a counted
 // vmcnt (10 = five younger items in the steady state) in front of its mid barrier, which both rows pass before either reads the item.
-// K tile 0 reads its W0 in phase 1 (nothing pre-read it) and therefore requests W-lo(2) in phase 3; KIND 0 / 1 = the two peeled K tiles.
+// W0 of K tile 0 is read right behind the tile-top barrier (in front of the stagger barrier), so K tile 0 runs the steady-state phases too
+// (its phase-3 wait counts the three items of K tile 1 the tile top requested: vmcnt(6)).
 #define G2_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define G2_TILE_BAL(T, B, FIRST, KIND, FA, FB)                                                       \
-    {   /* KIND 0 / 1: K tiles 0 / 1; 2: steady state (t + 2 < nk); 3 / 4: the last two K tiles -- no run-time condition in here */ \
+    {   /* KIND 0: K tile 0 (its W0 was read in front of the loop); 2: steady state (t + 2 < nk); 3 / 4: the last two K tiles -- no run-time condition in here */ \
         const int t_ = (T);                                                                         \
-        /* p1: X0 (+ W0 for K tile 0) -> (0,0) */                                                   \
-        if ((KIND) == 0) g2_read_w<0>(FA, wb[B][0], wb[B][1]);                                      \
+        /* p1: X0 -> (0,0) */                                                                       \
         g2_read_x<0>(fx, xb[B][0], xb[B][1]);                                                       \
         if ((KIND) != 4) stage(1, t_ + 1);                                                          \
-        if ((KIND) == 4) G2_VM(2); else if ((KIND) != 0) G2_VM(10);                                 \
+        if ((KIND) == 4) G2_VM(2); else G2_VM(10);                                                  \
         G2_BAR(); G2_LGKM0();                                                                       \
         g2_mma<F16, FIRST>(acc[0][0], fx, FA);                                                      \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
         /* p2: W1 -> (0,1) */                                                                       \
         g2_read_w<1>(FB, wb[B][0], wb[B][1]);                                                       \
-        if ((KIND) == 1 || (KIND) == 2) stage(2, t_ + 2);                                           \
-        if ((KIND) == 4) G2_VM(0); else if ((KIND) == 3) G2_VM(8); else if ((KIND) != 0) G2_VM(10); \
+        if ((KIND) <= 2) stage(2, t_ + 2);                                                          \
+        if ((KIND) == 4) G2_VM(0); else if ((KIND) == 3) G2_VM(8); else G2_VM(10);                  \
         G2_BAR(); G2_LGKM0();                                                                       \
         g2_mma<F16, FIRST>(acc[0][1], fx, FB);                                                      \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
         /* p3: X1 -> (1,1) */                                                                       \
         g2_read_x<1>(fx, xb[B][0], xb[B][1]);                                                       \
-        if ((KIND) <= 2) { stage(0, t_ + 2); if ((KIND) == 0) stage(2, t_ + 2); }                   \
-        if ((KIND) == 0 || (KIND) == 3) G2_VM(6); else if ((KIND) == 1) G2_VM(8); else if ((KIND) == 2) G2_VM(10); \
+        if ((KIND) <= 2) stage(0, t_ + 2);                                                          \
+        if ((KIND) == 0 || (KIND) == 3) G2_VM(6); else if ((KIND) == 2) G2_VM(10);                  \
         G2_BAR(); G2_LGKM0();                                                                       \
         g2_mma<F16, FIRST>(acc[1][1], fx, FB);                                                      \
         __builtin_amdgcn_sched_barrier(0); G2_BAR();                                                \
@@ -1006,7 +1007,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
     }
         if constexpr (BAL) {
             G2_TILE_BAL(0, 0, true, 0, fw, fw2)
-            G2_TILE_BAL(1, 1, false, 1, fw2, fw)
+            G2_TILE_BAL(1, 1, false, 2, fw2, fw)
             for (int t = 2; t + 2 < nk; t += 2) {
                 G2_TILE_BAL(t, 0, false, 2, fw, fw2)
                 G2_TILE_BAL(t + 1, 1, false, 2, fw2, fw)

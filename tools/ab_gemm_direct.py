@@ -1,7 +1,7 @@
 """Persistent 256^2 GEMM epilogue: LDS-staged rows (two halves, four barriers) against DIRECT stores from the accumulator registers
 (v_permlane16_swap -> 16-byte buffer stores, one barrier; cpx_gemm_set_direct, debug build).  The four layer shapes in their in-engine
 configuration, one process, interleaved in alternating order, outputs compared bit for bit.
-    python tools/ab_gemm_direct.py [switch-name]        (default: direct)"""
+    python tools/ab_gemm_direct.py [switch-name [other_switch=value ...]]        (default: direct)"""
 import os as _os
 _os.environ.setdefault("CLASSPOSE_HIP_DEBUG", "1")
 import sys, os
@@ -33,6 +33,8 @@ OPS = {
 }
 t = {k: {0: [], 1: []} for k in OPS}
 SW = getattr(L, 'cpx_gemm_set_' + (sys.argv[1] if len(sys.argv) > 1 else 'direct'))
+for kv in sys.argv[2:]:                      # other switches held fixed, e.g. `balanced direct=0`
+    getattr(L, 'cpx_gemm_set_' + kv.split('=')[0])(int(kv.split('=')[1]))
 for r in range(8):
     for k, f in OPS.items():
         for v in ((0, 1) if r % 2 == 0 else (1, 0)):
