@@ -18,7 +18,7 @@ KERNELS = [
     ("void k_gemm256p<1, false, 33>", "mlp.lin1 (fc1, GELU + folded LayerNorm, direct-store epilogue)", gemm_flops(HID, C), gemm_bytes(HID, C)),
     ("void k_gemm256p<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), persistent with the balanced tile list", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
     ("void k_gemm256<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), one workgroup per tile", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
-    ("void k_gemm256p<2, false, 2>", "attn.proj and mlp.lin2 (residual + row statistics), average of both",
+    ("void k_gemm256p<2, false, 66>", "attn.proj and mlp.lin2 (residual + row statistics, balanced fragment-read schedule), average of both",
      (gemm_flops(C, C) + gemm_flops(C, HID)) / 2, (gemm_bytes(C, C, 2 * M * C) + gemm_bytes(C, HID, 2 * M * C)) / 2),
     ("void k_attention4p<false", "rel-pos flash attention (4-wave, LDS-DMA ring; production variant 2)",
      4.0 * 32 * 16 * 1024 * 1024 * 64 + 4.0 * 32 * 16 * 1024 * 32 * 64, 2.0 * 4 * M * C),      # algorithmic: 4 T^2 hd heads + 4 heads T sqrt(T) hd
