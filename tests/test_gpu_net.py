@@ -150,6 +150,44 @@ def test_gemm256_epilogues(cuda, M, N, K):
     assert torch.equal(outs[1][0], outs[0][0]) or _rel(outs[1][0].float(), outs[0][0].float()) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 256), (8192, 2048, 1024), (16384, 1024, 512)])
+def test_gemm256_epilogue_and_schedule_variants_are_bitwise_equal(cuda, M, N, K):
+    """The persistent 256^2 kernel's production choices against the forms they replaced (debug-build switches): the direct-store
+    epilogue (v_permlane16_swap -> 16-byte buffer stores) against the LDS-staged rows, and the balanced fragment-read schedule
+    against the plain 8-phase one -- every epilogue, K = 256 (four K tiles: only the peeled head and tail tiles run), 512 and
+    1024, one and two tiles per workgroup.  Same accumulation order by construction -> bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(cuda)
+    stats = ops.row_stats(A) if K == 1024 else None               # (the folded LayerNorm is defined for the 1024-channel rows)
+    colsum = W.float().sum(1).contiguous() if K == 1024 else None
+
+    def run():
+        o = [ops.gemm(A, W, "bf16", bias), ops.gemm(A, W, "gelu", bias), ops.gemm(A, W, "relu", None)]
+        o += list(ops.gemm_ln(A, W, "resid", bias, res, want_stats=True)) if N == 1024 else [ops.gemm(A, W, "resid", bias, res)]
+        if stats is not None:
+            o.append(ops.gemm_ln(A, W, "gelu", bias, None, ln_stats=stats, ln_colsum=colsum))
+        return o
+
+    prod = run()
+    with _lib.use_debug_library() as L:
+        outs = {}
+        try:
+            for direct, bal in ((1, 1), (0, 0), (2, 2), (0, 2), (2, 0)):
+                L.cpx_gemm_set_direct(direct); L.cpx_gemm_set_balanced(bal)
+                outs[direct, bal] = run()
+        finally:
+            L.cpx_gemm_set_direct(1); L.cpx_gemm_set_balanced(1)
+    for key, o in outs.items():
+        assert len(o) == len(prod)
+        for k, (a, b) in enumerate(zip(prod, o)):
+            assert torch.equal(a, b), (key, k)
+    ref = torch.nn.functional.gelu(A.float() @ W.float().T + bias)
+    assert _rel(prod[1].float(), ref) < 5e-3
+
+
 def test_gemm256_identity_asymmetric(cuda):
     """exact layout check of the big kernel: A = [I | 0] rows against an asymmetric W"""
     M, N, K = 16384, 1024, 128
