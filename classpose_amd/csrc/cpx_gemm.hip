@@ -135,10 +135,15 @@ __device__ __forceinline__ unsigned short to_half(float f) {
 // Same rounding as to_half (round to nearest even; the instruction the compiler itself picks for the scalar cast).
 template <bool F16>
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    unsigned r;
-    if constexpr (F16) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    // a vector convert, NOT inline asm: one v_cvt_pk_* either way, but the hazard recogniser must see this VALU write -- v_permlane16_swap
+    // needs two wait states behind a VALU write of either operand (the direct-store epilogue), and behind an inline-asm conversion the
+    // compiler inserted none: one launch in ~1 500 of the light bf16 epilogue stored a stale half-row (round 4, tools/stress_gemm_variants.py)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f32x2_t v = {a, b};
+    if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 template <bool F16>
 __device__ __forceinline__ float from_half(unsigned short u) {

@@ -829,15 +829,17 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     }
 
     A4_STAMP(4);
-    auto tile = [&](const int kh, auto slot_tag, auto next_tag) {
-        constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value;
+    // TAIL (compile time): 0 = any key tile up to 28 (every end-of-sequence condition below holds), 1 / 2 / 3 = tiles 29 / 30 / 31 -- the last four
+    // tiles are peeled so that the steady-state body carries no scalar branch for them (round 4)
+    auto tile = [&](const int kh, auto slot_tag, auto next_tag, auto tail_tag) {
+        constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value, TAIL = decltype(tail_tag)::value;
         // tile kh + 1 (this thread's part) has landed; after the barrier every part has, and every wave is done with
         // slot (kh - 1) & 3, which the next request overwrites
-        if (kh < 30) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (TAIL < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         A4_STAMP(0);
-        if (kh + 3 < 32) issue(kh + 3);
+        if constexpr (TAIL == 0) issue(kh + 3);
         unsigned gh_bits;
         asm volatile("ds_read_u16 %0, %1" : "=v"(gh_bits) : "v"(gaddr - 2u * (unsigned)kh));
         f32x16 Sn = S;
@@ -851,8 +853,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");             // gh only
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            if (kh + 1 < 32) Sn = qk(integral_constant<int, SN>{});          // waits lgkmcnt(0): gh is there too
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (TAIL < 3) Sn = qk(integral_constant<int, SN>{});          // waits lgkmcnt(0): gh is there too
+            else {
+                // (gh_bits is an inline-asm LDS read: the wait must carry it as an operand, or the compiler is free to schedule its consumer in
+                // front of the wait -- it did, in the peeled last tile, and every output was wrong by a few per cent)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gh_bits)::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         A4_STAMP(1);
         const float gh = (float)__builtin_bit_cast(_Float16, (unsigned short)gh_bits);
@@ -897,10 +904,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             __builtin_amdgcn_sched_barrier(0);
             O0 = mfma32<F16>(ev00, pf0, O0);
             O1 = mfma32<F16>(ev10, pf0, O1);
-            if (kh + 1 < 32) Sn = mfma32<F16>(ek0, qf[0], GW);
+            if constexpr (TAIL < 3) Sn = mfma32<F16>(ek0, qf[0], GW);
             O0 = mfma32<F16>(ev01, pf1, O0);
             O1 = mfma32<F16>(ev11, pf1, O1);
-            if (kh + 1 < 32) {
+            if constexpr (TAIL < 3) {
                 Sn = mfma32<F16>(ek1, qf[1], Sn);
                 Sn = mfma32<F16>(ek2, qf[2], Sn);
                 Sn = mfma32<F16>(ek3, qf[3], Sn);
@@ -920,12 +927,17 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         A4_STAMP(3);
         S = Sn;
     };
-    for (int kh0 = 0; kh0 < 32; kh0 += 4) {
-        tile(kh0 + 0, integral_constant<int, 0>{}, integral_constant<int, 1>{});
-        tile(kh0 + 1, integral_constant<int, 1>{}, integral_constant<int, 2>{});
-        tile(kh0 + 2, integral_constant<int, 2>{}, integral_constant<int, 3>{});
-        tile(kh0 + 3, integral_constant<int, 3>{}, integral_constant<int, 0>{});
+    using T0 = integral_constant<int, 0>;
+    for (int kh0 = 0; kh0 < 28; kh0 += 4) {
+        tile(kh0 + 0, integral_constant<int, 0>{}, integral_constant<int, 1>{}, T0{});
+        tile(kh0 + 1, integral_constant<int, 1>{}, integral_constant<int, 2>{}, T0{});
+        tile(kh0 + 2, integral_constant<int, 2>{}, integral_constant<int, 3>{}, T0{});
+        tile(kh0 + 3, integral_constant<int, 3>{}, integral_constant<int, 0>{}, T0{});
     }
+    tile(28, integral_constant<int, 0>{}, integral_constant<int, 1>{}, T0{});
+    tile(29, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    tile(30, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+    tile(31, integral_constant<int, 3>{}, integral_constant<int, 0>{}, integral_constant<int, 3>{});
     float l_tot;
     if constexpr (LSUM) l_tot = Lacc[0];
     else l_tot = l_run + __shfl_xor(l_run, 32);
