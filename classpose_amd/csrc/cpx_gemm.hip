@@ -1641,7 +1641,7 @@ CPX_SWITCH(g_gemm_persist_qkv, 1);  // balanced persistent tile list for the qkv
 // 26.55 ms per engine step in a one-process A/B (tools/ab_switch.py) -> no gain, not enabled.
 CPX_SWITCH(g_gemm_rev, 0);
 CPX_SWITCH(g_gemm_big, 1);          // 1 = use the 256^2 kernel when the shape allows
-CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of the persistent main loop (G2F_BAL; K >= 256) for the residual epilogues, 2 (debug build) = everywhere, 0 = plain
+CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of the persistent main loop (G2F_BAL; K >= 256) for the bf16 residual + statistics epilogue, 0 = plain
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
@@ -1801,24 +1801,15 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                                        || EPI != CPX_EPI_RESID_BF16
 #endif
                 ;
-            // balanced fragment-read schedule (G2F_BAL): production for the residual epilogues (proj 0.986, mlp.lin2 0.983 of the plain
-            // schedule in two one-process A/Bs, bitwise equal); qkv / mlp.lin1 measured 0.995-1.007 and keep the plain one
-            // (cpx_gemm_set_balanced(2) in the debug build forces it everywhere)
-            constexpr bool BAL_OK = EPI == CPX_EPI_RESID_BF16
-#ifdef CPX_DEBUG
-                                    || true
-#endif
-                ;
-            const bool bal = BAL_OK && (EPI == CPX_EPI_RESID_BF16 ? g_gemm_bal != 0 : g_gemm_bal == 2) && a.K >= 256;
+            // balanced fragment-read schedule (G2F_BAL): ONLY the bf16 residual epilogue with row statistics (proj / mlp.lin2 of the engine: 0.98 of the
+            // plain schedule, bitwise equal, 255 VGPRs and no scratch).  Everything else keeps the plain schedule: the fp16 and the statistics-less
+            // instantiations spill an accumulator under it, qkv gains nothing, mlp.lin1 loses what its direct-store epilogue gained, and the
+            // LayerNorm + direct-store + balanced combination -- built once as a debug variant, 255 VGPRs + scratch -- returned NaNs in four token rows
+            // of every tile (not understood; the combination no longer exists in either build)
+            constexpr bool BAL_OK = EPI == CPX_EPI_RESID_BF16 && !F16;
+            const bool bal = BAL_OK && g_gemm_bal != 0 && f1 && a.K >= 256;
             if constexpr (DIRECT_OK) {
                 if ((EPI == CPX_EPI_GELU_BF16 ? g_gemm_direct != 0 : g_gemm_direct == 2) && (size_t)a.M * (size_t)a.ld_out * 2 < ((size_t)1 << 31)) {
-#ifdef CPX_DEBUG
-                    if (bal) {
-                        if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DIRECT | G2F_BAL>(a, s);
-                        else launch_gemm256_flags<EPI, F16, G2F_DIRECT | G2F_BAL>(a, s);
-                        return true;
-                    }
-#endif
                     if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_DIRECT>(a, s);
                     else launch_gemm256_flags<EPI, F16, G2F_DIRECT>(a, s);
                     return true;
@@ -1826,8 +1817,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
             }
             if constexpr (BAL_OK) {
                 if (bal) {
-                    if (f1) launch_gemm256_flags<EPI, F16, F1 | G2F_BAL>(a, s);
-                    else launch_gemm256_flags<EPI, F16, G2F_BAL>(a, s);
+                    launch_gemm256_flags<EPI, F16, F1 | G2F_BAL>(a, s);
                     return true;
                 }
             }

@@ -32,13 +32,14 @@ OPS = {
     "mlp.lin2": lambda o: ck(L.cpx_gemm_ln(hid.data_ptr(), W2.data_ptr(), M, 1024, 4096, E["resid"], b2.data_ptr(), x.data_ptr(), o["fc2"].data_ptr(), 1024, None, None, o["fst"].data_ptr(), st)),
 }
 t = {k: {0: [], 1: []} for k in OPS}
-SW = getattr(L, 'cpx_gemm_set_' + (sys.argv[1] if len(sys.argv) > 1 else 'direct'))
+SW_NAME = sys.argv[1] if len(sys.argv) > 1 else 'direct'
+SW = getattr(L, 'cpx_gemm_set_' + SW_NAME)
 for kv in sys.argv[2:]:                      # other switches held fixed, e.g. `balanced direct=0`
     getattr(L, 'cpx_gemm_set_' + kv.split('=')[0])(int(kv.split('=')[1]))
 for r in range(8):
     for k, f in OPS.items():
         for v in ((0, 1) if r % 2 == 0 else (1, 0)):
-            SW(2 * v)     # 2 = every non-residual epilogue (1, the production setting, is the GELU epilogue only)
+            SW(2 * v if SW_NAME == 'direct' else v)     # direct: 2 = every non-residual epilogue (1, the production setting, is the GELU epilogue only)
             for _ in range(3): f(O[v])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
