@@ -620,7 +620,9 @@ def test_predict_wsi_eight_ranks_share_one_gpu_gloo(cuda, tmp_path, monkeypatch)
         fs = json.load(open(next(o.glob("*_cell_contours.geojson"))))["features"]
         feats.append([(f["geometry"]["coordinates"], f["properties"]["classification"], f["properties"]["measurements"]) for f in fs])
     assert len(feats[0]) > 100
-    assert feats[0] == feats[1]                              # same cells, same order, same polygons
+    first = next((i for i, (a, b) in enumerate(zip(feats[0], feats[1])) if a != b), None)
+    assert len(feats[0]) == len(feats[1]) and first is None, (                     # same cells, same order, same polygons
+        len(feats[0]), len(feats[1]), first, None if first is None else (feats[0][first][1:], feats[1][first][1:]))
     cent = [json.load(open(next(o.glob("*_cell_centroids.geojson"))))["features"] for o in (o1, o8)]
     assert [f["geometry"] for f in cent[0]] == [f["geometry"] for f in cent[1]]
     # byte identity of the files apart from the uuid4 feature ids (the reference draws them at random too)
