@@ -188,21 +188,25 @@ def test_gemm256_epilogue_and_schedule_variants_are_bitwise_equal(cuda, M, N, K)
     assert _rel(prod[1].float(), ref) < 5e-3
 
 
-def test_gemm_operand_of_two_gib_takes_the_flat_addressed_kernel(cuda):
-    """The persistent 256^2 kernel addresses its operands through 32-bit buffer offsets; an operand of >= 2^31 bytes must fall back to
-    the one-workgroup-per-tile kernel (64-bit flat addresses).  A = [2^20, 1024] bf16 is exactly 2 GiB: rows at both ends and across
-    the 2^31-byte boundary of what a 32-bit offset could reach are compared with torch."""
-    M, N, K = 1 << 20, 256, 1024
+@pytest.mark.parametrize("N,K,epi", [(256, 1024, "bf16"), (1024, 256, "gelu")])
+def test_gemm_two_gib_operand_or_output_takes_64_bit_addresses(cuda, N, K, epi):
+    """The persistent 256^2 kernel addresses its operands -- and the direct-store epilogue its output -- through 32-bit buffer offsets.
+    An OPERAND of >= 2^31 bytes (A = [2^20, 1024] bf16 is exactly 2 GiB) must fall back to the one-workgroup-per-tile kernel, an OUTPUT of
+    >= 2^31 bytes ([2^20, 1024] from K = 256) to the staged epilogue with its 64-bit store addresses: rows at both ends and across the
+    2^31-byte boundary are compared with torch."""
+    M = 1 << 20
     g = torch.Generator(device=cuda).manual_seed(3)
     A = torch.randn(M, K, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=cuda) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, generator=g, device=cuda)
-    assert A.numel() * 2 == 1 << 31
-    out = ops.gemm(A, W, "bf16", bias)
+    assert max(A.numel(), M * N) * 2 == 1 << 31
+    out = ops.gemm(A, W, epi, bias)
     rows = torch.cat([torch.arange(0, 512), torch.arange(M // 2 - 256, M // 2 + 256), torch.arange(M - 512, M)]).to(cuda)
     ref = A[rows].float() @ W.float().T + bias
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
     assert _rel(out[rows].float(), ref) < 5e-3
-    assert torch.isfinite(out.float()).all()
+    assert bool(torch.isfinite(out[::4097].float()).all())
 
 
 def test_gemm256_identity_asymmetric(cuda):
