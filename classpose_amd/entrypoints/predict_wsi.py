@@ -87,8 +87,9 @@ class TileStream:
                  gate_at: int | None = None):
         self.slide, self.plan, self.idxs, self.nT = slide, plan, list(idxs), nT
         self.dev, self.extra = device, extra
-        # optional gate: batches >= gate_at are not read (nor copied) before release() -- bench.py times a region that
-        # starts with a warm reader thread but with none of its tiles read ahead
+        # optional gate: batches >= gate_at are not COPIED to the device (nor handed over) before release() -- bench.py times a
+        # region that starts with the reader in its steady state: up to `ahead` batches decoded into pinned host memory, none
+        # of them resident on the device
         self.gate_at, self.gate = gate_at, threading.Event()
         self._stop = threading.Event()
         n_workers = max(2, min(32, (os.cpu_count() or 4) // 2))
@@ -147,19 +148,19 @@ class TileStream:
             nxt = 0
             while (nxt < n_batches or pending) and not self._stop.is_set():
                 while nxt < n_batches and len(pending) < self.ahead:
-                    if self.gate_at is not None and nxt >= self.gate_at and not self.gate.is_set():
-                        if pending:
-                            break                        # hand over what was read before the gate first
-                        while not self.gate.wait(0.5):
-                            pass
-                        if self._stop.is_set():
-                            break
-                    pending.append(self._submit(nxt))
+                    pending.append((nxt,) + self._submit(nxt))       # decode into pinned host memory, up to `ahead` batches ahead
                     nxt += 1
                 if self._stop.is_set() or not pending:
                     break
-                chunk, slot, futs = pending.pop(0)
+                b, chunk, slot, futs = pending.pop(0)
                 extras = [f.result() for f in futs]
+                if self.gate_at is not None and b >= self.gate_at and not self.gate.is_set():
+                    # the gate holds back the H2D copy and the hand-over of a gated batch, not its decoding: when it opens the reader
+                    # is where it is in the steady state -- `ahead` batches decoded in pinned memory, none of them on the device yet
+                    while not self.gate.wait(0.5):
+                        pass
+                    if self._stop.is_set():
+                        break
                 with torch.cuda.stream(self.copy_stream):
                     dev = self.pinned[slot][: len(chunk)].to(self.dev, non_blocking=True)
                     ev = torch.cuda.Event()
