@@ -149,6 +149,7 @@ _PRIVATE = {
     "cpx_postproc_set_fused": (None, [_i]),
     "cpx_gemm_set_split": (None, [_i]),
     "cpx_gemm_set_direct": (None, [_i]),
+    "cpx_gemm4w": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "cpx_gemm_set_balanced": (None, [_i]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),

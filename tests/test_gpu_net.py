@@ -209,6 +209,25 @@ def test_gemm_two_gib_operand_or_output_takes_64_bit_addresses(cuda, N, K, epi):
     assert bool(torch.isfinite(out[::4097].float()).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 2048, 1024)])
+def test_gemm_one_wave_per_simd_prototype_equals_the_production_kernel(cuda, M, N, K):
+    """csrc/cpx_gemm4w.hip (debug build): the 256^2 tile with one wave per SIMD (128 x 128 per wave, AGPR accumulators through inline-asm
+    MFMAs, one barrier per K tile).  Same accumulation order per output element as k_gemm256p -> bit for bit, K = 256 (only the peeled
+    head and tail K tiles run) and 1024."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    ref = ops.gemm(A, W, "bf16", bias)
+    out = torch.empty_like(ref)
+    with _lib.use_debug_library() as L:
+        for _ in range(3):
+            _lib.check(L.cpx_gemm4w(A.data_ptr(), W.data_ptr(), M, N, K, bias.data_ptr(), out.data_ptr(), N,
+                                    torch.cuda.current_stream().cuda_stream), "gemm4w")
+            assert torch.equal(out, ref)
+    assert _rel(out.float(), A.float() @ W.float().T + bias) < 5e-3
+
+
 def test_gemm256_identity_asymmetric(cuda):
     """exact layout check of the big kernel: A = [I | 0] rows against an asymmetric W"""
     M, N, K = 16384, 1024, 128
