@@ -453,11 +453,16 @@ class Engine:
             if sl.cells is None:
                 sl.cells = torch.empty(self.nT * self.max_rec * C.sizeof(_lib.CpxCell), dtype=torch.uint8, device=self.dev)
                 sl.xy_pool = torch.empty((self.max_pts, 2), dtype=torch.float64, device=self.dev)
-                sl.n_pts_total = torch.zeros(1, dtype=torch.int32, device=self.dev)
+                # (torch.empty, not zeros: a fill kernel would run on the CALLER's stream, unordered against the post stream that writes
+                # these buffers -- under GPU contention it landed after the H2D copy of the origins / after the vertex scan and
+                # zeroed them: the first batch's cells at the slide origin, the 8-ranks-on-one-GPU test failing in 9 of 40 runs.
+                # k_poly_scan writes n_pts_total, the copy below writes every row of origins)
+                sl.n_pts_total = torch.empty(1, dtype=torch.int32, device=self.dev)
                 sl.poly_ws = torch.empty(self.L.cpx_polygonize_workspace_bytes(self.nT, self.H, self.W, self.max_rec),
                                          dtype=torch.uint8, device=self.dev)
                 sl.origins_host = torch.zeros((self.nT, 2), dtype=torch.float64).pin_memory()
-                sl.origins = torch.zeros((self.nT, 2), dtype=torch.float64, device=self.dev)
+                sl.origins = torch.empty((self.nT, 2), dtype=torch.float64, device=self.dev)
+                self.s_post.wait_stream(cur)             # the allocator may have handed out blocks with work pending on the caller's stream
             sl.origins_host[:n] = torch.as_tensor(np.asarray(origins, dtype=np.float64).reshape(n, 2))
             with torch.cuda.stream(self.s_post):
                 sl.origins.copy_(sl.origins_host, non_blocking=True)
