@@ -21,7 +21,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 DTYPE_CODE = {"bf16": DT_BF16, "fp16": DT_F16, "fp32": DT_F32}
 PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2")
 # the kernel behind kind "fc1" (the dominant launch of the network; its name as rocprofv3 prints it)
-FC1_KERNEL_NAME = "k_gemm256p<GELU, folded LayerNorm, direct-store epilogue> = void k_gemm256p<1, false, 33>(GemmArgs)"
+FC1_KERNEL_NAME = "k_gemm4w<GELU + folded LayerNorm, one wave per SIMD> = void k_gemm4w<1, 0>(Gemm4wArgs)"
 
 
 class CpxTiling(C.Structure):
@@ -150,6 +150,8 @@ _PRIVATE = {
     "cpx_gemm_set_split": (None, [_i]),
     "cpx_gemm_set_direct": (None, [_i]),
     "cpx_gemm4w": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "cpx_gemm4w_set_variant": (None, [_i]),
+    "cpx_gemm_set_4w": (None, [_i]),
     "cpx_gemm_set_balanced": (None, [_i]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),

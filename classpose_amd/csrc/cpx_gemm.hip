@@ -1645,6 +1645,7 @@ CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of th
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
+CPX_SWITCH(g_gemm_4w, 1);           // 1 = mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel (cpx_gemm4w.hip), 0 = on k_gemm256p; same bits
 CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
 CPX_SWITCH(g_gemm_pp_persist, 1);   // ping-pong kernel: 1 = two persistent workgroups per CU walk the tiles, 0 = one workgroup per tile
 CPX_SWITCH(g_gemm_pp_delay, 2);     // ping-pong kernel: start offset of a CU's second workgroup, x s_sleep 127 (~8k cycles)
@@ -1661,6 +1662,7 @@ extern "C" void cpx_gemm_set_split(int on) { g_gemm_split = on; }
 extern "C" void cpx_gemm_set_direct(int on) { g_gemm_direct = on; }
 extern "C" void cpx_gemm_set_balanced(int on) { g_gemm_bal = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
+extern "C" void cpx_gemm_set_4w(int on) { g_gemm_4w = on; }
 extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
 
@@ -1794,6 +1796,13 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                 }
             }
 #endif
+            // mlp.lin1 of the bf16 network (folded LayerNorm + bias + erf-GELU) on the one-wave-per-SIMD kernel: bitwise equal to the
+            // k_gemm256p instantiation below, its main loop and its epilogue both faster (profiles/r05_ab_gemm4w_*.txt)
+            if constexpr (EPI == CPX_EPI_GELU_BF16 && !F16) {
+                if (g_gemm_4w && f1 && a.bias && a.K >= 256 && (a.K / 64) % 2 == 0 &&
+                    cpx_gemm4w_gelu_ln(a.A, a.W, a.M, a.N, a.K, a.bias, a.ln_stats, a.ln_colsum, a.out, a.ld_out, s))
+                    return true;
+            }
             // direct-store epilogue (G2F_DIRECT): production for the GELU epilogue (mlp.lin1 -3.5 %, bitwise equal); the lighter epilogues
             // measured equal or slower with it (qkv +1.2 %) and keep the staged rows -- cpx_gemm_set_direct(2) in the debug build forces it
             constexpr bool DIRECT_OK = EPI == CPX_EPI_GELU_BF16

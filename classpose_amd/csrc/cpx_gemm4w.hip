@@ -1,20 +1,33 @@
-// PROTOTYPE (debug build only, round 4): the 256 x 256 x 64 GEMM tile with ONE wave per SIMD.
+// The 256 x 256 x 64 GEMM tile with ONE wave per SIMD (round 5: persistent, three fragment sets, requests two K tiles ahead).
 //
-// The production kernel (cpx_gemm.hip: k_gemm256p) runs a 256^2 tile with 8 waves -- two per SIMD, 128 x 64 outputs each, handing the matrix
-// pipe to each other in half-phases between barriers.  The vendor's hand-written kernel for the same macro-tile uses 4 waves, one per SIMD,
-// 128 x 128 outputs each with the accumulators in the 256 AGPRs: half the fragment bytes per MFMA (32 ds_read_b128 per 128 MFMAs instead of
-// 24-28 per 64) and no hand-over inside a SIMD.  This file measures what that structure reaches when it is written in HIP:
-//   * 256 threads, wave (wm, wn) = (wave >> 1, wave & 1) owns token rows wm * 128 .. + 127 and channels wn * 128 .. + 127: 8 x 8 accumulators
-//     of 16 x 16 (f32x4 each, 256 registers), operand fragments of one k-substep (32 k) = 8 + 8 ds_read_b128, two fragment sets;
-//   * the same LDS image as k_gemm256p: per K tile four 16 KB items (X rows 0-127, X rows 128-255, W rows 0-127, W rows 128-255) of 128-byte
-//     rows, 16-byte chunk c of row r at position c ^ (r & 7), two K-tile buffers, landed by LDS-DMA (buffer loads, scalar offsets): 16 requests
-//     per wave and K tile;
-//   * ONE barrier per K tile, in its middle: [reads of k-substep 1 -> set B; 64 MFMAs on set A] wait(B landed, K tile t + 1 landed) barrier
-//     [requests of K tile t + 2 into the buffer just consumed; reads of (t + 1, k-substep 0) -> set A; 64 MFMAs on set B];
-//   * bias epilogue only (bf16 out), stored straight from the registers (v_permlane16_swap -> 16-byte buffer stores).
-// Same accumulation order per output element as k_gemm256p (k-substep 0 then 1 of every K tile) -> bitwise equal results.
-// One workgroup per tile (no persistent loop): the measurement is about the main loop, on the K = 4096 shape most of all.
-#ifdef CPX_DEBUG
+// The 8-wave kernel (cpx_gemm.hip: k_gemm256p) runs two waves per SIMD, 128 x 64 outputs each, handing the matrix pipe to each other in
+// half-phases between barriers.  Here a workgroup is 256 threads: wave (wm, wn) = (wave >> 1, wave & 1) owns token rows wm * 128 .. + 127 and
+// channels wn * 128 .. + 127 -- 8 x 8 accumulators of 16 x 16 (f32x4 each) in the 256 AGPRs, half the fragment bytes per MFMA (32 ds_read_b128
+// per 128 MFMAs instead of 24-28 per 64) and no hand-over inside a SIMD.
+//
+// LDS image = k_gemm256p's: per K tile four 16 KB items (X rows 0-127, X rows 128-255, W rows 0-127, W rows 128-255) of 128-byte rows, 16-byte
+// chunk c of row r at position c ^ (r & 7), two K-tile buffers, landed by LDS-DMA (buffer loads with scalar offsets, 16 requests per wave and
+// K tile).  What the round-4 prototype of this file lacked was prefetch distance: it read the k-substep-1 fragments of K tile t during the
+// first half of t, so buffer t & 1 was free only at mid(t), its refill was requested during the second half of t and had to have landed by
+// mid(t + 1): 0.5 - 1 K tile (~0.5 - 1 us), less than a loaded HBM / Infinity Cache round trip.  Here:
+//   * THREE fragment sets (192 VGPRs beside the 256 AGPRs): P always holds k-substep 0, the k-substep-1 set alternates between Q (even K
+//     tiles) and R (odd) -- period 2, like the buffers.  BOTH sets of K tile t + 1 are read during the second half of K tile t (32 reads
+//     beside 64 MFMAs), so buffer (t + 1) & 1 is free at end(t);
+//   * the requests of K tile t + 2 go into buffer t & 1 during K tile t itself: the 8 X requests in its first half, the 8 W requests in its
+//     second, one behind every eighth MFMA (all 16 in the first half -- one per fourth MFMA, the texture path saturated for half of the time and
+//     idle for the other -- measured 1 - 4 % slower: profiles/r05_ablate_gemm4w.txt), waited for at mid(t + 1) behind a counted vmcnt(8) (the 8
+//     youngest = the X requests of K tile t + 3): 1 - 3 k-substeps of cover, the long end for the activation rows, which are the operand that
+//     comes from HBM or the Infinity Cache;
+//   * two barriers per K tile: mid(t) [K tile t + 1 has landed for everybody -> reads], end(t) [everybody has read buffer (t + 1) & 1 ->
+//     the requests of K tile t + 1 may overwrite it];
+//   * persistent: the request stream simply runs on across output tiles (the last two K tiles of a tile request K tiles 0 / 1 of the NEXT
+//     tile, the last half reads the next tile's first fragments), the epilogue is a direct store from the registers and touches neither
+//     buffer, and the per-tile vectors (bias, LayerNorm row statistics, column sums) arrive by LDS-DMA in a 10 KB tail: no ordinary global
+//     load anywhere, so hipcc never drains the request queue.
+// Same accumulation order per output element as k_gemm256p (k-substep 0 then 1 of every K tile) and the same epilogue arithmetic -> bitwise
+// equal results.  Epilogues: bias only (the debug-build entry point cpx_gemm4w: A/B tools, bitwise tests) and, PRODUCTION, folded LayerNorm +
+// bias + erf-GELU (mlp.lin1 of the bf16 network).  One wave per SIMD is the one regime where v_pk_fma_f32 doubles the f32 rate
+// (tools/micro/pk_rate.hip), so the LayerNorm fold and the GELU polynomial are written on float2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "cpx_common.h"
@@ -29,14 +42,19 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 #define G4_THREADS 256
 #define G4_ITEM 16384
 #define G4_BUF 65536
-#define G4_LDS_BYTES (2 * G4_BUF + 1024)          // + the tile's 256 bias values
+#define G4_TAIL (2 * G4_BUF)                      // [0, 8192) raw LayerNorm row statistics, [8192, 9216) bias, [9216, 10240) column sums
+#define G4_TAIL_BIAS (G4_TAIL + 8192)
+#define G4_TAIL_CSUM (G4_TAIL + 9216)
+#define G4_LDS_BYTES (G4_TAIL + 10240)
 
 struct Gemm4wArgs {
     const unsigned short *A, *W;
-    const float *bias;
+    const float *bias, *ln_stats, *ln_colsum;     // ln_*: folded LayerNorm of the K = 1024 input rows (G4_EPI_GELU_LN), as in cpx_gemm.hip
     unsigned short *out;
     int M, N, K, ld_out, tiles_n, n_blocks;
 };
+#define G4_EPI_BIAS 0
+#define G4_EPI_GELU_LN 1
 
 template <int OFF>
 __device__ __forceinline__ u32x4 g4_read128(unsigned addr) {
@@ -44,37 +62,41 @@ __device__ __forceinline__ u32x4 g4_read128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-// 8 row blocks of 16 rows x 128 bytes of one 128-row item: one k-substep's fragments
-__device__ __forceinline__ void g4_read8(u32x4 (&f)[8], unsigned a) {
-    f[0] = g4_read128<0 * 2048>(a); f[1] = g4_read128<1 * 2048>(a); f[2] = g4_read128<2 * 2048>(a); f[3] = g4_read128<3 * 2048>(a);
-    f[4] = g4_read128<4 * 2048>(a); f[5] = g4_read128<5 * 2048>(a); f[6] = g4_read128<6 * 2048>(a); f[7] = g4_read128<7 * 2048>(a);
-}
-template <bool FIRST>
-__device__ __forceinline__ void g4_mma(f32x4 (&acc)[8][8], const u32x4 (&fx)[8], const u32x4 (&fw)[8]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[nb]), __builtin_bit_cast(bf16x8, fx[mb]),
-                                                                  FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][nb], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-}
-#define G4_WAIT_LGKM() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G4_SB() __builtin_amdgcn_sched_barrier(0)
+#define G4_LDSP(p) ((__attribute__((address_space(3))) void *)(p))
 
+// erf-GELU of cpx_gemm.hip (gelu_erf: max(x, 0) - |x| 2^P5(|x|)) on two values: the polynomial as v_pk_fma_f32, the rest per value
+__device__ __forceinline__ f32x2_t g4_gelu2(f32x2_t x) {
+    const f32x2_t ax = __builtin_elementwise_abs(x);
+    f32x2_t p = {-4.732933965e-04f, -4.732933965e-04f};
+    p = __builtin_elementwise_fma(p, ax, (f32x2_t){7.084452800e-03f, 7.084452800e-03f});
+    p = __builtin_elementwise_fma(p, ax, (f32x2_t){-5.182713611e-02f, -5.182713611e-02f});
+    p = __builtin_elementwise_fma(p, ax, (f32x2_t){-4.599926953e-01f, -4.599926953e-01f});
+    p = __builtin_elementwise_fma(p, ax, (f32x2_t){-1.150787739e+00f, -1.150787739e+00f});
+    p = __builtin_elementwise_fma(p, ax, (f32x2_t){-1.000037638e+00f, -1.000037638e+00f});
+    const float q0 = __builtin_amdgcn_exp2f(p[0]), q1 = __builtin_amdgcn_exp2f(p[1]);
+    return (f32x2_t){__fmaf_rn(-ax[0], q0, fmaxf(x[0], 0.0f)), __fmaf_rn(-ax[1], q1, fmaxf(x[1], 0.0f))};
+}
+
+// VAR (debug build; 0 in production).  Timing-only ablations, results are garbage: 1 = no LDS-DMA requests inside the loop, 2 = no fragment
+// reads, 4 = no barriers, 8 = no MFMAs, 16 = the requests as ORDINARY buffer loads into 16 staging registers (consumed by an empty asm in the
+// second half), 32 = ... and written to LDS by ds_write_b128 there, 64 = every workgroup walks K from its own starting K tile.
+// 128 (results valid): all 16 requests of a K tile in its first half (the first form of this kernel), vmcnt(16) at mid.
+template <int EPI, int VAR>
 __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_gemm4w(Gemm4wArgs g) {
+    constexpr bool LN = EPI == G4_EPI_GELU_LN;
+    constexpr bool SPLIT = !(VAR & 128);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
-    const int K = g.K, nk = K / 64;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8; each XCD sweeps 8 x 4 super-tiles of its contiguous tile range
-    int tile_m, tile_n;
-    {
-        const int nblk = g.n_blocks, tiles_m = nblk / g.tiles_n;
-        const int v = blockIdx.x, nxcd = 8, q = nblk / nxcd, r = nblk % nxcd, x = v % nxcd;
+    const int K = g.K, nk = K / 64, nblk = g.n_blocks, tiles_m = nblk / g.tiles_n;
+    // XCD-aware tile order: workgroup ids with equal id % 8 share an XCD and take a contiguous range of tiles, swept 8 x 4 super-tile by super-tile
+    auto coords = [&](int v, int &m0_, int &n0_) {
+        const int nxcd = 8, q = nblk / nxcd, r = nblk % nxcd, x = v % nxcd;
         const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / nxcd;
+        int tile_m, tile_n;
         if ((tiles_m & 7) == 0 && (g.tiles_n & 3) == 0) {
             const int grp = bid >> 5, w_ = bid & 31, cgn = g.tiles_n >> 2;
             const int rg = grp / cgn, cg = grp - rg * cgn;
@@ -82,28 +104,32 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
         } else {
             tile_m = bid / g.tiles_n; tile_n = bid - tile_m * g.tiles_n;
         }
-    }
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+        m0_ = tile_m * 256; n0_ = tile_n * 256;
+    };
     // ---- LDS-DMA: a request of the workgroup lands 32 rows x 128 bytes (256 lanes x 16 bytes); a 128-row item = 4 requests
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_stats, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_colsum, 0, 0x7FFFFFFF, 0x00020000);
     const int srow = tid >> 3, kc = (tid & 7) ^ (srow & 7);                     // row inside a 32-row group, swizzled source chunk
     const unsigned voff = ((unsigned)srow * (unsigned)K + (unsigned)kc * 8u) * 2u;
-    const unsigned sX = (unsigned)m0 * (unsigned)K * 2u, sW = (unsigned)n0 * (unsigned)K * 2u, k32b = (unsigned)K * 64u;   // 32 rows in bytes
+    const unsigned vlin = (unsigned)lane * 16u;                                  // linear 1 KB copies (the tail)
+    const unsigned k32b = (unsigned)K * 64u;                                     // 32 rows in bytes
     char *sdst = smem + wave * 1024;
-    auto stage = [&](int t) {                                                    // all four items of K tile t -> buffer t & 1: 16 requests
-        char *d = sdst + (t & 1) * G4_BUF;
-        const unsigned kb = (unsigned)t * 128u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                                            // X rows 32 j .. 32 j + 31
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(d + j * 4096), 16, voff, sX + (unsigned)j * k32b + kb, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void *)(d + 2 * G4_ITEM + j * 4096), 16, voff, sW + (unsigned)j * k32b + kb, 0, 0);
-        }
-    };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    // the per-tile vectors as linear 1 KB LDS-DMA copies into the tail: wave w brings the raw row statistics of token rows 64 w .. 64 w + 63 (two
+    // requests of 32 rows x 32 bytes), wave 0 the bias, wave 1 the column sums.  Issued at the tile top, i.e. OLDER than the K-tile requests
+    // the counted waits of the main loop leave in flight
+#define G4_TAIL_REQUESTS(M0_, N0_)                                                                                                            \
+    {                                                                                                                                         \
+        if (LN) {                                                                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, G4_LDSP(smem + G4_TAIL + (2 * wave) * 1024), 16, vlin, (unsigned)(M0_) * 32u + (unsigned)(2 * wave) * 1024u, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, G4_LDSP(smem + G4_TAIL + (2 * wave + 1) * 1024), 16, vlin, (unsigned)(M0_) * 32u + (unsigned)(2 * wave + 1) * 1024u, 0, 0); \
+            if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcC, G4_LDSP(smem + G4_TAIL_CSUM), 16, vlin, (unsigned)(N0_) * 4u, 0, 0); \
+        }                                                                                                                                     \
+        if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, G4_LDSP(smem + G4_TAIL_BIAS), 16, vlin, (unsigned)(N0_) * 4u, 0, 0);   \
+    }
     unsigned xa[2][2], wa[2][2];                                                 // [buffer][k-substep]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -112,130 +138,272 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
         wa[0][ks] = lds0 + (unsigned)((2 + wn) * G4_ITEM + fr * 128) + sw;
         xa[1][ks] = xa[0][ks] + G4_BUF; wa[1][ks] = wa[0][ks] + G4_BUF;
     }
-    float bias_v = 0.f;
-    if (g.bias) bias_v = g.bias[n0 + tid];
-    stage(0);
-    if (nk > 1) stage(1);
-    *reinterpret_cast<float *>(smem + 2 * G4_BUF + tid * 4) = bias_v;
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
     f32x4 acc[8][8];
-    u32x4 fxA[8], fwA[8], fxB[8], fwB[8];
-    g4_read8(fxA, xa[0][0]); g4_read8(fwA, wa[0][0]);
-    G4_WAIT_LGKM();
-    // one row block of MFMAs (token rows mb * 16 .. + 15 of the wave, all eight channel blocks): 8 MFMAs = 128 cycles of the matrix pipe, during
-    // which the wave has ~100 spare issue cycles -- the fragment reads and the LDS-DMA requests are placed between the row blocks
-// (inline-asm MFMAs with the accumulator tied to itself in an AGPR quad: with the builtin, hipcc's allocator rotates the 256 loop-carried
-// accumulator registers between the unrolled K-tile bodies and pays for it with v_accvgpr_mov chains between the MFMAs)
+    u32x4 PX[8], PW[8], QX[8], QW[8], RX[8], RW[8];
+    [[maybe_unused]] u32x4 SG[16];                                               // (ablation 16 / 32 only)
+
+// ---- building blocks (macros: every index is a compile-time constant, nothing in a K-tile body branches)
+// inline-asm MFMAs with the accumulator tied to itself in an AGPR quad: with the builtin, hipcc's allocator rotates the 256 loop-carried
+// accumulator registers between the unrolled K-tile bodies and pays for it with v_accvgpr_mov chains between the MFMAs
 #define G4_MM(MB, NB, FX, FW, FIRST)                                                                             \
     {                                                                                                           \
-        if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); \
+        if (VAR & 8) { if (FIRST) asm volatile("; no mfma %0 %1 %2" : "=a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); else asm volatile("; no mfma %0 %1 %2" : "+a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); } \
+        else if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); \
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); \
     }
-#define G4_SB() __builtin_amdgcn_sched_barrier(0)
 // the fragment set a half multiplies with stays LIVE to the end of that half: otherwise the allocator hands the registers of a fragment whose
 // last MFMA has just been issued to the next inline-asm LDS read (legal in program order -- and the outputs were wrong by 2 % when it did)
 #define G4_KEEP(FX, FW)                                                                                         \
     { asm volatile("" ::"v"(FX[0]), "v"(FX[1]), "v"(FX[2]), "v"(FX[3]), "v"(FX[4]), "v"(FX[5]), "v"(FX[6]), "v"(FX[7]),                      \
                    "v"(FW[0]), "v"(FW[1]), "v"(FW[2]), "v"(FW[3]), "v"(FW[4]), "v"(FW[5]), "v"(FW[6]), "v"(FW[7])); }
-#define G4_DMAX(T2, I)                                                                                          \
-    { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(sdst + ((T2) & 1) * G4_BUF + (I) * 4096), 16, voff, sX + (unsigned)(I) * k32b + (unsigned)(T2) * 128u, 0, 0); G4_SB(); }
-#define G4_DMAW(T2, I)                                                                                          \
-    { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void *)(sdst + ((T2) & 1) * G4_BUF + 2 * G4_ITEM + (I) * 4096), 16, voff, sW + (unsigned)(I) * k32b + (unsigned)(T2) * 128u, 0, 0); G4_SB(); }
-// one row block (8 MFMAs) with ONE other instruction behind every second MFMA: a lone wave issues in order, so a fragment read or an LDS-DMA
-// request only hides in the ~12 cycles the matrix pipe still needs for the MFMA in front of it
-#define G4_HALF1(B, FIRST, I)                                                                                   \
+// request 32-row group I of the X / W operand: RQ = scalar byte offset of (tile origin row, K tile) in the operand, B = destination buffer
+#define G4_DMAX(B, I, RQ)                                                                                       \
+    {   if (VAR & 16) { SG[I] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff, (RQ) + (unsigned)(I) * k32b, 0); G4_SB(); }        \
+        else if (!(VAR & 1)) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, G4_LDSP(sdst + (B) * G4_BUF + (I) * 4096), 16, voff, (RQ) + (unsigned)(I) * k32b, 0, 0); G4_SB(); } }
+#define G4_DMAW(B, I, RQ)                                                                                       \
+    {   if (VAR & 16) { SG[8 + (I)] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, voff, (RQ) + (unsigned)(I) * k32b, 0); G4_SB(); }  \
+        else if (!(VAR & 1)) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, G4_LDSP(sdst + (B) * G4_BUF + 2 * G4_ITEM + (I) * 4096), 16, voff, (RQ) + (unsigned)(I) * k32b, 0, 0); G4_SB(); } }
+// first half, row block I: 8 MFMAs on set P, the X request of the row block behind the fourth
+#define G4_H1ROW(B, FIRST, I, RQX, RQW)                                                                         \
     {                                                                                                           \
-        G4_MM(I, 0, fxA, fwA, FIRST) G4_MM(I, 1, fxA, fwA, FIRST) fxB[I] = g4_read128<(I) * 2048>(xa[B][1]);    \
-        G4_MM(I, 2, fxA, fwA, FIRST) G4_MM(I, 3, fxA, fwA, FIRST) G4_MM(I, 4, fxA, fwA, FIRST) G4_MM(I, 5, fxA, fwA, FIRST) \
-        fwB[I] = g4_read128<(I) * 2048>(wa[B][1]);                                                              \
-        G4_MM(I, 6, fxA, fwA, FIRST) G4_MM(I, 7, fxA, fwA, FIRST) G4_SB();                                      \
+        G4_MM(I, 0, PX, PW, FIRST) G4_MM(I, 1, PX, PW, FIRST) G4_MM(I, 2, PX, PW, FIRST) G4_MM(I, 3, PX, PW, FIRST) G4_SB(); \
+        G4_DMAX(B, I, RQX)                                                                                      \
+        G4_MM(I, 4, PX, PW, FIRST) G4_MM(I, 5, PX, PW, FIRST) G4_MM(I, 6, PX, PW, FIRST) G4_MM(I, 7, PX, PW, FIRST) G4_SB(); \
+        if (!SPLIT) G4_DMAW(B, I, RQW)                                                                          \
     }
-// KIND (compile time, no branch inside a K-tile body): 0 = steady state (t + 2 < nk), 1 = K tile nk - 2 (nothing left to request), 2 = the last K tile
-#define G4_HALF2(T, B, I, KIND)                                                                                 \
+#define G4_WRS(J)                                                                                               \
+    { if (VAR & 32) { asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(lds0 + (unsigned)tid * 16u), "v"(SG[J]), "n"((J) * 4096) : "memory"); G4_SB(); } \
+      else if (VAR & 16) { asm volatile("" :: "v"(SG[J])); G4_SB(); } }
+// second half, row block I: 8 MFMAs on the k-substep-1 set, one fragment read of K tile t + 1 behind every second, the W request behind the last
+#define G4_H2ROW(I, BX, BW, R0, R1, R2, R3, B, RQW)                                                             \
     {                                                                                                           \
-        G4_MM(I, 0, fxB, fwB, false) G4_MM(I, 1, fxB, fwB, false) if ((KIND) < 2) fxA[I] = g4_read128<(I) * 2048>(xa[(B) ^ 1][0]); \
-        G4_MM(I, 2, fxB, fwB, false) G4_MM(I, 3, fxB, fwB, false) G4_SB(); if ((KIND) < 1) G4_DMAX((T) + 2, I)  \
-        G4_MM(I, 4, fxB, fwB, false) G4_MM(I, 5, fxB, fwB, false) if ((KIND) < 2) fwA[I] = g4_read128<(I) * 2048>(wa[(B) ^ 1][0]); \
-        G4_MM(I, 6, fxB, fwB, false) G4_MM(I, 7, fxB, fwB, false) G4_SB(); if ((KIND) < 1) G4_DMAW((T) + 2, I)  \
+        G4_MM(I, 0, BX, BW, false) G4_WRS(2 * (I)) G4_MM(I, 1, BX, BW, false) R0;                               \
+        G4_MM(I, 2, BX, BW, false) G4_MM(I, 3, BX, BW, false) R1;                                               \
+        G4_MM(I, 4, BX, BW, false) G4_WRS(2 * (I) + 1) G4_MM(I, 5, BX, BW, false) R2;                           \
+        G4_MM(I, 6, BX, BW, false) G4_MM(I, 7, BX, BW, false) R3; G4_SB();                                      \
+        if (SPLIT) G4_DMAW(B, I, RQW)                                                                           \
     }
-#define G4_KTILE(T, B, FIRST, KIND)                                                                            \
-    {                                                                                                          \
-        const int t_ = (T);                                                                                    \
-        G4_HALF1(B, FIRST, 0) G4_HALF1(B, FIRST, 1) G4_HALF1(B, FIRST, 2) G4_HALF1(B, FIRST, 3)                \
-        G4_HALF1(B, FIRST, 4) G4_HALF1(B, FIRST, 5) G4_HALF1(B, FIRST, 6) G4_HALF1(B, FIRST, 7)                \
-        G4_KEEP(fxA, fwA)                                                                                      \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      /* set B and K tile t + 1 have landed */ \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        G4_SB();                                                                                               \
-        G4_HALF2(t_, B, 0, KIND) G4_HALF2(t_, B, 1, KIND) G4_HALF2(t_, B, 2, KIND) G4_HALF2(t_, B, 3, KIND)    \
-        G4_HALF2(t_, B, 4, KIND) G4_HALF2(t_, B, 5, KIND) G4_HALF2(t_, B, 6, KIND) G4_HALF2(t_, B, 7, KIND)    \
-        G4_KEEP(fxB, fwB)                                                                                      \
-        G4_WAIT_LGKM();                                                                                        \
+#define G4_RW(F, KS, NB_, I) { if (!(VAR & 2)) F[I] = g4_read128<(I) * 2048>(wa[NB_][KS]); }
+#define G4_RX(F, KS, NB_, I) { if (!(VAR & 2)) F[I] = g4_read128<(I) * 2048>(xa[NB_][KS]); }
+// K tile in buffer B: (BX, BW) = its k-substep-1 set, (NX, NW) = the set that receives k-substep 1 of the following K tile (buffer B ^ 1)
+#define G4_KTILE(B, FIRST, BX, BW, NX, NW, RQX, RQW)                                                            \
+    {                                                                                                           \
+        G4_H1ROW(B, FIRST, 0, RQX, RQW) G4_H1ROW(B, FIRST, 1, RQX, RQW) G4_H1ROW(B, FIRST, 2, RQX, RQW) G4_H1ROW(B, FIRST, 3, RQX, RQW) \
+        G4_H1ROW(B, FIRST, 4, RQX, RQW) G4_H1ROW(B, FIRST, 5, RQX, RQW) G4_H1ROW(B, FIRST, 6, RQX, RQW) G4_H1ROW(B, FIRST, 7, RQX, RQW) \
+        G4_KEEP(PX, PW)                                                                                         \
+        if (SPLIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* the following K tile has landed (mine) */ \
+        if (!(VAR & 4)) __builtin_amdgcn_s_barrier();                /* ... and everybody's */                  \
+        G4_SB();                                                                                                \
+        G4_H2ROW(0, BX, BW, G4_RW(PW, 0, (B) ^ 1, 0), G4_RW(PW, 0, (B) ^ 1, 1), G4_RW(PW, 0, (B) ^ 1, 2), G4_RW(PW, 0, (B) ^ 1, 3), B, RQW) \
+        G4_H2ROW(1, BX, BW, G4_RW(PW, 0, (B) ^ 1, 4), G4_RW(PW, 0, (B) ^ 1, 5), G4_RW(PW, 0, (B) ^ 1, 6), G4_RW(PW, 0, (B) ^ 1, 7), B, RQW) \
+        G4_H2ROW(2, BX, BW, G4_RX(PX, 0, (B) ^ 1, 0), G4_RX(PX, 0, (B) ^ 1, 1), G4_RX(PX, 0, (B) ^ 1, 2), G4_RX(PX, 0, (B) ^ 1, 3), B, RQW) \
+        G4_H2ROW(3, BX, BW, G4_RX(PX, 0, (B) ^ 1, 4), G4_RX(PX, 0, (B) ^ 1, 5), G4_RX(PX, 0, (B) ^ 1, 6), G4_RX(PX, 0, (B) ^ 1, 7), B, RQW) \
+        G4_H2ROW(4, BX, BW, G4_RW(NW, 1, (B) ^ 1, 0), G4_RW(NW, 1, (B) ^ 1, 1), G4_RW(NW, 1, (B) ^ 1, 2), G4_RW(NW, 1, (B) ^ 1, 3), B, RQW) \
+        G4_H2ROW(5, BX, BW, G4_RW(NW, 1, (B) ^ 1, 4), G4_RW(NW, 1, (B) ^ 1, 5), G4_RW(NW, 1, (B) ^ 1, 6), G4_RW(NW, 1, (B) ^ 1, 7), B, RQW) \
+        G4_H2ROW(6, BX, BW, G4_RX(NX, 1, (B) ^ 1, 0), G4_RX(NX, 1, (B) ^ 1, 1), G4_RX(NX, 1, (B) ^ 1, 2), G4_RX(NX, 1, (B) ^ 1, 3), B, RQW) \
+        G4_H2ROW(7, BX, BW, G4_RX(NX, 1, (B) ^ 1, 4), G4_RX(NX, 1, (B) ^ 1, 5), G4_RX(NX, 1, (B) ^ 1, 6), G4_RX(NX, 1, (B) ^ 1, 7), B, RQW) \
+        G4_KEEP(BX, BW)                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           /* my reads of buffer B ^ 1 are done */    \
+        G4_SB();                                                                                                \
+        if (!(VAR & 4)) __builtin_amdgcn_s_barrier();                /* ... and everybody's: the next K tile may request into it */ \
+        G4_SB();                                                                                                \
     }
-    // (nk >= 4, even: the launcher checks)
-    G4_KTILE(0, 0, true, 0)
-    G4_KTILE(1, 1, false, 0)
-    for (int t = 2; t + 2 < nk; t += 2) {
-        G4_KTILE(t, 0, false, 0)
-        G4_KTILE(t + 1, 1, false, 0)
-    }
-    G4_KTILE(nk - 2, 0, false, 1)
-    G4_KTILE(nk - 1, 1, false, 2)
-#undef G4_HALF1
-#undef G4_HALF2
-#undef G4_MM
-#undef G4_DMAX
-#undef G4_DMAW
-#undef G4_SB
-#undef G4_KEEP
-#undef G4_KTILE
-    // the last inline-asm MFMAs' results: the compiler does not see the MFMA -> v_accvgpr_read hazard, and without the scheduling barriers it
-    // hoisted some of the epilogue's accumulator reads in front of the pad (one element of two channel blocks lost part of the last K tile)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // ... and every accumulator is re-defined BEHIND the pad (empty asm, "+a"): an accumulator's last MFMA is issued up to 63 MFMAs before the
-    // end of the loop, and the compiler is free to read it right there, one instruction behind an MFMA that takes 32 cycles
+
+    int v = blockIdx.x, m0, n0;
+    coords(v, m0, n0);
+    // ---- prologue of the workgroup's first tile: tail, K tiles 0 and 1, the first two fragment sets
+    G4_TAIL_REQUESTS(m0, n0)
+    {
+        const unsigned sX = (unsigned)m0 * (unsigned)K * 2u, sW = (unsigned)n0 * (unsigned)K * 2u;
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-        asm volatile("" : "+a"(acc[mb][0]), "+a"(acc[mb][1]), "+a"(acc[mb][2]), "+a"(acc[mb][3]), "+a"(acc[mb][4]), "+a"(acc[mb][5]), "+a"(acc[mb][6]), "+a"(acc[mb][7]));
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue: bias, one conversion per pair, lane rows swapped into 16-byte pieces, buffer stores (as the direct-store epilogue of k_gemm256p)
-    const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc((void *)g.out, 0, 0x7FFFFFFF, 0x00020000);
-    const unsigned ldb = (unsigned)g.ld_out * 2u;
-    const unsigned ovoff = (unsigned)(wm * 128 + fr) * ldb + (unsigned)(wn * 128 + ((fq & 1) << 4) + ((fq >> 1) << 3)) * 2u;
-    const unsigned so0 = (unsigned)m0 * ldb + (unsigned)n0 * 2u;
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int np = 0; np < 4; ++np) {                                             // channel block pairs (2 np, 2 np + 1): 32 channels
-        const float4 b0 = *reinterpret_cast<const float4 *>(smem + 2 * G4_BUF + (wn * 128 + (2 * np) * 16 + fq * 4) * 4);
-        const float4 b1 = *reinterpret_cast<const float4 *>(smem + 2 * G4_BUF + (wn * 128 + (2 * np + 1) * 16 + fq * 4) * 4);
+            for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, G4_LDSP(sdst + t * G4_BUF + j * 4096), 16, voff, sX + (unsigned)j * k32b + (unsigned)t * 128u, 0, 0);
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            const f32x4 v0 = acc[mb][2 * np], v1 = acc[mb][2 * np + 1];
-            const f32x2_t p00 = {v0[0] + b0.x, v0[1] + b0.y}, p01 = {v0[2] + b0.z, v0[3] + b0.w};
-            const f32x2_t p10 = {v1[0] + b1.x, v1[1] + b1.y}, p11 = {v1[2] + b1.z, v1[3] + b1.w};
-            const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p00, bf16x2_t)), a1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2_t));
-            const unsigned c0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p10, bf16x2_t)), c1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p11, bf16x2_t));
-            const auto r0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
-            const auto r1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
-            const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, 0);
+            for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, G4_LDSP(sdst + t * G4_BUF + 2 * G4_ITEM + j * 4096), 16, voff, sW + (unsigned)j * k32b + (unsigned)t * 128u, 0, 0);
         }
     }
+    G4_SB();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    G4_SB();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { PW[i] = g4_read128<0>(wa[0][0] + i * 2048); PX[i] = g4_read128<0>(xa[0][0] + i * 2048); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { QW[i] = g4_read128<0>(wa[0][1] + i * 2048); QX[i] = g4_read128<0>(xa[0][1] + i * 2048); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G4_SB();
+    __builtin_amdgcn_s_barrier();
+    G4_SB();
+
+    for (;;) {
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < nblk;
+        int m0n = m0, n0n = n0;                                                  // no next tile: the run-on requests re-read this tile's first K tiles (never consumed)
+        if (has_next) coords(vn, m0n, n0n);
+        const unsigned sX = (unsigned)m0 * (unsigned)K * 2u, sW = (unsigned)n0 * (unsigned)K * 2u;
+        const unsigned sXn = (unsigned)m0n * (unsigned)K * 2u, sWn = (unsigned)n0n * (unsigned)K * 2u;
+        // (nk >= 4, even: the launcher checks)
+        // (ablation 64, timing only: every workgroup walks K from its own starting tile -- much SLOWER: workgroups that share an operand panel
+        // must stream it together, it does not stay in the L2 between them)
+        const int rot = (VAR & 64) ? (int)((blockIdx.x >> 3) * 5 + (blockIdx.x & 7) * 2) : 0;
+#define kofs(t) ((VAR & 64) ? (unsigned)(((t) + rot) & (nk - 1)) * 128u : (unsigned)(t) * 128u)
+        G4_KTILE(0, true, QX, QW, RX, RW, sX + kofs(2), sW + kofs(2))
+        G4_KTILE(1, false, RX, RW, QX, QW, sX + kofs(3), sW + kofs(3))
+        for (int t = 2; t + 2 < nk; t += 2) {
+            const unsigned kb = kofs(t + 2), kb1 = kofs(t + 3);
+            G4_KTILE(0, false, QX, QW, RX, RW, sX + kb, sW + kb)
+            G4_KTILE(1, false, RX, RW, QX, QW, sX + kb1, sW + kb1)
+        }
+        G4_KTILE(0, false, QX, QW, RX, RW, sXn + kofs(0), sWn + kofs(0))
+        G4_KTILE(1, false, RX, RW, QX, QW, sXn + kofs(1), sWn + kofs(1))
+#undef kofs
+        // the last inline-asm MFMAs' results: the compiler does not see the MFMA -> v_accvgpr_read hazard ...
+        G4_SB();
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        // ... and every accumulator is re-defined BEHIND the pad (empty asm, "+a") right where the epilogue reads it: an accumulator's last MFMA is
+        // issued up to 63 MFMAs before the end of the loop, and the compiler is free to read it right there, one instruction behind an MFMA that
+        // takes 16 cycles.  (One redefinition of all 64 in front of the epilogue made the allocator copy half of them into VGPRs at once --
+        // with the next tile's two fragment sets live that spilled six fragments, stored to scratch straight behind their asynchronous LDS reads.)
+        G4_SB();
+        // ---- epilogue: [folded LayerNorm +] bias [+ GELU], one conversion per pair, lane rows swapped into 16-byte pieces, buffer stores (the
+        // direct-store epilogue of k_gemm256p).  Every LDS read of the tail is inline asm: an ordinary one makes hipcc drain the request queue
+        {
+            const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc((void *)g.out, 0, 0x7FFFFFFF, 0x00020000);
+            const unsigned ldb = (unsigned)g.ld_out * 2u;
+            const unsigned ovoff = (unsigned)(wm * 128 + fr) * ldb + (unsigned)(wn * 128 + ((fq & 1) << 4) + ((fq >> 1) << 3)) * 2u;
+            const unsigned so0 = (unsigned)m0 * ldb + (unsigned)n0 * 2u;
+            const unsigned tb = lds0 + G4_TAIL_BIAS + (unsigned)(wn * 128 + fq * 4) * 4u;
+            // this lane's 8 token rows (mb, fr): (rstd, -mean rstd) from the four partial (sum, sum of squares) slots, in exactly the operations of
+            // k_gemm256p's park_tile_vectors (its ISA: two add trees, mean = inv_k sum, fma(inv_k, sq, -(mean mean)), max 0, + 1e-6, v_rsq, rstd (-mean))
+            [[maybe_unused]] float ln_rs[8], ln_nm[8];
+            if constexpr (LN) {
+                const float inv_k = 1.0f / K;
+                const unsigned ts = lds0 + G4_TAIL + (unsigned)(wm * 128 + fr) * 32u;
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    u32x4 au, bu;
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(au), "=&v"(bu) : "v"(ts), "n"(mb * 512), "n"(mb * 512 + 16));
+                    const f32x4 a = __builtin_bit_cast(f32x4, au), b = __builtin_bit_cast(f32x4, bu);
+                    const float sum = __fadd_rn(__fadd_rn(a[0], a[2]), __fadd_rn(b[0], b[2])), sq = __fadd_rn(__fadd_rn(a[1], a[3]), __fadd_rn(b[1], b[3]));
+                    const float mean = __fmul_rn(inv_k, sum);
+                    const float var = __fmaf_rn(inv_k, sq, -__fmul_rn(mean, mean));
+                    const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(var, 0.f), 1e-6f));
+                    ln_rs[mb] = rstd; ln_nm[mb] = __fmul_rn(rstd, -mean);
+                }
+            }
+#pragma unroll
+            for (int np = 0; np < 4; ++np) {                                     // channel block pairs (2 np, 2 np + 1): 32 channels
+                u32x4 b0u, b1u, c0u = {0u, 0u, 0u, 0u}, c1u = {0u, 0u, 0u, 0u};
+                if constexpr (LN)
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(b0u), "=&v"(b1u), "=&v"(c0u), "=&v"(c1u) : "v"(tb), "n"((2 * np) * 64), "n"((2 * np + 1) * 64), "n"(1024 + (2 * np) * 64), "n"(1024 + (2 * np + 1) * 64));
+                else
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(b0u), "=&v"(b1u) : "v"(tb), "n"((2 * np) * 64), "n"((2 * np + 1) * 64));
+                const f32x4 b0 = __builtin_bit_cast(f32x4, b0u), b1 = __builtin_bit_cast(f32x4, b1u);
+                [[maybe_unused]] const f32x4 c0 = __builtin_bit_cast(f32x4, c0u), c1 = __builtin_bit_cast(f32x4, c1u);
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    asm volatile("" : "+a"(acc[mb][2 * np]), "+a"(acc[mb][2 * np + 1]));
+                    const f32x4 v0 = acc[mb][2 * np], v1 = acc[mb][2 * np + 1];
+                    f32x2_t p00 = {v0[0], v0[1]}, p01 = {v0[2], v0[3]}, p10 = {v1[0], v1[1]}, p11 = {v1[2], v1[3]};
+                    const f32x2_t bb00 = {b0[0], b0[1]}, bb01 = {b0[2], b0[3]}, bb10 = {b1[0], b1[1]}, bb11 = {b1[2], b1[3]};
+                    if constexpr (LN) {
+                        // rstd (acc - mean colsum) + bias = fma(acc, rstd, fma(-mean rstd, colsum, bias)), as in k_gemm256p
+                        const f32x2_t rs = {ln_rs[mb], ln_rs[mb]}, nm = {ln_nm[mb], ln_nm[mb]};
+                        p00 = __builtin_elementwise_fma(p00, rs, __builtin_elementwise_fma(nm, (f32x2_t){c0[0], c0[1]}, bb00));
+                        p01 = __builtin_elementwise_fma(p01, rs, __builtin_elementwise_fma(nm, (f32x2_t){c0[2], c0[3]}, bb01));
+                        p10 = __builtin_elementwise_fma(p10, rs, __builtin_elementwise_fma(nm, (f32x2_t){c1[0], c1[1]}, bb10));
+                        p11 = __builtin_elementwise_fma(p11, rs, __builtin_elementwise_fma(nm, (f32x2_t){c1[2], c1[3]}, bb11));
+                    } else {
+                        p00 += bb00; p01 += bb01; p10 += bb10; p11 += bb11;
+                    }
+                    if constexpr (EPI == G4_EPI_GELU_LN) { p00 = g4_gelu2(p00); p01 = g4_gelu2(p01); p10 = g4_gelu2(p10); p11 = g4_gelu2(p11); }
+                    const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p00, bf16x2_t)), a1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2_t));
+                    const unsigned e0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p10, bf16x2_t)), e1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p11, bf16x2_t));
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, 0);
+                    G4_SB();                                                     // (keeps the scheduler from hoisting all 256 accumulator reads: the next tile's two fragment sets are live here)
+                }
+            }
+        }
+        G4_SB();
+        __builtin_amdgcn_s_barrier();                                            // everybody has read the tail: the next tile's vectors may land in it
+        G4_SB();
+        if (!has_next) break;
+        v = vn; m0 = m0n; n0 = n0n;
+        G4_TAIL_REQUESTS(m0, n0)
+        G4_SB();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the run-on requests of the last tile: landed before the LDS is given back
+#undef G4_TAIL_REQUESTS
+#undef G4_MM
+#undef G4_KEEP
+#undef G4_DMAX
+#undef G4_DMAW
+#undef G4_H1ROW
+#undef G4_H2ROW
+#undef G4_WRS
+#undef G4_RW
+#undef G4_RX
+#undef G4_KTILE
 }
 
+static int g4_num_cus() {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+// shapes this kernel takes: whole 256 x 256 tiles, an even number (>= 4) of K tiles, every operand below 2 GiB (32-bit buffer offsets)
+static bool g4_shape_ok(int M, int N, int K, int ld_out) {
+    if (M % 256 || N % 256 || K % 128 || K < 256) return false;
+    return (size_t)M * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 31) && (size_t)M * ld_out * 2 < ((size_t)1 << 31);
+}
+template <int EPI, int VAR>
+static void g4_launch(const Gemm4wArgs &a, hipStream_t s) {
+    static CpxOncePerDevice once;
+    once([] { (void)hipFuncSetAttribute((const void *)k_gemm4w<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); });
+    const int n_cu = g4_num_cus();
+    hipLaunchKernelGGL((k_gemm4w<EPI, VAR>), dim3(a.n_blocks < n_cu ? a.n_blocks : n_cu), dim3(G4_THREADS), G4_LDS_BYTES, s, a);
+}
+
+// mlp.lin1 of the bf16 network: out = gelu(LayerNorm-folded(A) W^T + bias), bf16.  Returns 1 when launched, 0 when the shape is not this
+// kernel's (the caller then takes k_gemm256p, which computes the same bits).
+int cpx_gemm4w_gelu_ln(const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
+                       void *out, int ld_out, hipStream_t s) {
+    if (!g4_shape_ok(M, N, K, ld_out) || !bias || !ln_stats || !ln_colsum) return 0;
+    Gemm4wArgs a;
+    a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = ln_stats; a.ln_colsum = ln_colsum;
+    a.out = (unsigned short *)out; a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
+    g4_launch<G4_EPI_GELU_LN, 0>(a, s);
+    return 1;
+}
+
+#ifdef CPX_DEBUG
+static int g_gemm4w_var = 0;
+extern "C" void cpx_gemm4w_set_variant(int v) { g_gemm4w_var = v; }
 // out[M][ld_out] (bf16) = A[M][K] . W[N][K]^T + bias; M, N multiples of 256, K a multiple of 128, every operand below 2 GiB
 extern "C" int cpx_gemm4w(const void *A, const void *W, int M, int N, int K, const float *bias, void *out, int ld_out, void *stream) {
-    if (M % 256 || N % 256 || K % 128 || K < 256) return CPX_EINVAL;
-    if ((size_t)M * K * 2 >= ((size_t)1 << 31) || (size_t)N * K * 2 >= ((size_t)1 << 31) || (size_t)M * ld_out * 2 >= ((size_t)1 << 31)) return CPX_EINVAL;
+    if (!g4_shape_ok(M, N, K, ld_out) || !bias) return CPX_EINVAL;
     Gemm4wArgs a;
-    a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.out = (unsigned short *)out;
-    a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
-    static CpxOncePerDevice once;
-    once([] { (void)hipFuncSetAttribute((const void *)k_gemm4w, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); });
-    hipLaunchKernelGGL(k_gemm4w, dim3(a.n_blocks), dim3(G4_THREADS), G4_LDS_BYTES, (hipStream_t)stream, a);
+    a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = nullptr; a.ln_colsum = nullptr;
+    a.out = (unsigned short *)out; a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (g_gemm4w_var) {
+        case 1: g4_launch<G4_EPI_BIAS, 1>(a, s); break;
+        case 2: g4_launch<G4_EPI_BIAS, 2>(a, s); break;
+        case 3: g4_launch<G4_EPI_BIAS, 3>(a, s); break;
+        case 4: g4_launch<G4_EPI_BIAS, 4>(a, s); break;
+        case 7: g4_launch<G4_EPI_BIAS, 7>(a, s); break;
+        case 8: g4_launch<G4_EPI_BIAS, 8>(a, s); break;
+        case 128: g4_launch<G4_EPI_BIAS, 128>(a, s); break;
+        default: g4_launch<G4_EPI_BIAS, 0>(a, s);
+    }
     return hipGetLastError() == hipSuccess ? 0 : CPX_EHIP;
 }
 #endif  // CPX_DEBUG

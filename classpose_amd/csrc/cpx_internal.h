@@ -52,6 +52,9 @@ int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C
                    void *out, int ld_out, void *stream);
 int cpx_row_stats_half(int dtype, const void *x, int rows, float *stats, void *stream);
 int cpx_gemm_half_uses_big_tile(int M, int N, int K, int epilogue);
+// one-wave-per-SIMD 256^2 kernel (cpx_gemm4w.hip), bf16: gelu(folded-LayerNorm(A) W^T + bias); 1 = launched, 0 = not this kernel's shape
+int cpx_gemm4w_gelu_ln(const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
+                       void *out, int ld_out, hipStream_t s);
 int cpx_layernorm_half(int dtype, const void *x, const float *w, const float *b, int rows, int C, float eps,
                        void *out, void *stream);
 int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles, void *vT_ws,

@@ -209,7 +209,34 @@ def test_gemm_two_gib_operand_or_output_takes_64_bit_addresses(cuda, N, K, epi):
     assert bool(torch.isfinite(out[::4097].float()).all())
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 2048, 1024)])
+@pytest.mark.parametrize("M,N", [(8192, 2048), (16384, 4096), (32768, 1024)])
+def test_gemm_lin1_one_wave_per_simd_equals_the_eight_wave_kernel(cuda, M, N):
+    """PRODUCTION mlp.lin1 (bf16: folded LayerNorm + bias + erf-GELU) runs on csrc/cpx_gemm4w.hip (one wave per SIMD, packed-f32 epilogue);
+    cpx_gemm_set_4w(0) in the debug build sends the same call to k_gemm256p.  Same accumulation order and the same epilogue arithmetic
+    operation by operation -> bit for bit, one / two / four tiles per workgroup, biases spread so that both GELU tails are exercised."""
+    K = 1024
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 3 + 0.5).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = (torch.randn(N, generator=g) * 3).to(cuda)
+    stats = ops.row_stats(A)
+    colsum = W.float().sum(1).contiguous()
+    prod = ops.gemm_ln(A, W, "gelu", bias, None, ln_stats=stats, ln_colsum=colsum)
+    with _lib.use_debug_library() as L:
+        try:
+            L.cpx_gemm_set_4w(1)
+            four = ops.gemm_ln(A, W, "gelu", bias, None, ln_stats=stats, ln_colsum=colsum)
+            L.cpx_gemm_set_4w(0)
+            eight = ops.gemm_ln(A, W, "gelu", bias, None, ln_stats=stats, ln_colsum=colsum)
+        finally:
+            L.cpx_gemm_set_4w(1)
+    assert torch.equal(prod, four) and torch.equal(four, eight)
+    xn = torch.nn.functional.layer_norm(A[:512].float(), (K,), eps=1e-6)
+    ref = torch.nn.functional.gelu(xn @ W.float().T + bias)
+    assert _rel(prod[:512].float(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 2048, 1024), (16384, 2048, 256), (32768, 1024, 1024), (24576, 1024, 512)])
 def test_gemm_one_wave_per_simd_prototype_equals_the_production_kernel(cuda, M, N, K):
     """csrc/cpx_gemm4w.hip (debug build): the 256^2 tile with one wave per SIMD (128 x 128 per wave, AGPR accumulators through inline-asm
     MFMAs, one barrier per K tile).  Same accumulation order per output element as k_gemm256p -> bit for bit, K = 256 (only the peeled

@@ -68,7 +68,7 @@ def _regs(text: str) -> list[tuple[str, int, int]]:
 
 # timing-only ablation instantiations whose loads go to dead registers by design (results are garbage, the debug build says so)
 ALLOW = re.compile(r"k_attention2qILb[01]ELb1ELi[1-9]")
-NO_SPILL = re.compile(r"^_Z\d+(k_gemm256pI|k_attention4pI)")
+NO_SPILL = re.compile(r"^_Z\d+(k_gemm256pI|k_attention4pI|k_gemm4wI)")
 
 
 def permlane_findings(sym: str, body: list[str], lib: str) -> list[str]:
