@@ -93,13 +93,29 @@ def physical_core_cpus() -> list[int]:
     return out or allowed
 
 
+def _profiler_in_env(env=None):
+    """(variable, value) of the first environment entry that says this process runs UNDER a rocprofiler / roctracer tool, else None.
+    Only values that name such a library count: the GPU boxes preload an unrelated guard library through LD_PRELOAD, and round 4's
+    driver line lost its live traffic measurement to a test for the mere presence of that variable."""
+    env = os.environ if env is None else env
+    for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES"):
+        v = env.get(k, "")
+        if any(tag in v.lower() for tag in ("rocprof", "roctracer", "rocprofiler", "librocm-profiler", "rocprofv")):
+            return k, v
+    for k, v in env.items():
+        if v and k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_", "ROCTRACER_")):
+            return k, v
+    return None
+
+
 def measure_traffic_live(timeout_s: float = 90.0):
     """HBM-side bytes per launch of the dominant kernel, measured NOW on this box: two rocprofv3 --pmc passes (FETCH_SIZE,
     WRITE_SIZE -- separate passes, they do not fit one; kernel-trace only) over tools/pmc_fc1.py, which runs mlp.lin1 of one
     8-tile batch alone.  PMC counters cannot be read from inside this process, so the passes run as child processes (the
     program itself follows ``--``).  gfx950 correction of MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 64 B per 128-B request
-    for wide coalesced / LDS-DMA reads -> doubled; WRITE_SIZE is exact for 16-B stores; both in KB.  None if rocprofv3 is
-    missing or a pass fails (the caller then falls back to the committed profile of the same passes)."""
+    for wide coalesced / LDS-DMA reads -> doubled; WRITE_SIZE is exact for 16-B stores; both in KB.
+    Returns (detail dict | None, reason): when the live passes do not produce a figure the reason says why (the caller falls back
+    to the committed profile of the same passes and records the reason in roofline.traffic_detail)."""
     import csv
     import glob
     import shutil
@@ -109,15 +125,15 @@ def measure_traffic_live(timeout_s: float = 90.0):
     # never from under a profiler: a rocprofv3 started from a process that is itself running under rocprofv3 inherits the
     # outer tool's LD_PRELOAD / ROCP_TOOL_LIBRARIES, its launcher initialises the GPU and then execs -- which takes the
     # box down on this pool -- and the nested passes would pollute the outer counters anyway
-    def _profiler_var(k):
-        return k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB") or k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_", "ROCTRACER"))
-    if any(_profiler_var(k) and os.environ.get(k) for k in os.environ):
-        return None
+    hit = _profiler_in_env()
+    if hit is not None:
+        return None, f"not attempted: this process runs under a profiler ({hit[0]}={hit[1][:80]})"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
-        return None
-    child_env = {k: v for k, v in os.environ.items() if not _profiler_var(k)}
+        return None, "rocprofv3 not found on PATH or under /opt/rocm/bin"
+    child_env = dict(os.environ)
     child_env["TMPDIR"] = "/tmp"
+    kname = _lib.FC1_KERNEL_NAME.split(" = ")[1].split("(")[0]
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="cpx_pmc_", dir="/tmp")
@@ -126,33 +142,34 @@ def measure_traffic_live(timeout_s: float = 90.0):
             # orphaned pmc_fc1.py would keep the GPU busy under the side lines)
             proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
                                      os.path.join(ROOT, "tools", "pmc_fc1.py")], cwd="/tmp", env=child_env,
-                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True, text=True)
             try:
-                rc = proc.wait(timeout=timeout_s)
+                _, err = proc.communicate(timeout=timeout_s)
+                rc = proc.returncode
             except subprocess.TimeoutExpired:
                 try:
                     os.killpg(proc.pid, signal.SIGKILL)
                 except ProcessLookupError:
                     pass
                 proc.wait()
-                return None
+                return None, f"the rocprofv3 --pmc {counter} pass did not finish within {timeout_s:.0f} s (killed)"
             if rc != 0:
-                return None
+                return None, f"the rocprofv3 --pmc {counter} pass exited with code {rc}: {(err or '').strip()[-200:]}"
             tot, n = 0.0, 0
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r["Counter_Name"] == counter and r["Kernel_Name"].startswith(_lib.FC1_KERNEL_NAME.split(" = ")[1].split("(")[0]):
+                        if r["Counter_Name"] == counter and r["Kernel_Name"].startswith(kname):
                             tot += float(r["Counter_Value"]); n += 1
             if n == 0:
-                return None
+                return None, f"the rocprofv3 --pmc {counter} pass wrote no row for {kname}"
             vals[counter] = (tot / n, n)
-        except Exception:
-            return None
+        except Exception as e:                                                  # noqa: BLE001 -- any failure here is a reason, not a crash
+            return None, f"the rocprofv3 --pmc {counter} pass raised {type(e).__name__}: {e}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
-    return {"traffic": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "launches_counted": vals["FETCH_SIZE"][1]}
+    return {"traffic": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "launches_counted": vals["FETCH_SIZE"][1]}, None
 
 
 def cgroup_cpu_limit() -> float | None:
@@ -225,6 +242,25 @@ def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=75.0):
                        f"reference cannot run here (cellpose / cv2 / openslide wheels absent)")
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N ...` started directly: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>` as a child process (this process has not initialised a GPU: torch.cuda.device_count() does not) and return its exit code.
+    Fewer than N GPUs is an error unless CPX_DIST_BACKEND=gloo asks for the dry run in which several ranks share a device."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("CPX_DIST_BACKEND", "") != "gloo":
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); nothing was run "
+              f"(CPX_DIST_BACKEND=gloo runs {n} ranks over the GPUs there are, as a dry run of the launch line)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
 def _mmm(v):
     v = sorted(v)
     return {"min": round(v[0], 4), "median": round(v[len(v) // 2], 4), "max": round(v[-1], 4)}
@@ -244,9 +280,13 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic then comes from the committed profile)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as fresh child processes, BEFORE anything in this
+        # process has touched a GPU -- and leave with their exit code.  (Until round 4 this ran ONE rank and printed n_gpus: 1.)
+        sys.exit(spawn_ranks(args.gpus))
     rank, world, local = parallel.init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would misreport n_gpus")
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))   # (dry runs may map 2 ranks to 1 GPU)
     torch.cuda.set_device(dev)
     L = _lib.lib()
@@ -323,6 +363,7 @@ def main():
             print("BENCH_DEBUG host ms between loop iterations:", [round((b - a) * 1e3, 1) for a, b in zip(dbg_t, dbg_t[1:])], file=sys.stderr)
 
     rec_counts: list[int] = []                # records every rank contributed to the timed run's all-gather
+    decode_ahead = None                       # TileStream.ahead of the timed run: batches the reader may have decoded into pinned memory at t0
 
     def timed_run(e, n_steps, n_warm, inject=True, prof=None, collective=False):
         """ONE TileStream over warm-up + timed batches (its reader / copy threads pay their one-off HIP thread start-up
@@ -356,6 +397,8 @@ def main():
             dt = time.perf_counter() - t0
             if prof is not None:
                 e.w.c.prof = None
+            nonlocal decode_ahead
+            decode_ahead = ts.ahead
         return dt, float(cells_acc.item()), allrec
 
     # the dominant GEMM is timed on every 4th layer, the sampled layers rotating by one per step so that all 24 are
@@ -369,7 +412,8 @@ def main():
     dt, cells, allrec = timed_run(eng, steps, args.warmup, inject=True, prof=prof, collective=True)
     dt = parallel.allreduce_max(dt, dev)
     cells = parallel.allreduce_sum(cells, dev)
-    ms_k, cnt_k = (C.c_double * 5)(), (C.c_int * 5)()
+    NK = len(_lib.PROF_KINDS)
+    ms_k, cnt_k = (C.c_double * NK)(), (C.c_int * NK)()
     _lib.check(L.cpx_prof_collect(prof, ms_k, cnt_k), "prof_collect")
     L.cpx_prof_destroy(prof)
     fc1_launches = int(cnt_k[0])
@@ -384,16 +428,20 @@ def main():
     # otherwise (N > 1, --no-live-traffic, rocprofv3 unavailable) the figure of the same passes over the whole bench command
     # committed under profiles/ is reported, named with its source
     traffic, traffic_src, traffic_detail = None, None, None
-    if rank == 0 and world == 1 and not args.no_live_traffic:
-        traffic_detail = measure_traffic_live()
+    fallback_reason = ("not attempted: --no-live-traffic" if args.no_live_traffic else
+                       "not attempted: the live passes run on rank 0 of a 1-GPU run only" if (rank != 0 or world != 1) else None)
+    if fallback_reason is None:
+        traffic_detail, fallback_reason = measure_traffic_live()
         if traffic_detail is not None:
             traffic, traffic_src = traffic_detail["traffic"], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over tools/pmc_fc1.py"
     if traffic is None:
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic_detail = {"fallback_reason": fallback_reason}
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["traffic_bytes_per_launch"]
                 traffic_src = "profiles/%s (separate rocprofv3 --pmc passes over this command)" % name
+                traffic_detail["source"] = "profiles/" + name
                 break
             except Exception:
                 pass
@@ -409,10 +457,12 @@ def main():
     if rank == 0 and not args.no_stages:
         stages = {}
         n6 = min(6, n_distinct)
-        cap = n6 * args.depth * 5 + 8
+        cap = n6 * (args.depth * 5 + 2) + 8
         prof2 = C.c_void_p()
-        _lib.check(L.cpx_prof_create(cap, 1, 0x1F, C.byref(prof2)), "prof_create")
+        _lib.check(L.cpx_prof_create(cap, 1, 0x7F, C.byref(prof2)), "prof_create")
+        eng.stage_timing = []
         timed_run(eng, n6, 2, inject=True, prof=prof2)
+        stage_ev, eng.stage_timing = eng.stage_timing[2:], None         # (the two warm-up batches are not counted)
         ms_l, kind_l, n_l = (C.c_float * cap)(), (C.c_int * cap)(), C.c_int(0)
         _lib.check(L.cpx_prof_collect_launches(prof2, ms_l, kind_l, cap, C.byref(n_l)), "prof_collect_launches")
         L.cpx_prof_destroy(prof2)
@@ -421,7 +471,14 @@ def main():
         for i in range(n_l):
             per_kind[kind_l[i]].append(float(ms_l[i]))
         kernel_time_sum = 0.0
-        for k, name in enumerate(_lib.PROF_KINDS):
+        med_of = lambda v: sorted(v)[len(v) // 2] if v else None
+        # what the network stream runs besides the five per-layer kernels, and the post stream's blend: per step, median over the pass
+        other = {"pre: percentile statistics + patch rows (3 launches)": med_of([e[0].elapsed_time(e[1]) for e in stage_ev]),
+                 "patch_embed (1 launch)": med_of(per_kind[_lib.PROF_KINDS.index("patch_embed")]),
+                 "neck + head (5 launches, one span)": med_of(per_kind[_lib.PROF_KINDS.index("neck_head")]),
+                 "post stream: blend (1 launch; beside the next batch's network)": med_of([e[3].elapsed_time(e[4]) for e in stage_ev])}
+        net_span = med_of([e[0].elapsed_time(e[2]) for e in stage_ev])   # first pre-processing launch -> end of the head GEMM, network stream
+        for k, name in enumerate(_lib.PROF_KINDS[:5]):
             v = sorted(per_kind[k])
             if not v:
                 continue
@@ -488,7 +545,11 @@ def main():
                                    "configs[1]" if S == 10000 else "north-star slide" if S == 40000 else "custom slide",
                                    S, S, len(coords), args.depth, bt, MAX_DISTINCT_BATCHES),
                    "slide": S, "tile": TILE, "overlap": OVERLAP, "batch_subtiles": bt * 4,
-                   "tiles_per_step": bt, "distinct_batches": n_distinct, "records_gathered": int(allrec.shape[0])},
+                   "tiles_per_step": bt, "distinct_batches": n_distinct, "records_gathered": int(allrec.shape[0]),
+                   # since round 4 the gate holds back the H2D copy of the timed batches, not their decoding: up to this many of them
+                   # (of `steps`) may already sit decoded in pinned host memory when the clock starts, as at any moment of the steady
+                   # state.  Rounds 1-3 also timed their decoding (worth ~1.3 % at 20 steps, nothing over the whole slide)
+                   "decode_ahead_batches_at_t0": decode_ahead},
         "roofline": {"bound": "mfma", "kernel": "%s (mlp.lin1 %dx4096x1024)" % (_lib.FC1_KERNEL_NAME, M),
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
@@ -502,6 +563,16 @@ def main():
         # the five per-layer kernels at their median launch time x depth: the part of ms_per_step the network stream spends
         # in them (must be <= ms_per_step; the rest is the small kernels: patch embedding, neck, head, blend, normalise)
         line["roofline"]["kernel_time_sum_ms_per_step"] = round(kernel_time_sum, 3)
+        # ... and the rest, itemised (stage pass: every launch between its own event pair, so its steps are slower than the headline's):
+        # network_stream_span = first pre-processing launch -> end of the head GEMM of one batch; span - (five kernels x depth) - the three
+        # network-stream items = what no kernel owns: ~125 launch boundaries + the event pairs of this pass
+        on_net = sum(v for k, v in other.items() if v is not None and not k.startswith("post stream"))
+        line["roofline"]["other_kernels_ms_per_step"] = {k: (round(v, 4) if v is not None else None) for k, v in other.items()}
+        line["roofline"]["other_kernels_ms_per_step"]["sum on the network stream"] = round(on_net, 4)
+        if net_span is not None:
+            line["roofline"]["network_stream_span_ms_per_step_stage_pass"] = round(net_span, 3)
+            line["roofline"]["launch_boundaries_and_event_pairs_ms_per_step_stage_pass"] = round(net_span - kernel_time_sum - on_net, 3)
+        line["roofline"]["ms_per_step_minus_itemised"] = round(dt / steps * 1e3 - kernel_time_sum - on_net, 3)
     if side is not None:
         line["side_lines"] = side
     if rank == 0:

@@ -16,10 +16,10 @@ LIB_PATH = os.path.join(_HERE, "libclasspose_hip.so")
 DEBUG_LIB_PATH = os.path.join(_HERE, "libclasspose_hip_debug.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 DTYPE_CODE = {"bf16": DT_BF16, "fp16": DT_F16, "fp32": DT_F32}
-PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2")
+PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2", "patch_embed", "neck_head")
 # the kernel behind kind "fc1" (the dominant launch of the network; its name as rocprofv3 prints it)
 FC1_KERNEL_NAME = "k_gemm4w<GELU + folded LayerNorm, one wave per SIMD> = void k_gemm4w<1, 0>(Gemm4wArgs)"
 
@@ -191,10 +191,16 @@ def source_build_id() -> str:
     return h.hexdigest()[:16]
 
 
+_BUILD_ID_CHECKED: set = set()
+
+
 def build_id() -> str:
     """``cpx_build_id()`` of the loaded library; a mismatch with the sources on disk is reported once on stderr (the .so
     files are git-ignored and travel with snapshots: this is how a stale one shows)."""
     bid = lib().cpx_build_id().decode()
+    if bid in _BUILD_ID_CHECKED:
+        return bid
+    _BUILD_ID_CHECKED.add(bid)
     try:
         src = source_build_id()
     except OSError:

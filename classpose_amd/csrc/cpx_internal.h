@@ -24,7 +24,10 @@ struct CpxOncePerDevice {
 // optional per-launch timing (bench.py's roofline lines): HIP events on the launch stream
 // around the kernels of the selected kinds.  Created by cpx_prof_create, carried in
 // cpx_net_weights.prof, owned by the caller; one handle per engine / host thread.
-enum { CPX_PROF_FC1 = 0, CPX_PROF_ATTN = 1, CPX_PROF_QKV = 2, CPX_PROF_PROJ = 3, CPX_PROF_FC2 = 4, CPX_PROF_KINDS = 5 };
+enum { CPX_PROF_FC1 = 0, CPX_PROF_ATTN = 1, CPX_PROF_QKV = 2, CPX_PROF_PROJ = 3, CPX_PROF_FC2 = 4,
+       CPX_PROF_PE = 5,        // the patch embedding (one launch per forward)
+       CPX_PROF_TAIL = 6,      // neck (1x1 conv, LayerNorm2d, 3x3 conv, LayerNorm2d) + head GEMM [+ UNet head]: ONE span per forward
+       CPX_PROF_KINDS = 7 };
 struct CpxProf {
     hipEvent_t *ev = nullptr;      // 2 per timed launch
     int *kind = nullptr;
@@ -35,7 +38,8 @@ struct CpxProf {
 };
 // returns true and records the start event when this launch is to be timed
 static inline bool cpx_prof_begin(CpxProf *p, int kind, int layer, hipStream_t s) {
-    if (!p || !p->ev || p->n >= p->cap || !((p->kinds_mask >> kind) & 1) || ((layer + p->phase) % p->stride) != 0) return false;
+    if (!p || !p->ev || p->n >= p->cap || !((p->kinds_mask >> kind) & 1)) return false;
+    if (kind < CPX_PROF_PE && ((layer + p->phase) % p->stride) != 0) return false;      // (the once-per-forward kinds ignore the layer stride)
     p->kind[p->n] = kind;
     return hipEventRecord(p->ev[2 * p->n], s) == hipSuccess;
 }

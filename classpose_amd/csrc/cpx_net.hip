@@ -1167,7 +1167,7 @@ extern "C" int cpx_prof_create(int max_launches, int stride, unsigned kinds_mask
     return CPX_OK;
 }
 // per kind: sum of elapsed ms and number of timed launches since the last collect; call after a stream sync.
-// ms_sum / count: arrays of CPX_PROF_KINDS (5) entries: fc1, attention, qkv, proj, fc2.
+// ms_sum / count: arrays of CPX_PROF_N_KINDS (7) entries: fc1, attention, qkv, proj, fc2, patch embedding, neck + head (one span).
 extern "C" int cpx_prof_collect(void *prof, double *ms_sum, int *count) {
     CpxProf *p = (CpxProf *)prof;
     CPX_REQUIRE(p && ms_sum && count);
@@ -1231,8 +1231,8 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
                            cpx_gemm_half_uses_big_tile(M, 1024, 4096, CPX_EPI_RESID_BF16);
     // on the 256^2 kernel (three K tiles) the patch embedding emits the first layer's row statistics itself
     const bool pe_stats = big_stats && cpx_gemm_half_uses_big_tile(M, 1024, 192, CPX_EPI_POS_BF16);
-    RUN(cpx_gemm_half(dt, patches, w->pe_w, M, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024, nullptr, nullptr,
-                      pe_stats ? st : nullptr, stream));
+    TIMED(CPX_PROF_PE, 0, cpx_gemm_half(dt, patches, w->pe_w, M, 1024, 192, CPX_EPI_POS_BF16, w->pe_b, w->pos, x, 1024, nullptr, nullptr,
+                                        pe_stats ? st : nullptr, stream));
     if (fuse && !pe_stats) RUN(cpx_row_stats_half(dt, x, M, st, stream));
     const int qkv_epi = trv ? CPX_EPI_BF16 : CPX_EPI_QKV_BF16;
     for (int i = 0; i < w->depth; ++i) {
@@ -1256,6 +1256,7 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
         TIMED(CPX_PROF_FC2, i, GEMM(hb, b.fc2_w, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024));
     }
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d
+    const bool t_tail = cpx_prof_begin(prof, CPX_PROF_TAIL, 0, hs);
     RUN(GEMM(x, w->neck0_w, 256, 1024, CPX_EPI_BF16, nullptr, nullptr, nk, 256));
     RUN(cpx_layernorm_half(dt, nk, w->neck_ln1_w, w->neck_ln1_b, M, 256, 1e-6f, nk2, stream));
     // 3x3 conv as an implicit GEMM (K = 9 x 256, the shifted operand is read by the LDS-DMA itself: no im2col buffer)
@@ -1268,6 +1269,7 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
         CPX_REQUIRE(workspace_bytes >= L.total + need);
         RUN(cpx_unet_head_run(dt, w->unet_ops, w->n_unet_ops, nk2, nS, head, w->ld_head, 192, ws + L.total, need, stream));
     }
+    if (t_tail) cpx_prof_end(prof, hs);
 #undef TIMED
 #undef GEMM
 #undef RUN

@@ -397,6 +397,9 @@ class Engine:
         self.s_post = torch.cuda.Stream(d, priority=int(os.environ.get("CPX_POST_STREAM_PRIORITY", "0")))
         self._next = 0
         self._last: _Slot | None = None
+        # None, or a list that submit() appends five timing events per batch to: [pre start, pre end = network start, network end] on the
+        # network stream, [blend start, blend end] on the post stream (bench.py: roofline.other_kernels_ms_per_step)
+        self.stage_timing: list | None = None
 
     # -- pipeline -------------------------------------------------------
     def submit(self, tiles_u8: torch.Tensor, inject=None, records: bool = True, polygons=None) -> int:
@@ -405,9 +408,16 @@ class Engine:
         mode (the network still runs; the dynamics consume the injected fields instead).
         ``polygons`` = (scale, origins [n][2] level-0 tile origins): also polygonise the instances
         on the device (``cpx_polygonize_device``), results via ``fetch_polygons``."""
+        # (ValueError, not assert: these guard raw device pointers handed to the C ABI and must survive `python -O`)
+        if tiles_u8.dtype != torch.uint8 or tiles_u8.dim() != 4 or not tiles_u8.is_contiguous():
+            raise ValueError(f"Engine.submit: tiles must be a contiguous uint8 [n, H, W, 3] tensor, got {tiles_u8.dtype} {tuple(tiles_u8.shape)}")
         n = tiles_u8.shape[0]
-        assert n <= self.nT and tiles_u8.dtype == torch.uint8 and tiles_u8.is_contiguous()
-        assert tiles_u8.shape[1:] == (self.H, self.W, 3) and tiles_u8.device == self.dev
+        if n > self.nT or tuple(tiles_u8.shape[1:]) != (self.H, self.W, 3):
+            raise ValueError(f"Engine.submit: got {tuple(tiles_u8.shape)}, this engine takes at most {self.nT} tiles of {(self.H, self.W, 3)}")
+        if tiles_u8.device != self.dev:
+            raise ValueError(f"Engine.submit: tiles live on {tiles_u8.device}, the engine on {self.dev}")
+        if inject is not None and (len(inject) != 3 or any(t.device != self.dev or not t.is_contiguous() for t in inject)):
+            raise ValueError("Engine.submit: inject = (dP, cellprob, logits) contiguous tensors on the engine's device")
         sid = self._next
         self._next = (self._next + 1) % self.N_SLOTS
         sl = self.slots[sid]
@@ -419,15 +429,23 @@ class Engine:
         self.s_net.wait_event(sl.ev_post)               # this slot's previous batch left the head buffer
         lo_p, lo_g, hi_p, hi_g = self.pct
         sn, sp = self.s_net.cuda_stream, self.s_post.cuda_stream
+        tm = self.stage_timing                          # bench.py's stage pass: event pairs around the stages the C-side profile does not see
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if tm is not None else None
+        if ev:
+            ev[0].record(self.s_net)
         check(self.L.cpx_normalize_stats_u8(ptr(tiles_u8), n, self.H, self.W, lo_p, lo_g, hi_p, hi_g,
                                             ptr(sl.stats), ptr(sl.hist), sn), "normalize_stats")
         check(self.L.cpx_make_patches(ptr(tiles_u8), ptr(sl.stats), n, C.byref(self.tiling), self.w.c.dtype,
                                       ptr(sl.patches), sn), "make_patches")
+        if ev:
+            ev[1].record(self.s_net)
         # the network always runs the full batch (rows of absent tiles hold old patches): kernel selection
         # and tile shapes depend on M, so a partial last batch would otherwise round differently --
         # this keeps a tile's outputs bitwise independent of batch composition, rank and world size
         check(self.L.cpx_net_forward(C.byref(self.w.c), ptr(sl.patches), self.nT * self.n_sub, ptr(sl.head),
                                      ptr(self.net_ws), self.net_ws_bytes, sn), "net_forward")
+        if ev:
+            ev[2].record(self.s_net)
         sl.ev_net.record(self.s_net)
         tiles_u8.record_stream(self.s_net)
         # post stream
@@ -435,9 +453,14 @@ class Engine:
         if inject is not None:
             self.s_post.wait_stream(cur)
         ncls = self.w.ncls
+        if ev:
+            ev[3].record(self.s_post)
         check(self.L.cpx_blend_subtiles(ptr(sl.head), self.w.c.ld_head, ncls if ncls > 1 else 0, n,
                                         C.byref(self.tiling), ptr(self.taper), ptr(sl.dP),
                                         ptr(sl.cellprob), ptr(sl.logits), sp), "blend")
+        if ev:
+            ev[4].record(self.s_post)
+            tm.append(ev)
         dP, cp, lg = (sl.dP, sl.cellprob, sl.logits) if inject is None else inject
         # one fused chain: ids, classes and (when asked for) the per-cell records leave in its last pass
         check(self.L.cpx_compute_masks_records(ptr(dP), ptr(cp), ptr(lg) if ncls > 1 else None, n, ncls,
@@ -448,7 +471,8 @@ class Engine:
                                                ptr(sl.pp_ws), sp), "compute_masks")
         sl.has_polygons = polygons is not None
         if polygons is not None:
-            assert records, "polygons need the per-cell records"
+            if not records:
+                raise ValueError("Engine.submit: polygons need the per-cell records (records=True)")
             scale, origins = polygons
             if sl.cells is None:
                 sl.cells = torch.empty(self.nT * self.max_rec * C.sizeof(_lib.CpxCell), dtype=torch.uint8, device=self.dev)

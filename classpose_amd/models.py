@@ -49,7 +49,7 @@ class ClassposeModel:
     def __init__(self, gpu: bool = True, pretrained_model: str | dict = "cpsam", model_type=None,
                  diam_mean=None, device: torch.device | None = None, nchan=None, nclasses: int = 3,
                  feature_transformation_structure: list[int] | None = None, precision: str = "bf16",
-                 max_batch_tiles: int = 8):
+                 max_batch_tiles: int = 8, max_engines: int = 4):
         if device is None:
             device = torch.device("cuda:0")
         device = torch.device(device)
@@ -66,23 +66,56 @@ class ClassposeModel:
         self.nclasses = self.weights.ncls
         self.max_batch_tiles = max_batch_tiles
         # several Python threads may share one model and call eval concurrently (the reference's --inference_threads,
-        # predict_wsi.py:728-798): the weights are shared and read-only, every calling thread gets its OWN engine (work
-        # spaces, output slots, HIP streams), so concurrent calls overlap on the GPU instead of queueing behind a lock.
-        # The lock only guards the engine table.
-        self._engines: dict = {}
-        self._lock = threading.Lock()
+        # predict_wsi.py:728-798): the weights are shared and read-only; an ENGINE (network + post-processing work spaces, output
+        # slots, two HIP streams: ~0.9 GB for 8 tiles of 256 px at ViT-L, growing with the tile area) is checked out of a bounded pool
+        # per (tile shape, options) for the duration of one batch and returned afterwards.  At most `max_engines` exist per key, so N
+        # concurrent callers overlap on the GPU up to that number and queue beyond it, and a caller that starts a fresh thread per
+        # request re-uses the pool's engines instead of leaking one per thread (round 4 keyed the table by thread id and never pruned).
+        self.max_engines = max(1, int(max_engines))
+        self._pool: dict = {}                    # key -> {"idle": [Engine], "n": engines created}
+        self._cv = threading.Condition()
         self.timing = []
 
+    class _Lease:
+        def __init__(self, model, key, make):
+            self.model, self.key, self.make, self.eng = model, key, make, None
+
+        def __enter__(self):
+            m = self.model
+            with m._cv:
+                slot = m._pool.setdefault(self.key, {"idle": [], "n": 0})
+                while True:
+                    if slot["idle"]:
+                        self.eng = slot["idle"].pop()
+                        return self.eng
+                    if slot["n"] < m.max_engines:
+                        slot["n"] += 1                       # reserve; built outside the lock (allocations take tens of ms)
+                        break
+                    m._cv.wait()
+            try:
+                self.eng = self.make()
+            except BaseException:
+                with m._cv:
+                    slot["n"] -= 1
+                    m._cv.notify()
+                raise
+            return self.eng
+
+        def __exit__(self, *exc):
+            m = self.model
+            with m._cv:
+                m._pool[self.key]["idle"].append(self.eng)
+                m._cv.notify()
+
     def _engine(self, H, W, augment, tile_overlap, kw):
-        key = (threading.get_ident(), H, W, bool(augment), float(tile_overlap), tuple(sorted(kw.items())))
-        with self._lock:
-            eng = self._engines.get(key)
-        if eng is None:
-            eng = engine.Engine(self.weights, H, W, batch_tiles=self.max_batch_tiles,
-                                augment=augment, tile_overlap=tile_overlap, **kw)
-            with self._lock:
-                self._engines[key] = eng
-        return eng
+        """``with self._engine(...) as eng:`` -- an engine of the bounded pool for this tile shape and these options"""
+        key = (H, W, bool(augment), float(tile_overlap), tuple(sorted(kw.items())))
+        return self._Lease(self, key, lambda: engine.Engine(self.weights, H, W, batch_tiles=self.max_batch_tiles,
+                                                            augment=augment, tile_overlap=tile_overlap, **kw))
+
+    def engines_alive(self) -> int:
+        with self._cv:
+            return sum(slot["n"] for slot in self._pool.values())
 
     def eval(self, x, batch_size: int = 8, resample: bool = True, channels=None, channel_axis=None,
              z_axis=None, normalize=True, invert: bool = False, rescale=None, diameter=None,
@@ -107,16 +140,17 @@ class ClassposeModel:
             groups.setdefault(im.shape, []).append(i)
         kw = dict(niter=200 if not niter else int(niter), cellprob_threshold=cellprob_threshold,
                   flow_threshold=flow_threshold, min_size=min_size, max_size_fraction=max_size_fraction)
+        nT = self.max_batch_tiles
         for shape, idxs in groups.items():
-            eng = self._engine(shape[0], shape[1], augment, tile_overlap, kw)
-            for s in range(0, len(idxs), eng.nT):
-                chunk = idxs[s:s + eng.nT]
+            for s in range(0, len(idxs), nT):
+                chunk = idxs[s:s + nT]
                 tiles = torch.from_numpy(np.stack([np.ascontiguousarray(imgs[i]) for i in chunk])).to(self.device)
-                o = eng.run(tiles, records=False)
-                masks = ops.masks_to_numpy(o.masks) if compute_masks else None
-                cm = o.class_masks.cpu().numpy().astype(np.int64) if compute_masks else None
-                dP, cp = o.dP.cpu().numpy(), o.cellprob.cpu().numpy()
-                yc = o.logits.cpu().numpy() if o.logits is not None else None
+                with self._engine(shape[0], shape[1], augment, tile_overlap, kw) as eng:     # held for this batch only
+                    o = eng.run(tiles, records=False)
+                    masks = ops.masks_to_numpy(o.masks) if compute_masks else None
+                    cm = o.class_masks.cpu().numpy().astype(np.int64) if compute_masks else None
+                    dP, cp = o.dP.cpu().numpy(), o.cellprob.cpu().numpy()
+                    yc = o.logits.cpu().numpy() if o.logits is not None else None
                 for k, i in enumerate(chunk):
                     outs[i] = (masks[k].copy() if compute_masks else np.zeros(0),
                                (dx_to_circ(dP[k]), dP[k].copy(), cp[k].copy(),

@@ -33,7 +33,12 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # the ranks cannot each pick a free port, and a fixed default (29500 until round 4) makes two jobs on one node collide:
+            # whoever starts the ranks chooses the port (torch.distributed.run; the CLI's --device cuda:0,1 parent and bench.py's
+            # --gpus N parent probe a free one and hand it to their children)
+            raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is not set: start the ranks with torch.distributed.run, "
+                               "`classpose-predict-wsi --device cuda:0,1,...` or `bench.py --gpus N`, which choose a free port")
         if backend is None:
             backend = os.environ.get("CPX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":

@@ -41,7 +41,11 @@ extern "C" {
 #define CPX_DT_F16 1
 #define CPX_DT_F32 2   /* --precision fp32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations */
 
-/* Library / device identification. Returns the ABI version (this header: 2). */
+/* Library / device identification. Returns the ABI version (this header: 3).
+ * Version history: 2 = no process-global compute state (round 2); round 4 ADDED cpx_build_id, cpx_compute_masks_records and
+ * cpx_prof_collect_launches without a bump (additive); 3 (round 5) = cpx_prof_collect fills CPX_PROF_N_KINDS = 7 entries (was 5) and
+ * the post-processing workspace of cpx_postproc_workspace_bytes holds six table sets per tile -- callers compiled against version 2
+ * must be rebuilt, and classpose_amd/_lib.py refuses a library whose version differs.                                          */
 int cpx_abi_version(void);
 /* Last HIP error string recorded by a failing call on this thread (host ptr). */
 const char *cpx_last_error(void);
@@ -198,10 +202,11 @@ int cpx_net_forward(const cpx_net_weights *w_host, const void *patches, int n_su
 /* Per-launch timing of the dominant kernels of cpx_net_forward (bench.py's roofline lines): HIP
  * events recorded on the launch stream around every `stride`-th layer's kernels (the sampled layers
  * rotate by one per forward, so every layer is covered equally over `stride` forwards) of the kinds in
- * kinds_mask (bit 0 mlp.lin1, 1 attention, 2 qkv, 3 attn.proj, 4 mlp.lin2).  The handle is carried in
- * cpx_net_weights.prof and belongs to one engine / host thread.  cpx_prof_collect (after a stream
- * sync) fills ms_sum[5] / count[5] per kind and resets the handle.                              */
-#define CPX_PROF_N_KINDS 5
+ * kinds_mask (bit 0 mlp.lin1, 1 attention, 2 qkv, 3 attn.proj, 4 mlp.lin2; once per forward, whatever the
+ * stride: 5 the patch embedding, 6 ONE span over neck + head = the launches behind the last block).  The handle
+ * is carried in cpx_net_weights.prof and belongs to one engine / host thread.  cpx_prof_collect (after a stream
+ * sync) fills ms_sum[CPX_PROF_N_KINDS] / count[CPX_PROF_N_KINDS] per kind and resets the handle.  */
+#define CPX_PROF_N_KINDS 7
 int cpx_prof_create(int max_launches, int stride, unsigned kinds_mask, void **prof_out);
 int cpx_prof_collect(void *prof, double *ms_sum, int *count);
 /* the same launches one by one (launch order; ms[i], kind[i] for i < min(n, cap); *n_out = n; no reset: call it before

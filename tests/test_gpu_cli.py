@@ -82,12 +82,13 @@ def test_classpose_model_eval_parity_and_concurrency(cuda):
     cellprob / class logits within the half-precision tolerance of the float32 oracle network, the id map bit-exact w.r.t.
     the oracle dynamics on the RETURNED fields, class_masks == the oracle's class vote -- and two Python threads calling
     eval on ONE model at the same time (the reference's --inference_threads, predict_wsi.py:790-797) get exactly what the
-    serial calls return (every thread runs its own engine on the shared weights; no lock around the GPU work)."""
+    serial calls return (engines come from a bounded pool on the shared weights; no lock around the GPU work) -- and six
+    more short-lived threads afterwards create no further engine (the pool is capped at max_engines, callers beyond it queue)."""
     import threading
     from classpose_amd.models import ClassposeModel
     from oracle import classmask, dynamics, net as onet, tiling
     sd = synth.make_state_dict(7, None, depth=2, seed=12)
-    model = ClassposeModel(gpu=True, pretrained_model=sd, device=cuda, nclasses=7, precision="bf16")
+    model = ClassposeModel(gpu=True, pretrained_model=sd, device=cuda, nclasses=7, precision="bf16", max_engines=2)
     tiles = [synth.render_region(77, 0, 0, 256, 256), synth.render_region(77, 300, 120, 256, 256),
              synth.render_region(78, 40, 700, 256, 256)]
     masks, flows, class_masks, styles = model.eval(tiles, batch_size=8, augment=False, bsize=256, compute_masks=True)
@@ -121,8 +122,14 @@ def test_classpose_model_eval_parity_and_concurrency(cuda):
     for t in th: t.start()
     for t in th: t.join()
     assert not err, err
-    assert len(model._engines) >= 3                                       # main thread + one engine per worker thread
-    for tid in (0, 1):
+    assert 1 <= model.engines_alive() <= 2
+    # a caller that starts a fresh thread per request: six more threads, three at a time in flight -> still at most max_engines engines
+    th = [threading.Thread(target=work, args=(k, [k % 3])) for k in range(2, 8)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not err, err
+    assert model.engines_alive() <= 2
+    for tid in range(8):
         for j, m, dP_t, cp_t, c in res[tid]:
             assert np.array_equal(m, masks[j]) and np.array_equal(c, class_masks[j])
             assert np.array_equal(dP_t, flows[j][1]) and np.array_equal(cp_t, flows[j][2])
