@@ -185,6 +185,11 @@ __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict_
 typedef float flow4 __attribute__((ext_vector_type(4), aligned(8)));
 
 // HIST (fused chain): the final position goes straight into the padded histogram of get_masks (k_hist's pass)
+// (Round 5 measured TWO Euler chains per lane -- entries e and e + 128 of a quarter segment in one instruction stream, half as many waves, the
+// per-chain operation order untouched -- as the round-4 review suggested for a latency-bound loop: 194-207 us against 120-123 us for this
+// kernel on the analytic fields, 264 against 217-229 on random ones (profiles/r05_ab_follow_two_chains.txt).  The loop is not waiting for one
+// wave's gather: every step is two wave-wide gathers of 64 different cache lines each, i.e. the CU's texture addresser is the busy unit, and
+// fewer, fatter waves only take away what overlapped it.)
 template <bool HIST>
 __global__ void k_follow(int niter, float shx, float shy,
                          float hw, float hh, int32_t *__restrict__ p_final,
