@@ -42,7 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from classpose_amd import _lib, engine, parallel, synth, wsi  # noqa: E402
+from classpose_amd import _lib, engine, hostinfo, parallel, synth, wsi  # noqa: E402
 from classpose_amd.entrypoints.predict_wsi import TileStream  # noqa: E402
 
 TILE, OVERLAP, NCLS = 256, 32, 7
@@ -172,22 +172,7 @@ def measure_traffic_live(timeout_s: float = 90.0):
     return {"traffic": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "launches_counted": vals["FETCH_SIZE"][1]}, None
 
 
-def cgroup_cpu_limit() -> float | None:
-    """CPU time this process tree may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown"""
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, per = f.read().split()
-        return None if q == "max" else float(q) / float(per)
-    except Exception:
-        pass
-    try:
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
-            q = float(f.read())
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
-            per = float(f.read())
-        return None if q <= 0 else q / per
-    except Exception:
-        return None
+cgroup_cpu_limit = hostinfo.cgroup_cpu_limit
 
 
 def cpu_baseline(slide_px, depth, n_tiles=64, warm_total=4, budget_s=75.0):
@@ -308,7 +293,8 @@ def main():
     use = mine[: n_distinct * bt]
 
     # ---- before the timed region: rendered slide tiles in host memory, analytic fields in HBM
-    with ThreadPoolExecutor(max_workers=max(2, min(32, os.cpu_count() or 4))) as pool:
+    hostinfo.limit_torch_threads()
+    with ThreadPoolExecutor(max_workers=max(2, min(32, hostinfo.usable_cpus()))) as pool:
         rendered = list(pool.map(lambda ti: np.concatenate(
             [synth.render_region(SEED, coords[ti][0][0], coords[ti][0][1], TILE, TILE),
              np.full((TILE, TILE, 1), 255, np.uint8)], -1), use))

@@ -35,7 +35,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import engine, geojson, hooks, ops, parallel, postprocess, roi, wsi
+from .. import engine, geojson, hooks, hostinfo, ops, parallel, postprocess, roi, wsi
 from ..log import get_logger
 from ..model_configs import DEFAULT_MODEL_CONFIGS, ModelConfig
 
@@ -92,12 +92,16 @@ class TileStream:
         # of them resident on the device
         self.gate_at, self.gate = gate_at, threading.Event()
         self._stop = threading.Event()
-        n_workers = max(2, min(32, (os.cpu_count() or 4) // 2))
+        self._pe_lock = threading.Lock()
+        # (small tiles are many short numpy / decoder calls that take turns at the GIL: 32 threads still beat 12 on a 16-core cgroup quota -- the
+        # 40 000^2 slide at 256 px read at 360 against 221 tiles/s -- so the quota only caps the pool at twice its cores)
+        n_workers = max(2, min(32, (os.cpu_count() or 4) // 2, hostinfo.usable_cpus() * 2))
         self.ahead = max(depth, -(-n_workers // max(nT, 1)))        # batches being decoded at once
         self.q: queue.Queue = queue.Queue(maxsize=depth)
         self.pinned = [torch.empty((nT, H, W, 3), dtype=torch.uint8).pin_memory()
                        for _ in range(self.ahead + depth + 2)]
         self.copied: dict = {}
+        self.pinned_extra: dict = {}             # slot -> tuple of pinned [nT, ...] float arrays (allocated when the first side input arrives)
         self.copy_stream = torch.cuda.Stream(device)
         self.readers = ThreadPoolExecutor(max_workers=n_workers)
         self.t = threading.Thread(target=self._run, daemon=True)
@@ -138,7 +142,22 @@ class TileStream:
 
         def read(k, ti):
             host[k].copy_(torch.from_numpy(wsi.read_tile(self.slide, self.plan, self.plan.coords[ti])))
-            return self.extra(ti) if self.extra is not None else None
+            if self.extra is None:
+                return None
+            # side inputs of a plug-in (flow-injection tests): every reader thread writes its tile's arrays straight into the slot's pinned
+            # batch -- until round 4 the CONSUMER np.stack-ed the batch (320 MB for 8 tiles of 1024 px) and copied it from pageable memory
+            # on its own thread, 180 ms per batch against 140 ms of GPU work
+            arrs = self.extra(ti)
+            pe = self.pinned_extra.get(slot)
+            if pe is None:
+                with self._pe_lock:
+                    pe = self.pinned_extra.get(slot)
+                    if pe is None:
+                        pe = tuple(torch.empty((self.nT,) + tuple(a.shape), dtype=torch.from_numpy(np.asarray(a)).dtype).pin_memory() for a in arrs)
+                        self.pinned_extra[slot] = pe
+            for dst, a in zip(pe, arrs):
+                dst[k].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+            return True
         return chunk, slot, [self.readers.submit(read, k, ti) for k, ti in enumerate(chunk)]
 
     def _run(self):
@@ -163,6 +182,8 @@ class TileStream:
                         break
                 with torch.cuda.stream(self.copy_stream):
                     dev = self.pinned[slot][: len(chunk)].to(self.dev, non_blocking=True)
+                    if extras and extras[0] is not None:           # the side inputs of the batch, device tensors by the same event
+                        extras = tuple(t[: len(chunk)].to(self.dev, non_blocking=True) for t in self.pinned_extra[slot])
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 self.copied[slot] = ev
@@ -201,8 +222,24 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         model_config = ModelConfig.load_from_yaml(args.model_config)
     model_config.download_if_necessary()
     torch.cuda.set_device(device)
+    # wall-clock attribution of this rank (main thread), logged at the end: where a run's seconds go besides the GPU
+    stage = {k: 0.0 for k in ("checkpoint load", "slide open + plan", "tissue detection", "wait for weights", "engine + stream setup",
+                              "reader wait", "resize + submit", "device wait", "polygons D2H + cell rows")}
+    t_s = time.time()
     sd = model_config.load_state_dict()
     fts, n_classes, _ = engine.NetWeights.infer_structure(sd)
+    stage["checkpoint load"] = time.time() - t_s
+    # the 0.6 GB of network weights are converted and uploaded on a background thread while this one opens the slide, plans the grid, runs
+    # the tissue detection and starts the readers (until round 4 this sat serially in front of the first tile: ~1.5 s of a ~9 s start-up)
+    bg = ThreadPoolExecutor(max_workers=2, thread_name_prefix="cpx-bg")
+
+    def _make_weights():
+        torch.cuda.set_device(device)
+        t_w = time.time()
+        w_ = engine.NetWeights.from_state_dict(sd, args.precision, device)
+        return w_, time.time() - t_w
+    weights_fut = bg.submit(_make_weights)
+    t_s = time.time()
     if getattr(args, "model_path", None) is not None:
         if n_classes > 1:
             raise ValueError("--model_path expects a Cellpose-SAM checkpoint without a class head; "
@@ -237,6 +274,8 @@ def run_rank(args, rank: int, world: int, device: torch.device):
             logger.info(f"Selecting tiles using ROI with {len(rois)} polygons: {len(plan.coords)} tiles")
     plan.rois = rois
     plan.tissue_cnts = None
+    stage["slide open + plan"] = time.time() - t_s
+    t_s = time.time()
     if args.tissue_detection_model_path is not None:
         # SlideLoader._get_tissue_contours (predict_wsi.py:305-322): GrandQC tissue detection on the
         # 10 um/px thumbnail before the first tile is read; tiles that miss every tissue polygon are skipped
@@ -254,12 +293,19 @@ def run_rank(args, rank: int, world: int, device: torch.device):
             plan.coords = [c for c in plan.coords if roi.check_tile_in_cnts(c[0], c[1], plan.ts, plan.tissue_cnts)]
         if rank == 0:
             logger.info(f"Tiles to predict after the tissue filter: {len(plan.coords)}")
-    weights = engine.NetWeights.from_state_dict(sd, args.precision, device)
+    stage["tissue detection"] = time.time() - t_s
+    # GrandQC artefact detection (predict_wsi.py:1678-1760 of the reference runs it after the tile loop): its result is needed by the final
+    # cell filter only, so rank 0 starts it NOW on a background thread -- thumbnail rendering / JPEG round trip on the host, ~300 patches on
+    # the GPU beside the tile loop -- and write_outputs collects it (8 s of a 41 s run were spent serially behind the loop in round 4)
+    plan.artefact_future = None
+    if rank == 0 and args.artefact_detection_model_path is not None and args.tissue_detection_model_path is not None and plan.coords:
+        plan.artefact_future = bg.submit(_detect_artefacts, args, device)
+    weights = None
     mine = list(parallel.shard_indices(len(plan.coords), rank, world))
     by_size: dict[int, list[int]] = {}
     for ti in mine:
         by_size.setdefault(plan.coords[ti][1], []).append(ti)
-    pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // max(world, 1))))
+    pool = ThreadPoolExecutor(max_workers=max(2, min(16, hostinfo.usable_cpus() // max(world, 1))))
     futures = []
     cells_all, xy_all, tile_all, n_invalid = [], [], [], 0
     scale = plan.polygon_scale        # min(train_mpp / mpp_x, train_mpp / mpp_y) from the shared slots, predict_wsi.py:1517-1524
@@ -274,19 +320,32 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         nT = max(1, max(args.batch_size, 96) // n_sub)
         step = 8 // math.gcd(n_sub, 8)
         nT = -(-nT // step) * step
-        eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
+        t_s = time.time()
         extra = None
         provider = hooks.field_provider(slide, plan, n_classes) if hooks.field_provider else None
         if provider is not None:                                 # plug-in supplied dynamics inputs (classpose_amd/hooks.py)
             def extra(ti, R=R, W=W, H=H):
-                return provider(ti, R, W, H)
-        stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra)
+                return provider(ti, R, W, H)[:3]                 # (dP, cellprob, logits)
+        stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra)      # the readers start decoding now
+        waited = 0.0
+        if weights is None:
+            t_w = time.time()
+            weights, t_conv = weights_fut.result()
+            waited = stage["wait for weights"] = time.time() - t_w
+            logger.info(f"[rank {rank}] weights converted + uploaded in {t_conv:.2f} s on a background thread "
+                        f"(this thread waited {waited:.2f} s for them)")
+        eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
+        stage["engine + stream setup"] += time.time() - t_s - waited
+
         def collect(sid, chunk, keep_alive):
             nonlocal n_done, n_invalid
             n = len(chunk)
+            t_c = time.time()
             out = eng.result(sid)
-            if int(out.nlabels.max()) >= 65535:
+            if int(out.nlabels.max()) >= 65535:              # (the first read-back of the batch: this is where the host waits for the GPU)
                 raise RuntimeError("more than 65535 instances in one tile: uint16 ids would wrap")
+            stage["device wait"] += time.time() - t_c
+            t_c = time.time()
             polys = eng.fetch_polygons(n, out)
             if polys is not None:                                    # contours traced on the device (f1)
                 cells, tile_in_batch, xy = polys
@@ -305,23 +364,36 @@ def run_rank(args, rank: int, world: int, device: torch.device):
                     origin = plan.coords[ti][0]
                     futures.append((ti, pool.submit(postprocess.polygonize_tile, masks[k].copy(),
                                                     recs[recs["tile"] == k], scale, origin)))
+            stage["polygons D2H + cell rows"] += time.time() - t_c
             n_done += n
             if rank == 0 and (n_done // nT) % 20 == 0:
                 logger.info(f"Predicted tiles: {n_done}/{len(mine)} "
                             f"({n_done / max(time.time() - t0, 1e-9):.1f} tiles/s/GPU)")
 
         in_flight = None                     # one batch runs on the device while the previous one is collected
-        for chunk, tiles_dev, ev, f in stream:
-            torch.cuda.current_stream(device).wait_event(ev)
+        it = iter(stream)
+        while True:
+            t_r = time.time()
+            try:
+                chunk, tiles_dev, ev, f = next(it)
+            except StopIteration:
+                break
+            stage["reader wait"] += time.time() - t_r
+            t_r = time.time()
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ev)
             # the raw batch was allocated on the copy stream: tell the allocator that this stream reads it too,
             # or its block could be handed to the next H2D copy while the resize kernel is still reading
-            tiles_dev.record_stream(torch.cuda.current_stream(device))
+            tiles_dev.record_stream(cur)
             tiles_dev = ops.resize_tile_to_target_mpp(tiles_dev, plan.resize_factor)
             inject = None
-            if extra is not None:
-                inject = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(device) for k in range(3))
+            if extra is not None:                # the plug-in's fields arrive as device tensors of the same copy-stream event (TileStream)
+                inject = tuple(f)
+                for t_ in inject:
+                    t_.record_stream(cur)
             sid = eng.submit(tiles_dev, inject=inject, records=True,
                              polygons=(scale, [plan.coords[ti][0] for ti in chunk]))
+            stage["resize + submit"] += time.time() - t_r
             if in_flight is not None:
                 collect(*in_flight)
             in_flight = (sid, chunk, (tiles_dev, inject))
@@ -344,6 +416,11 @@ def run_rank(args, rank: int, world: int, device: torch.device):
     xy = np.concatenate(xy_all) if xy_all else np.zeros((0, 2))
     plan.cell_tiles = np.concatenate(tile_all) if tile_all else np.zeros(0, np.int64)
     logger.info(f"[rank {rank}] {len(cells)} cells, {n_invalid} invalid, {len(mine)} tiles in {time.time() - t0:.1f}s")
+    # main-thread wall seconds per stage ("device wait" = blocked on the GPU's results, i.e. the engine is the pace-maker; "reader wait" = blocked
+    # on decoded tiles [+ the plug-in's fields]; the rest is host work between two batches)
+    logger.info(f"[rank {rank}] stage wall (s): " + ", ".join(f"{k} {v:.2f}" for k, v in stage.items()))
+    plan.stage_wall = stage
+    bg.shutdown(wait=False)
     return cells, xy, labels, plan
 
 
@@ -375,6 +452,20 @@ def gather_cells(cells: np.ndarray, xy: np.ndarray, device, tiles: np.ndarray | 
         return out_cells, out_xy
     t = torch.from_numpy(np.ascontiguousarray(tiles, dtype=np.int64).view(np.uint8).reshape(len(tiles), 8).copy()).to(device)
     return out_cells, out_xy, parallel.all_gather_records(t).cpu().numpy().reshape(-1).view(np.int64)
+
+
+def _detect_artefacts(args, device):
+    """GrandQC artefact contours of the slide (run by rank 0 on a background thread beside the tile loop, or inline by write_outputs)"""
+    from .. import grandqc
+    torch.cuda.set_device(device)
+    t_a = time.time()
+    logger.info("Running artefact detection")
+    _, _, artefact_cnts, _ = grandqc.detect_artefacts_wsi(
+        wsi.WSIReader(args.slide_path), model_art_path=args.artefact_detection_model_path,
+        model_td_path=args.tissue_detection_model_path, device=device,
+        tissue_override=_qc_override("tissue"), artefact_override=_qc_override("artefact"))
+    logger.info(f"Found {len(artefact_cnts)} artefact contours ({time.time() - t_a:.1f} s)")
+    return artefact_cnts
 
 
 def _qc_override(kind: str):
@@ -462,13 +553,11 @@ def write_outputs(args, cells, xy, labels, plan, device=None):
             logger.warning("Skipping artefact detection as --tissue_detection_model_path was not provided.")
         else:
             # predict_wsi.py:1678-1760: artefact detection, optional cell filter, <stem>_artefact_contours.geojson
-            from .. import grandqc
-            logger.info("Running artefact detection")
-            _, _, artefact_cnts, _ = grandqc.detect_artefacts_wsi(
-                wsi.WSIReader(args.slide_path), model_art_path=args.artefact_detection_model_path,
-                model_td_path=args.tissue_detection_model_path, device=device,
-                tissue_override=_qc_override("tissue"), artefact_override=_qc_override("artefact"))
-            logger.info(f"Found {len(artefact_cnts)} artefact contours")
+            fut = getattr(plan, "artefact_future", None)
+            t_a = time.time()
+            artefact_cnts = fut.result() if fut is not None else _detect_artefacts(args, device)
+            if fut is not None:
+                logger.info(f"Artefact detection ran beside the tile loop; waited {time.time() - t_a:.2f} s for it here")
             art = roi.polygons_from_cnts(artefact_cnts)
             if args.filter_artefacts and art:
                 hit = np.zeros(len(keep), bool)
@@ -564,10 +653,18 @@ def main(args, spawned: bool = False, parser_factory=None):
         mp.start_processes(_spawn_entry, args=(len(devices), port, _args_dict(args), ids),
                            nprocs=len(devices), start_method="spawn")
         return
+    hostinfo.limit_torch_threads()
     rank, world, local = parallel.init_distributed()
     device = torch.device("cuda", local) if world > 1 else \
         (devices[0] if devices[0].index is not None else torch.device("cuda", 0))
+    t_main = time.time()
+    try:
+        import psutil
+        t_proc = psutil.Process().create_time()                   # interpreter start: the imports lie between it and here
+    except Exception:                                             # noqa: BLE001
+        t_proc = t_main
     cells, xy, labels, plan = run_rank(args, rank, world, device)
+    t_loop_end = time.time()
     tiles = plan.cell_tiles
     if world > 1:
         n_local = len(cells)
@@ -575,8 +672,13 @@ def main(args, spawned: bool = False, parser_factory=None):
         logger.info(f"[rank {rank}] exchange over {torch.distributed.get_backend()}: {n_local} local cells -> {len(cells)} cell rows on "
                     f"every rank; vertex pool {'%d vertices on rank 0' % len(xy) if xy is not None else 'sent to rank 0'}")
     if rank == 0:
+        t_gather = time.time()
         cells, xy = canonical_cell_order(cells, xy, tiles)
         write_outputs(args, cells, xy, labels, plan, device)
+        t_end = time.time()
+        logger.info(f"wall (s): process start -> main {t_main - t_proc:.1f} (imports), main -> end of this rank's tile loop "
+                    f"{t_loop_end - t_main:.1f}, exchange {t_gather - t_loop_end:.1f}, rank-0 tail (order, de-duplication, filters, files) "
+                    f"{t_end - t_gather:.1f}; total {t_end - t_proc:.1f}")
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -70,7 +70,12 @@ class ModelConfig(BaseModel):
         """torch.load of the checkpoint, or the synthetic stand-in with the same key layout."""
         import torch
         if Path(self.path).exists():
-            return torch.load(self.path, map_location="cpu", weights_only=True)
+            # mmap: the tensors are paged in as NetWeights.from_state_dict converts them (on a background thread of the CLI), not read
+            # up front -- a ViT-L checkpoint is 1.2 GB of float32
+            try:
+                return torch.load(self.path, map_location="cpu", weights_only=True, mmap=True)
+            except (RuntimeError, ValueError):          # legacy (non-zipfile) checkpoints cannot be mapped
+                return torch.load(self.path, map_location="cpu", weights_only=True)
         from .synth import make_state_dict
         d = int(os.getenv("CLASSPOSE_SYNTHETIC_DEPTH", depth or 24))
         return make_state_dict(len(self.cell_types) + 1, None, depth=d, seed=0)
