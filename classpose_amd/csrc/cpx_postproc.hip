@@ -1298,23 +1298,51 @@ __device__ __forceinline__ void tail_rank(int vmax, const int *first, int *remap
     __shared__ int s_first[TAIL_LDS];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
-    const bool lds = vmax < TAIL_LDS;
-    int *tab = lds ? s_first : scratch;                      // (scratch: the stage's unused `rank` table, any tile size)
-    for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
-        int f = ld_agent(&first[v]);
-        if (f != 0x7FFFFFFF && removed(v)) f = 0x7FFFFFFF;
-        if (lds) tab[v] = f; else atomicExch(&tab[v], f);
-    }
-    __syncthreads();
     int kept = 0;
-    for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
-        const int f = lds ? tab[v] : ld_agent(&tab[v]);
-        if (f == 0x7FFFFFFF) { remap[v] = 0; continue; }
-        int r = 1;
-        if (lds) { for (int j = 1; j <= vmax; ++j) r += tab[j] < f; }
-        else { for (int j = 1; j <= vmax; ++j) r += ld_agent(&tab[j]) < f; }
-        remap[v] = r;
-        ++kept;
+    if (vmax < TAIL_LDS) {
+        for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+            int f = ld_agent(&first[v]);
+            if (f != 0x7FFFFFFF && removed(v)) f = 0x7FFFFFFF;
+            s_first[v] = f;
+        }
+        __syncthreads();
+        for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+            const int f = s_first[v];
+            if (f == 0x7FFFFFFF) { remap[v] = 0; continue; }
+            int r = 1;
+            for (int j = 1; j <= vmax; ++j) r += s_first[j] < f;
+            remap[v] = r;
+            ++kept;
+        }
+    } else {
+        // more labels than the LDS copy holds (dense 512 / 1024-px tiles): the table is ranked against itself chunk by chunk THROUGH the
+        // LDS -- thread-private partial ranks accumulate in remap[], each label is written and re-read by its own thread only.  (Until
+        // round 5 this path compared every label with every other by agent-scope loads from global memory: ~vmax^2 / 256 uncached loads
+        // per thread, tens of milliseconds for 20 000 labels.)  `scratch` (the stage's unused rank table) holds the filtered first[].
+        for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+            int f = ld_agent(&first[v]);
+            if (f != 0x7FFFFFFF && removed(v)) f = 0x7FFFFFFF;
+            scratch[v] = f;                              // read back by this thread (own store) and, through the LDS chunks, by the others
+            remap[v] = f == 0x7FFFFFFF ? 0 : 1;
+        }
+        for (int base = 1; base <= vmax; base += TAIL_LDS) {
+            const int n = min(TAIL_LDS, vmax - base + 1);
+            __syncthreads();                             // the previous chunk has been read by everybody
+            for (int j = (int)threadIdx.x; j < n; j += NTHR) {
+                int f = ld_agent(&first[base + j]);      // (re-derived rather than read from scratch[]: written there by ANOTHER thread)
+                if (f != 0x7FFFFFFF && removed(base + j)) f = 0x7FFFFFFF;
+                s_first[j] = f;
+            }
+            __syncthreads();
+            for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+                const int f = scratch[v];
+                if (f == 0x7FFFFFFF) continue;
+                int r = 0;
+                for (int j = 0; j < n; ++j) r += s_first[j] < f;
+                remap[v] += r;
+            }
+        }
+        for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) kept += scratch[v] != 0x7FFFFFFF;
     }
     if (kept) atomicAdd(&s_n, kept);
     __syncthreads();
@@ -1801,7 +1829,7 @@ extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks,
     return CPX_OK;
 }
 
-CPX_SWITCH(g_pp_fused, 1);          // 1 = the 16-launch fused chain (production), 0 = the stage-wise sequence (38 launches; A/B)
+CPX_SWITCH(g_pp_fused, 1);          // 1 = the 22-launch fused chain (production; the 16-launch ticket form was measured and abandoned, see above), 0 = the stage-wise sequence (38 launches; A/B)
 #ifdef CPX_DEBUG
 extern "C" void cpx_postproc_set_fused(int on) { g_pp_fused = on; }
 #endif
