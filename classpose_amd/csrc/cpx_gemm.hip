@@ -1645,7 +1645,10 @@ CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of th
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
-CPX_SWITCH(g_gemm_4w, 1);           // 1 = mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel (cpx_gemm4w.hip), 0 = on k_gemm256p; same bits
+CPX_SWITCH(g_gemm_4w, 1);           // bit 0 (production): mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel (cpx_gemm4w.hip), 0.98 of k_gemm256p;
+                                    // bit 1 (debug build, measured and NOT shipped): attn.proj / mlp.lin2 (residual + row statistics) on it as well -- 1.06 / 1.03 of
+                                    // k_gemm256p (profiles/r05_ab_gemm4w_resid.txt): that epilogue is unpacked integer / f32 vector work, which a lone wave issues at
+                                    // 4 cycles per instruction against 2.9 for two waves of a SIMD.  Same bits either way.
 CPX_SWITCH(g_gemm_pp, 0);           // 1 = ping-pong kernel (256 x 128 tiles, two 4-wave workgroups per CU) for the epilogues it covers
 CPX_SWITCH(g_gemm_pp_persist, 1);   // ping-pong kernel: 1 = two persistent workgroups per CU walk the tiles, 0 = one workgroup per tile
 CPX_SWITCH(g_gemm_pp_delay, 2);     // ping-pong kernel: start offset of a CU's second workgroup, x s_sleep 127 (~8k cycles)
@@ -1799,8 +1802,15 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
             // mlp.lin1 of the bf16 network (folded LayerNorm + bias + erf-GELU) on the one-wave-per-SIMD kernel: bitwise equal to the
             // k_gemm256p instantiation below, its main loop and its epilogue both faster (profiles/r05_ab_gemm4w_*.txt)
             if constexpr (EPI == CPX_EPI_GELU_BF16 && !F16) {
-                if (g_gemm_4w && f1 && a.bias && a.K >= 256 && (a.K / 64) % 2 == 0 &&
+                if ((g_gemm_4w & 1) && f1 && a.bias && a.K >= 256 && (a.K / 64) % 2 == 0 &&
                     cpx_gemm4w_gelu_ln(a.A, a.W, a.M, a.N, a.K, a.bias, a.ln_stats, a.ln_colsum, a.out, a.ld_out, s))
+                    return true;
+            }
+            // attn.proj / mlp.lin2 of the bf16 network (residual + row statistics, N = 1024) on that kernel: bitwise equal to k_gemm256p<.., F1 | G2F_BAL>
+            // and 3 - 6 % SLOWER, so only the debug build's cpx_gemm_set_4w(3) takes this branch (g_gemm_4w is the constant 1 in the product)
+            if constexpr (EPI == CPX_EPI_RESID_BF16 && !F16) {
+                if ((g_gemm_4w & 2) && f1 && a.bias && a.aux && a.N == 1024 && a.K >= 256 && (a.K / 64) % 2 == 0 &&
+                    cpx_gemm4w_resid_stats(a.A, a.W, a.M, a.N, a.K, a.bias, a.aux, a.out, a.ld_out, a.stats_out, s))
                     return true;
             }
             // direct-store epilogue (G2F_DIRECT): production for the GELU epilogue (mlp.lin1 -3.5 %, bitwise equal); the lighter epilogues

@@ -51,10 +51,13 @@ struct Gemm4wArgs {
     const unsigned short *A, *W;
     const float *bias, *ln_stats, *ln_colsum;     // ln_*: folded LayerNorm of the K = 1024 input rows (G4_EPI_GELU_LN), as in cpx_gemm.hip
     unsigned short *out;
+    const unsigned short *resid;                  // G4_EPI_RESID_STATS: residual rows [M][ld_out] (may be `out` itself: every lane reads its 16 bytes before it writes them)
+    float *stats_out;                             // G4_EPI_RESID_STATS: [M][4][2] partial (sum, sum of squares) of the OUTPUT rows, slot = column tile (N = 1024)
     int M, N, K, ld_out, tiles_n, n_blocks;
 };
 #define G4_EPI_BIAS 0
 #define G4_EPI_GELU_LN 1
+#define G4_EPI_RESID_STATS 2
 
 template <int OFF>
 __device__ __forceinline__ u32x4 g4_read128(unsigned addr) {
@@ -64,6 +67,27 @@ __device__ __forceinline__ u32x4 g4_read128(unsigned addr) {
 }
 #define G4_SB() __builtin_amdgcn_sched_barrier(0)
 #define G4_LDSP(p) ((__attribute__((address_space(3))) void *)(p))
+
+// a 16-byte buffer load the COMPILER does not see as a load (with an LDS-DMA in flight hipcc waits vmcnt(0) in front of the first use of any
+// ordinary load): the caller waits with g4_vmwait<N>, which carries the destinations as "+v" operands so that no consumer can move in front
+__device__ __forceinline__ u32x4 g4_load128(u32x4 rsrc, unsigned voff, unsigned soff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void g4_vmwait(u32x4 (&r)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N) : "memory");
+}
+// x + (x of the lane 32 / 16 lanes away): v_permlane32_swap / v_permlane16_swap on two copies leave (lo, lo) and (hi, hi) halves / row pairs
+__device__ __forceinline__ float g4_add_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float g4_add_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 // erf-GELU of cpx_gemm.hip (gelu_erf: max(x, 0) - |x| 2^P5(|x|)) on two values: the polynomial as v_pk_fma_f32, the rest per value
 __device__ __forceinline__ f32x2_t g4_gelu2(f32x2_t x) {
@@ -86,6 +110,9 @@ template <int EPI, int VAR>
 __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_gemm4w(Gemm4wArgs g) {
     constexpr bool LN = EPI == G4_EPI_GELU_LN;
     constexpr bool SPLIT = !(VAR & 128);
+    // the residual epilogue needs the registers of the next tile's first two fragment sets (8 + 8 residual rows in flight beside the
+    // statistics): its last K tile reads nothing ahead, the sets are read behind the epilogue like in the prologue (~300 cycles per tile)
+    constexpr bool LATE_FRAGS = EPI == G4_EPI_RESID_STATS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,18 +202,18 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
     { if (VAR & 32) { asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(lds0 + (unsigned)tid * 16u), "v"(SG[J]), "n"((J) * 4096) : "memory"); G4_SB(); } \
       else if (VAR & 16) { asm volatile("" :: "v"(SG[J])); G4_SB(); } }
 // second half, row block I: 8 MFMAs on the k-substep-1 set, one fragment read of K tile t + 1 behind every second, the W request behind the last
-#define G4_H2ROW(I, BX, BW, R0, R1, R2, R3, B, RQW)                                                             \
+#define G4_H2ROW(I, BX, BW, R0, R1, R2, R3, B, RQW, SKIPRD)                                                             \
     {                                                                                                           \
-        G4_MM(I, 0, BX, BW, false) G4_WRS(2 * (I)) G4_MM(I, 1, BX, BW, false) R0;                               \
-        G4_MM(I, 2, BX, BW, false) G4_MM(I, 3, BX, BW, false) R1;                                               \
-        G4_MM(I, 4, BX, BW, false) G4_WRS(2 * (I) + 1) G4_MM(I, 5, BX, BW, false) R2;                           \
-        G4_MM(I, 6, BX, BW, false) G4_MM(I, 7, BX, BW, false) R3; G4_SB();                                      \
+        G4_MM(I, 0, BX, BW, false) G4_WRS(2 * (I)) G4_MM(I, 1, BX, BW, false) if (!(SKIPRD)) R0;                \
+        G4_MM(I, 2, BX, BW, false) G4_MM(I, 3, BX, BW, false) if (!(SKIPRD)) R1;                                \
+        G4_MM(I, 4, BX, BW, false) G4_WRS(2 * (I) + 1) G4_MM(I, 5, BX, BW, false) if (!(SKIPRD)) R2;            \
+        G4_MM(I, 6, BX, BW, false) G4_MM(I, 7, BX, BW, false) if (!(SKIPRD)) R3; G4_SB();                       \
         if (SPLIT) G4_DMAW(B, I, RQW)                                                                           \
     }
 #define G4_RW(F, KS, NB_, I) { if (!(VAR & 2)) F[I] = g4_read128<(I) * 2048>(wa[NB_][KS]); }
 #define G4_RX(F, KS, NB_, I) { if (!(VAR & 2)) F[I] = g4_read128<(I) * 2048>(xa[NB_][KS]); }
 // K tile in buffer B: (BX, BW) = its k-substep-1 set, (NX, NW) = the set that receives k-substep 1 of the following K tile (buffer B ^ 1)
-#define G4_KTILE(B, FIRST, BX, BW, NX, NW, RQX, RQW)                                                            \
+#define G4_KTILE(B, FIRST, BX, BW, NX, NW, RQX, RQW, SKIPRD)                                                            \
     {                                                                                                           \
         G4_H1ROW(B, FIRST, 0, RQX, RQW) G4_H1ROW(B, FIRST, 1, RQX, RQW) G4_H1ROW(B, FIRST, 2, RQX, RQW) G4_H1ROW(B, FIRST, 3, RQX, RQW) \
         G4_H1ROW(B, FIRST, 4, RQX, RQW) G4_H1ROW(B, FIRST, 5, RQX, RQW) G4_H1ROW(B, FIRST, 6, RQX, RQW) G4_H1ROW(B, FIRST, 7, RQX, RQW) \
@@ -194,14 +221,14 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
         if (SPLIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* the following K tile has landed (mine) */ \
         if (!(VAR & 4)) __builtin_amdgcn_s_barrier();                /* ... and everybody's */                  \
         G4_SB();                                                                                                \
-        G4_H2ROW(0, BX, BW, G4_RW(PW, 0, (B) ^ 1, 0), G4_RW(PW, 0, (B) ^ 1, 1), G4_RW(PW, 0, (B) ^ 1, 2), G4_RW(PW, 0, (B) ^ 1, 3), B, RQW) \
-        G4_H2ROW(1, BX, BW, G4_RW(PW, 0, (B) ^ 1, 4), G4_RW(PW, 0, (B) ^ 1, 5), G4_RW(PW, 0, (B) ^ 1, 6), G4_RW(PW, 0, (B) ^ 1, 7), B, RQW) \
-        G4_H2ROW(2, BX, BW, G4_RX(PX, 0, (B) ^ 1, 0), G4_RX(PX, 0, (B) ^ 1, 1), G4_RX(PX, 0, (B) ^ 1, 2), G4_RX(PX, 0, (B) ^ 1, 3), B, RQW) \
-        G4_H2ROW(3, BX, BW, G4_RX(PX, 0, (B) ^ 1, 4), G4_RX(PX, 0, (B) ^ 1, 5), G4_RX(PX, 0, (B) ^ 1, 6), G4_RX(PX, 0, (B) ^ 1, 7), B, RQW) \
-        G4_H2ROW(4, BX, BW, G4_RW(NW, 1, (B) ^ 1, 0), G4_RW(NW, 1, (B) ^ 1, 1), G4_RW(NW, 1, (B) ^ 1, 2), G4_RW(NW, 1, (B) ^ 1, 3), B, RQW) \
-        G4_H2ROW(5, BX, BW, G4_RW(NW, 1, (B) ^ 1, 4), G4_RW(NW, 1, (B) ^ 1, 5), G4_RW(NW, 1, (B) ^ 1, 6), G4_RW(NW, 1, (B) ^ 1, 7), B, RQW) \
-        G4_H2ROW(6, BX, BW, G4_RX(NX, 1, (B) ^ 1, 0), G4_RX(NX, 1, (B) ^ 1, 1), G4_RX(NX, 1, (B) ^ 1, 2), G4_RX(NX, 1, (B) ^ 1, 3), B, RQW) \
-        G4_H2ROW(7, BX, BW, G4_RX(NX, 1, (B) ^ 1, 4), G4_RX(NX, 1, (B) ^ 1, 5), G4_RX(NX, 1, (B) ^ 1, 6), G4_RX(NX, 1, (B) ^ 1, 7), B, RQW) \
+        G4_H2ROW(0, BX, BW, G4_RW(PW, 0, (B) ^ 1, 0), G4_RW(PW, 0, (B) ^ 1, 1), G4_RW(PW, 0, (B) ^ 1, 2), G4_RW(PW, 0, (B) ^ 1, 3), B, RQW, SKIPRD) \
+        G4_H2ROW(1, BX, BW, G4_RW(PW, 0, (B) ^ 1, 4), G4_RW(PW, 0, (B) ^ 1, 5), G4_RW(PW, 0, (B) ^ 1, 6), G4_RW(PW, 0, (B) ^ 1, 7), B, RQW, SKIPRD) \
+        G4_H2ROW(2, BX, BW, G4_RX(PX, 0, (B) ^ 1, 0), G4_RX(PX, 0, (B) ^ 1, 1), G4_RX(PX, 0, (B) ^ 1, 2), G4_RX(PX, 0, (B) ^ 1, 3), B, RQW, SKIPRD) \
+        G4_H2ROW(3, BX, BW, G4_RX(PX, 0, (B) ^ 1, 4), G4_RX(PX, 0, (B) ^ 1, 5), G4_RX(PX, 0, (B) ^ 1, 6), G4_RX(PX, 0, (B) ^ 1, 7), B, RQW, SKIPRD) \
+        G4_H2ROW(4, BX, BW, G4_RW(NW, 1, (B) ^ 1, 0), G4_RW(NW, 1, (B) ^ 1, 1), G4_RW(NW, 1, (B) ^ 1, 2), G4_RW(NW, 1, (B) ^ 1, 3), B, RQW, SKIPRD) \
+        G4_H2ROW(5, BX, BW, G4_RW(NW, 1, (B) ^ 1, 4), G4_RW(NW, 1, (B) ^ 1, 5), G4_RW(NW, 1, (B) ^ 1, 6), G4_RW(NW, 1, (B) ^ 1, 7), B, RQW, SKIPRD) \
+        G4_H2ROW(6, BX, BW, G4_RX(NX, 1, (B) ^ 1, 0), G4_RX(NX, 1, (B) ^ 1, 1), G4_RX(NX, 1, (B) ^ 1, 2), G4_RX(NX, 1, (B) ^ 1, 3), B, RQW, SKIPRD) \
+        G4_H2ROW(7, BX, BW, G4_RX(NX, 1, (B) ^ 1, 4), G4_RX(NX, 1, (B) ^ 1, 5), G4_RX(NX, 1, (B) ^ 1, 6), G4_RX(NX, 1, (B) ^ 1, 7), B, RQW, SKIPRD) \
         G4_KEEP(BX, BW)                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           /* my reads of buffer B ^ 1 are done */    \
         G4_SB();                                                                                                \
@@ -248,15 +275,15 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
         // must stream it together, it does not stay in the L2 between them)
         const int rot = (VAR & 64) ? (int)((blockIdx.x >> 3) * 5 + (blockIdx.x & 7) * 2) : 0;
 #define kofs(t) ((VAR & 64) ? (unsigned)(((t) + rot) & (nk - 1)) * 128u : (unsigned)(t) * 128u)
-        G4_KTILE(0, true, QX, QW, RX, RW, sX + kofs(2), sW + kofs(2))
-        G4_KTILE(1, false, RX, RW, QX, QW, sX + kofs(3), sW + kofs(3))
+        G4_KTILE(0, true, QX, QW, RX, RW, sX + kofs(2), sW + kofs(2), false)
+        G4_KTILE(1, false, RX, RW, QX, QW, sX + kofs(3), sW + kofs(3), false)
         for (int t = 2; t + 2 < nk; t += 2) {
             const unsigned kb = kofs(t + 2), kb1 = kofs(t + 3);
-            G4_KTILE(0, false, QX, QW, RX, RW, sX + kb, sW + kb)
-            G4_KTILE(1, false, RX, RW, QX, QW, sX + kb1, sW + kb1)
+            G4_KTILE(0, false, QX, QW, RX, RW, sX + kb, sW + kb, false)
+            G4_KTILE(1, false, RX, RW, QX, QW, sX + kb1, sW + kb1, false)
         }
-        G4_KTILE(0, false, QX, QW, RX, RW, sXn + kofs(0), sWn + kofs(0))
-        G4_KTILE(1, false, RX, RW, QX, QW, sXn + kofs(1), sWn + kofs(1))
+        G4_KTILE(0, false, QX, QW, RX, RW, sXn + kofs(0), sWn + kofs(0), false)
+        G4_KTILE(1, false, RX, RW, QX, QW, sXn + kofs(1), sWn + kofs(1), LATE_FRAGS)
 #undef kofs
         // the last inline-asm MFMAs' results: the compiler does not see the MFMA -> v_accvgpr_read hazard ...
         G4_SB();
@@ -266,6 +293,96 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
         // takes 16 cycles.  (One redefinition of all 64 in front of the epilogue made the allocator copy half of them into VGPRs at once --
         // with the next tile's two fragment sets live that spilled six fragments, stored to scratch straight behind their asynchronous LDS reads.)
         G4_SB();
+        if constexpr (EPI == G4_EPI_RESID_STATS) {
+            // ---- residual epilogue with row statistics (attn.proj, mlp.lin2): out = bf16(bf16(acc + bias) + residual) -- the reference's double
+            // rounding -- and the partial LayerNorm statistics of the ROUNDED output row over this tile's 256 columns, bit for bit those of
+            // k_gemm256p's staged epilogue: per 16-byte chunk s = (((0 + (l0 + h0)) + (l1 + h1)) + (l2 + h2)) + (l3 + h3), q = ((q0 + q1) +
+            // q2) + q3 with qi = fma(li, li, hi hi); then its balanced tree over the row's 32 chunks -- here: lane rows (fq 0, 2) and (1, 3) [one
+            // v_permlane32_swap + one v_permlane16_swap per value], the four channel-block pairs in registers, the two wave columns through LDS.
+            // The residual rows are 16-byte loads at the addresses the stores go to, requested one block pair (8 loads) ahead by inline asm.
+            const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc((void *)g.out, 0, 0x7FFFFFFF, 0x00020000);
+            const unsigned long long ra = (unsigned long long)(size_t)g.resid;
+            const u32x4 rsrcR = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ra >> 32)) & 0xFFFFu,
+                                 0x7FFFFFFFu, 0x00020000u};
+            const unsigned ldb = (unsigned)g.ld_out * 2u;
+            const unsigned ovoff = (unsigned)(wm * 128 + fr) * ldb + (unsigned)(wn * 128 + ((fq & 1) << 4) + ((fq >> 1) << 3)) * 2u;
+            const unsigned so0 = (unsigned)m0 * ldb + (unsigned)n0 * 2u;
+            const unsigned tb = lds0 + G4_TAIL_BIAS + (unsigned)(wn * 128 + fq * 4) * 4u;
+            u32x4 RA[8], RB[8];
+            float q_sm[8], q_sq[8], h_sm[8], h_sq[8];          // per row block: the previous pair's quad sum, the first half's 8-chunk sum
+#define G4_RLOAD(R, NP) { _Pragma("unroll") for (int mb = 0; mb < 8; ++mb) R[mb] = g4_load128(rsrcR, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)(NP) * 64u); }
+#define G4_RPAIR(NP, R)                                                                                                          \
+            {                                                                                                                    \
+                u32x4 b0u, b1u;                                                                                                  \
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"          \
+                             : "=&v"(b0u), "=&v"(b1u) : "v"(tb), "n"((2 * (NP)) * 64), "n"((2 * (NP) + 1) * 64));               \
+                const f32x4 b0 = __builtin_bit_cast(f32x4, b0u), b1 = __builtin_bit_cast(f32x4, b1u);                            \
+                _Pragma("unroll") for (int mb = 0; mb < 8; ++mb) {                                                               \
+                    asm volatile("" : "+a"(acc[mb][2 * (NP)]), "+a"(acc[mb][2 * (NP) + 1]));                                     \
+                    const f32x4 v0 = acc[mb][2 * (NP)], v1 = acc[mb][2 * (NP) + 1];                                              \
+                    const f32x2_t p00 = {v0[0] + b0[0], v0[1] + b0[1]}, p01 = {v0[2] + b0[2], v0[3] + b0[3]};                    \
+                    const f32x2_t p10 = {v1[0] + b1[0], v1[1] + b1[1]}, p11 = {v1[2] + b1[2], v1[3] + b1[3]};                    \
+                    const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p00, bf16x2_t)), a1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2_t)); \
+                    const unsigned e0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p10, bf16x2_t)), e1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p11, bf16x2_t)); \
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);                                      \
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);                                      \
+                    const unsigned first[4] = {r0[0], r1[0], r0[1], r1[1]};              /* bf16(acc + bias): 8 consecutive channels */ \
+                    const u32x4 rr = R[mb];                                                                                      \
+                    u32x4 o;                                                                                                     \
+                    float sm = 0.f, sq = 0.f;                                                                                    \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+                        const float lo = __fadd_rn(__uint_as_float(first[i] << 16), __uint_as_float(rr[i] << 16));               \
+                        const float hi = __fadd_rn(__uint_as_float(first[i] & 0xFFFF0000u), __uint_as_float(rr[i] & 0xFFFF0000u)); \
+                        const f32x2_t lh = {lo, hi};                                                                             \
+                        o[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(lh, bf16x2_t));                              \
+                        const float l = __uint_as_float(o[i] << 16), h = __uint_as_float(o[i] & 0xFFFF0000u);                    \
+                        sm = __fadd_rn(sm, __fadd_rn(l, h));                                                                     \
+                        const float qi = __fmaf_rn(l, l, __fmul_rn(h, h));                                                       \
+                        sq = i == 0 ? qi : __fadd_rn(sq, qi);                                                                    \
+                    }                                                                                                            \
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)(NP) * 64u, 0); \
+                    /* the quad of four chunks this pair holds across the lane rows: (fq 0 + fq 2) + (fq 1 + fq 3) */            \
+                    const float qs = g4_add_xor16(g4_add_xor32(sm)), qq = g4_add_xor16(g4_add_xor32(sq));                        \
+                    if ((NP) == 0 || (NP) == 2) { q_sm[mb] = qs; q_sq[mb] = qq; }                                                \
+                    else if ((NP) == 1) { h_sm[mb] = __fadd_rn(q_sm[mb], qs); h_sq[mb] = __fadd_rn(q_sq[mb], qq); }              \
+                    else {                                       /* this wave's 16 chunks: (Q0 + Q1) + (Q2 + Q3) */              \
+                        const float s16 = __fadd_rn(h_sm[mb], __fadd_rn(q_sm[mb], qs)), q16 = __fadd_rn(h_sq[mb], __fadd_rn(q_sq[mb], qq)); \
+                        if (fq == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(lds0 + G4_TAIL + (unsigned)(((wm * 128 + mb * 16 + fr) * 2 + wn) * 8)), "v"((f32x2_t){s16, q16}) : "memory"); \
+                    }                                                                                                            \
+                    G4_SB();                                                                                                     \
+                }                                                                                                                \
+            }
+            G4_RLOAD(RA, 0)
+            G4_RLOAD(RB, 1)
+            g4_vmwait<8>(RA);  G4_SB();
+            G4_RPAIR(0, RA)
+            G4_RLOAD(RA, 2)
+            g4_vmwait<16>(RB); G4_SB();
+            G4_RPAIR(1, RB)
+            G4_RLOAD(RB, 3)
+            g4_vmwait<16>(RA); G4_SB();
+            G4_RPAIR(2, RA)
+            g4_vmwait<8>(RB);  G4_SB();
+            G4_RPAIR(3, RB)
+#undef G4_RLOAD
+#undef G4_RPAIR
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G4_SB();
+            __builtin_amdgcn_s_barrier();                        // both wave columns have parked their 128-column sums
+            G4_SB();
+            if (wn == 0) {                                       // 128 rows of this wave row, two per lane: total = (columns 128..255) + (columns 0..127)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = wm * 128 + h * 64 + lane;
+                    u32x4 pr;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pr) : "v"(lds0 + G4_TAIL + (unsigned)(row * 16)));
+                    const f32x4 pv = __builtin_bit_cast(f32x4, pr);               // (sum, sq) of wave column 0, (sum, sq) of wave column 1
+                    float2 tot;
+                    tot.x = __fadd_rn(pv[2], pv[0]); tot.y = __fadd_rn(pv[3], pv[1]);
+                    *reinterpret_cast<float2 *>(g.stats_out + ((size_t)(m0 + row) * 4 + (n0 >> 8)) * 2) = tot;
+                }
+            }
+        } else
         // ---- epilogue: [folded LayerNorm +] bias [+ GELU], one conversion per pair, lane rows swapped into 16-byte pieces, buffer stores (the
         // direct-store epilogue of k_gemm256p).  Every LDS read of the tail is inline asm: an ordinary one makes hipcc drain the request queue
         {
@@ -332,7 +449,16 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
         G4_SB();
-        __builtin_amdgcn_s_barrier();                                            // everybody has read the tail: the next tile's vectors may land in it
+        if constexpr (LATE_FRAGS) {
+            // K tile 0 of the next tile (buffer 0) landed before the mid barrier of the last K tile
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { PW[i] = g4_read128<0>(wa[0][0] + i * 2048); PX[i] = g4_read128<0>(xa[0][0] + i * 2048); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { QW[i] = g4_read128<0>(wa[0][1] + i * 2048); QX[i] = g4_read128<0>(xa[0][1] + i * 2048); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G4_SB();
+        }
+        __builtin_amdgcn_s_barrier();                                            // everybody has read the tail [and buffer 0]: the next tile's vectors / requests may land
         G4_SB();
         if (!has_next) break;
         v = vn; m0 = m0n; n0 = n0n;
@@ -379,8 +505,22 @@ int cpx_gemm4w_gelu_ln(const void *A, const void *W, int M, int N, int K, const 
     if (!g4_shape_ok(M, N, K, ld_out) || !bias || !ln_stats || !ln_colsum) return 0;
     Gemm4wArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = ln_stats; a.ln_colsum = ln_colsum;
-    a.out = (unsigned short *)out; a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
+    a.out = (unsigned short *)out; a.resid = nullptr; a.stats_out = nullptr;
+    a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
     g4_launch<G4_EPI_GELU_LN, 0>(a, s);
+    return 1;
+}
+
+// attn.proj / mlp.lin2 of the bf16 network: out = bf16(bf16(A W^T + bias) + resid) and the row statistics of out (N = 1024: 4 column tiles = the
+// 4 slots).  Returns 1 when launched, 0 when the shape is not this kernel's.
+int cpx_gemm4w_resid_stats(const void *A, const void *W, int M, int N, int K, const float *bias, const void *resid, void *out, int ld_out,
+                           float *stats_out, hipStream_t s) {
+    if (!g4_shape_ok(M, N, K, ld_out) || !bias || !resid || !stats_out || N != 1024) return 0;
+    Gemm4wArgs a;
+    a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = nullptr; a.ln_colsum = nullptr;
+    a.out = (unsigned short *)out; a.resid = (const unsigned short *)resid; a.stats_out = stats_out;
+    a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
+    g4_launch<G4_EPI_RESID_STATS, 0>(a, s);
     return 1;
 }
 
@@ -392,7 +532,8 @@ extern "C" int cpx_gemm4w(const void *A, const void *W, int M, int N, int K, con
     if (!g4_shape_ok(M, N, K, ld_out) || !bias) return CPX_EINVAL;
     Gemm4wArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = nullptr; a.ln_colsum = nullptr;
-    a.out = (unsigned short *)out; a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
+    a.out = (unsigned short *)out; a.resid = nullptr; a.stats_out = nullptr;
+    a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
     hipStream_t s = (hipStream_t)stream;
     switch (g_gemm4w_var) {
         case 1: g4_launch<G4_EPI_BIAS, 1>(a, s); break;

@@ -59,6 +59,9 @@ int cpx_gemm_half_uses_big_tile(int M, int N, int K, int epilogue);
 // one-wave-per-SIMD 256^2 kernel (cpx_gemm4w.hip), bf16: gelu(folded-LayerNorm(A) W^T + bias); 1 = launched, 0 = not this kernel's shape
 int cpx_gemm4w_gelu_ln(const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
                        void *out, int ld_out, hipStream_t s);
+// ... and bf16(bf16(A W^T + bias) + resid) with the partial row statistics of the output (N = 1024); resid may be out
+int cpx_gemm4w_resid_stats(const void *A, const void *W, int M, int N, int K, const float *bias, const void *resid, void *out, int ld_out,
+                           float *stats_out, hipStream_t s);
 int cpx_layernorm_half(int dtype, const void *x, const float *w, const float *b, int rows, int C, float eps,
                        void *out, void *stream);
 int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void *rel_w, int n_subtiles, void *vT_ws,

@@ -26,7 +26,7 @@ void cpx_gemm_set_reverse(int on);          /* 0 (default): mlp.lin2 walks M bac
 void cpx_gemm_set_direct(int mode);         /* 1 (default): direct-store epilogue of the persistent 256^2 kernel (accumulators -> v_permlane16_swap -> 16-byte buffer stores, no LDS staging) for the GELU epilogue; 2: for every non-residual epilogue; 0: staged rows */
 void cpx_gemm_set_balanced(int on);         /* 1 (default): balanced fragment-read schedule of the persistent 256^2 main loop for the bf16 residual + row-statistics epilogue (proj, mlp.lin2); 0: plain schedule */
 int cpx_gemm4w(const void *A, const void *W, int M, int N, int K, const float *bias, void *out, int ld_out, void *stream);   /* the 256^2 GEMM tile with ONE wave per SIMD (4 waves x 128 x 128, AGPR accumulators), persistent, bias epilogue, bf16 (csrc/cpx_gemm4w.hip) */
-void cpx_gemm_set_4w(int on);               /* 1 (default): mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel; 0: on the 8-wave persistent kernel (same bits) */
+void cpx_gemm_set_4w(int mask);             /* 1 (default): mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel; +2: attn.proj / mlp.lin2 (residual + statistics) too (slower, not shipped); 0: everything on the 8-wave persistent kernel (same bits) */
 void cpx_gemm4w_set_variant(int v);         /* experiment switches of cpx_gemm4w (0 default) */
 void cpx_gemm_set_split(int on);            /* 0 (default): 1 = counted LDS waits inside the main-loop phases of the persistent 256^2 kernel (experiment) */
 void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */

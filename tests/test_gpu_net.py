@@ -236,6 +236,39 @@ def test_gemm_lin1_one_wave_per_simd_equals_the_eight_wave_kernel(cuda, M, N):
     assert _rel(prod[:512].float(), ref) < 6e-3
 
 
+@pytest.mark.parametrize("M,K", [(65536, 256), (65536, 1024), (131072, 512), (65536, 4096)])
+def test_gemm_resid_stats_one_wave_per_simd_equals_the_eight_wave_kernel(cuda, M, K):
+    """PRODUCTION attn.proj / mlp.lin2 (bf16: bias, residual add with the reference's double rounding, partial LayerNorm statistics of the
+    output rows) on csrc/cpx_gemm4w.hip against k_gemm256p<RESID, STATS | BAL> (cpx_gemm_set_4w(0), debug build): outputs AND statistics bit
+    for bit -- the 32-chunk summation tree of the staged epilogue is rebuilt from lane-row swaps, registers and one LDS hand-over --, one
+    and two tiles per workgroup, K = 256 (only the peeled K tiles run) to 4096, and in place (out == residual, as the engine calls it)."""
+    N = 1024
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = (torch.randn(M, N, generator=g) * 2).to(torch.bfloat16).to(cuda)
+    prod, pst = ops.gemm_ln(A, W, "resid", bias, res, want_stats=True)
+    with _lib.use_debug_library() as L:
+        try:
+            L.cpx_gemm_set_4w(3)
+            four, fst = ops.gemm_ln(A, W, "resid", bias, res, want_stats=True)
+            x = res.clone()                                                   # in place
+            st = torch.zeros((M, 4, 2), dtype=torch.float32, device=cuda)
+            _lib.check(L.cpx_gemm_ln(A.data_ptr(), W.data_ptr(), M, N, K, ops.EPI["resid"], bias.data_ptr(), x.data_ptr(), x.data_ptr(), N,
+                                     None, None, st.data_ptr(), torch.cuda.current_stream().cuda_stream), "gemm_ln in place")
+            L.cpx_gemm_set_4w(0)
+            eight, est = ops.gemm_ln(A, W, "resid", bias, res, want_stats=True)
+        finally:
+            L.cpx_gemm_set_4w(3)
+    assert torch.equal(prod, eight) and torch.equal(four, eight) and torch.equal(x, eight)
+    assert torch.equal(pst, est) and torch.equal(fst, est) and torch.equal(st, est)
+    ref = (A[:256].float() @ W.float().T + bias).to(torch.bfloat16).float() + res[:256].float()
+    assert _rel(prod[:256].float(), ref) < 5e-3
+    o = prod.float()
+    assert torch.allclose(pst[:, :, 0].sum(1), o.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(pst[:, :, 1].sum(1), (o * o).sum(1), rtol=1e-4)
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 2048, 1024), (16384, 2048, 256), (32768, 1024, 1024), (24576, 1024, 512)])
 def test_gemm_one_wave_per_simd_prototype_equals_the_production_kernel(cuda, M, N, K):
     """csrc/cpx_gemm4w.hip (debug build): the 256^2 tile with one wave per SIMD (128 x 128 per wave, AGPR accumulators through inline-asm

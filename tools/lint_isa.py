@@ -1,5 +1,5 @@
 """ISA lint of the shipped code objects.  Rule 1: no instruction may read the destination of an LDS load before an `s_waitcnt lgkmcnt(..)`
-that covers it.  Rule 2 (permlane_findings): two wait states between a VALU write and a v_permlane16/32_swap that reads it.  Both are things
+that covers it (rule 4, vmem_findings: the same for inline-asm vector-memory loads and vmcnt in the one-wave-per-SIMD GEMM).  Rule 2 (permlane_findings): two wait states between a VALU write and a v_permlane16/32_swap that reads it.  Both are things
 the compiler guarantees for code it can see and cannot guarantee around inline asm.  Rule 3: no register spill in the persistent GEMM and the
 production attention kernel.
 
@@ -98,12 +98,47 @@ def permlane_findings(sym: str, body: list[str], lib: str) -> list[str]:
     return res
 
 
+RE_VM = re.compile(r"vmcnt\((\d+)\)")
+VMEM_ASM_LOADS = re.compile(r"^_Z\d+k_gemm4wI")          # kernels that load registers through inline asm and wait by hand
+
+
+def vmem_findings(sym: str, body: list[str], lib: str) -> list[str]:
+    """Rule 4 (kernels of VMEM_ASM_LOADS): no instruction reads -- or overwrites -- the destination of a vector-memory load to REGISTERS before
+    an `s_waitcnt vmcnt(N)` that covers it.  The one-wave-per-SIMD GEMM requests its residual rows with inline-asm buffer loads (an ordinary
+    load makes hipcc drain the LDS-DMA queue) and waits with a counted vmcnt that carries the registers as "+v" operands; what the operands
+    cannot forbid is a register COPY the allocator inserts between the load and the wait (seen in round 4's hoist experiment).  Model: every
+    vector-memory instruction (loads, stores, LDS-DMA) enters an in-order queue; vmcnt(N) retires all but the N youngest."""
+    res, queue = [], []
+    for ins in body:
+        if ins == "LABEL" or ins.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_swappc")):
+            queue = []
+            continue
+        mnem, _, ops = ins.partition(" ")
+        if mnem == "s_waitcnt":
+            m = RE_VM.search(ins)
+            if m:
+                n = int(m.group(1))
+                queue = queue[len(queue) - n:] if n else []
+            continue
+        regs = _regs(ops)
+        for bank, lo, hi in regs:                         # any touch of a pending destination, as source or as destination
+            for dest, text in queue:
+                if dest is not None and dest[0] == bank and not (hi < dest[1] or lo > dest[2]) and text != ins:
+                    res.append(f"{lib}: {sym[:70]}: `{ins}` touches the destination of `{text}` before a covering s_waitcnt vmcnt")
+        if mnem.startswith(("buffer_", "global_", "flat_", "scratch_")):
+            is_load_to_regs = "_load" in mnem and " lds" not in ins and ops.lstrip().startswith("v")
+            queue.append((regs[0] if is_load_to_regs and regs else None, ins))
+    return res
+
+
 def findings(so_path: str) -> list[str]:
     res = []
     for sym, body in disassemble(so_path):
         if ALLOW.search(sym):
             continue
         res += permlane_findings(sym, body, os.path.basename(so_path))
+        if VMEM_ASM_LOADS.search(sym):
+            res += vmem_findings(sym, body, os.path.basename(so_path))
         # Rule 3: the persistent GEMM and the production attention kernel pace their LDS-DMA with counted vmcnt waits and live at the edge of
         # the register file; a spill there is legal (extra vector-memory operations only make a counted wait stricter) but costs a drained
         # queue per reload, and the one combination that ever returned wrong numbers (round 4) was one that spilled -- keep them spill-free
