@@ -612,7 +612,7 @@ def post_stage(L, eng, fields0, bt, dev, reps=20):
     ms = sorted(dev_b2b)[reps // 2]
     gbs = POST_BYTES_PER_TILE * bt / (ms * 1e-3) / 1e9
     prof_sum = None
-    for name in ("r04_post_kernel_sum.json", "r03_post_kernel_sum.json"):    # rocprofv3 kernel-time sum of the same chain (tools/r04_profile.sh)
+    for name in ("r05_post_kernel_sum.json", "r04_post_kernel_sum.json", "r03_post_kernel_sum.json"):    # rocprofv3 kernel-time sum of the same chain (tools/r04_profile.sh)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 prof_sum = json.load(f)

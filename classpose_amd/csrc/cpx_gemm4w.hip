@@ -410,42 +410,55 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
                     ln_rs[mb] = rstd; ln_nm[mb] = __fmul_rn(rstd, -mean);
                 }
             }
+            // two channel block pairs (64 channels = the wave's 128 bytes of a token row) per pass over the row blocks, so that the two
+            // 64-byte halves of every 128-byte line leave in consecutive stores (with the pairs as the OUTER loop the halves were 8 stores
+            // apart and the L2 wrote part of the lines back twice: WRITE_SIZE 384 MB per mlp.lin1 launch against 268 MB of output)
 #pragma unroll
-            for (int np = 0; np < 4; ++np) {                                     // channel block pairs (2 np, 2 np + 1): 32 channels
-                u32x4 b0u, b1u, c0u = {0u, 0u, 0u, 0u}, c1u = {0u, 0u, 0u, 0u};
-                if constexpr (LN)
-                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(b0u), "=&v"(b1u), "=&v"(c0u), "=&v"(c1u) : "v"(tb), "n"((2 * np) * 64), "n"((2 * np + 1) * 64), "n"(1024 + (2 * np) * 64), "n"(1024 + (2 * np + 1) * 64));
-                else
-                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(b0u), "=&v"(b1u) : "v"(tb), "n"((2 * np) * 64), "n"((2 * np + 1) * 64));
-                const f32x4 b0 = __builtin_bit_cast(f32x4, b0u), b1 = __builtin_bit_cast(f32x4, b1u);
-                [[maybe_unused]] const f32x4 c0 = __builtin_bit_cast(f32x4, c0u), c1 = __builtin_bit_cast(f32x4, c1u);
+            for (int nph = 0; nph < 2; ++nph) {
+                f32x4 bq[2][2], cq[2][2];                                        // [pair of the pass][block of the pair]: bias, column sums
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) {
-                    asm volatile("" : "+a"(acc[mb][2 * np]), "+a"(acc[mb][2 * np + 1]));
-                    const f32x4 v0 = acc[mb][2 * np], v1 = acc[mb][2 * np + 1];
-                    f32x2_t p00 = {v0[0], v0[1]}, p01 = {v0[2], v0[3]}, p10 = {v1[0], v1[1]}, p11 = {v1[2], v1[3]};
-                    const f32x2_t bb00 = {b0[0], b0[1]}, bb01 = {b0[2], b0[3]}, bb10 = {b1[0], b1[1]}, bb11 = {b1[2], b1[3]};
-                    if constexpr (LN) {
-                        // rstd (acc - mean colsum) + bias = fma(acc, rstd, fma(-mean rstd, colsum, bias)), as in k_gemm256p
-                        const f32x2_t rs = {ln_rs[mb], ln_rs[mb]}, nm = {ln_nm[mb], ln_nm[mb]};
-                        p00 = __builtin_elementwise_fma(p00, rs, __builtin_elementwise_fma(nm, (f32x2_t){c0[0], c0[1]}, bb00));
-                        p01 = __builtin_elementwise_fma(p01, rs, __builtin_elementwise_fma(nm, (f32x2_t){c0[2], c0[3]}, bb01));
-                        p10 = __builtin_elementwise_fma(p10, rs, __builtin_elementwise_fma(nm, (f32x2_t){c1[0], c1[1]}, bb10));
-                        p11 = __builtin_elementwise_fma(p11, rs, __builtin_elementwise_fma(nm, (f32x2_t){c1[2], c1[3]}, bb11));
-                    } else {
-                        p00 += bb00; p01 += bb01; p10 += bb10; p11 += bb11;
-                    }
-                    if constexpr (EPI == G4_EPI_GELU_LN) { p00 = g4_gelu2(p00); p01 = g4_gelu2(p01); p10 = g4_gelu2(p10); p11 = g4_gelu2(p11); }
-                    const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p00, bf16x2_t)), a1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2_t));
-                    const unsigned e0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p10, bf16x2_t)), e1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p11, bf16x2_t));
-                    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);
-                    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);
-                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, 0);
-                    G4_SB();                                                     // (keeps the scheduler from hoisting all 256 accumulator reads: the next tile's two fragment sets are live here)
+                for (int h = 0; h < 2; ++h) {
+                    const int np = 2 * nph + h;
+                    u32x4 b0u, b1u, c0u = {0u, 0u, 0u, 0u}, c1u = {0u, 0u, 0u, 0u};
+                    if constexpr (LN)
+                        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(b0u), "=&v"(b1u), "=&v"(c0u), "=&v"(c1u) : "v"(tb), "n"((2 * np) * 64), "n"((2 * np + 1) * 64), "n"(1024 + (2 * np) * 64), "n"(1024 + (2 * np + 1) * 64));
+                    else
+                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(b0u), "=&v"(b1u) : "v"(tb), "n"((2 * np) * 64), "n"((2 * np + 1) * 64));
+                    bq[h][0] = __builtin_bit_cast(f32x4, b0u); bq[h][1] = __builtin_bit_cast(f32x4, b1u);
+                    cq[h][0] = __builtin_bit_cast(f32x4, c0u); cq[h][1] = __builtin_bit_cast(f32x4, c1u);
                 }
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int np = 2 * nph + h;
+                        const f32x4 b0 = bq[h][0], b1 = bq[h][1];
+                        [[maybe_unused]] const f32x4 c0 = cq[h][0], c1 = cq[h][1];
+                        asm volatile("" : "+a"(acc[mb][2 * np]), "+a"(acc[mb][2 * np + 1]));
+                        const f32x4 v0 = acc[mb][2 * np], v1 = acc[mb][2 * np + 1];
+                        f32x2_t p00 = {v0[0], v0[1]}, p01 = {v0[2], v0[3]}, p10 = {v1[0], v1[1]}, p11 = {v1[2], v1[3]};
+                        const f32x2_t bb00 = {b0[0], b0[1]}, bb01 = {b0[2], b0[3]}, bb10 = {b1[0], b1[1]}, bb11 = {b1[2], b1[3]};
+                        if constexpr (LN) {
+                            // rstd (acc - mean colsum) + bias = fma(acc, rstd, fma(-mean rstd, colsum, bias)), as in k_gemm256p
+                            const f32x2_t rs = {ln_rs[mb], ln_rs[mb]}, nm = {ln_nm[mb], ln_nm[mb]};
+                            p00 = __builtin_elementwise_fma(p00, rs, __builtin_elementwise_fma(nm, (f32x2_t){c0[0], c0[1]}, bb00));
+                            p01 = __builtin_elementwise_fma(p01, rs, __builtin_elementwise_fma(nm, (f32x2_t){c0[2], c0[3]}, bb01));
+                            p10 = __builtin_elementwise_fma(p10, rs, __builtin_elementwise_fma(nm, (f32x2_t){c1[0], c1[1]}, bb10));
+                            p11 = __builtin_elementwise_fma(p11, rs, __builtin_elementwise_fma(nm, (f32x2_t){c1[2], c1[3]}, bb11));
+                        } else {
+                            p00 += bb00; p01 += bb01; p10 += bb10; p11 += bb11;
+                        }
+                        if constexpr (EPI == G4_EPI_GELU_LN) { p00 = g4_gelu2(p00); p01 = g4_gelu2(p01); p10 = g4_gelu2(p10); p11 = g4_gelu2(p11); }
+                        const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p00, bf16x2_t)), a1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2_t));
+                        const unsigned e0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p10, bf16x2_t)), e1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p11, bf16x2_t));
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, 0);
+                        G4_SB();                                                 // (keeps the scheduler from hoisting all 256 accumulator reads: the next tile's two fragment sets are live here)
+                    }
             }
         }
         G4_SB();
