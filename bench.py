@@ -393,7 +393,7 @@ def main():
     # tiles/s at the same measured launch duration; stride 8 reads ~3 % longer launches on the same box -- with fewer
     # idle gaps the chip sustains a lower clock -- DESIGN 5)
     prof = C.c_void_p()
-    _lib.check(L.cpx_prof_create(steps * args.depth + 8, int(os.environ.get("BENCH_PROF_STRIDE", "4")), 1,
+    _lib.check(L.cpx_prof_create(2 * steps * args.depth + 8, int(os.environ.get("BENCH_PROF_STRIDE", "4")), 1,
                                  C.byref(prof)), "prof_create")
     dt, cells, allrec = timed_run(eng, steps, args.warmup, inject=True, prof=prof, collective=True)
     dt = parallel.allreduce_max(dt, dev)
@@ -406,8 +406,11 @@ def main():
 
     n_tiles = steps * bt * world
     M = bt * eng.n_sub * 1024
+    # mlp.lin1 / mlp.lin2 run in row parts of 16 384 tokens (cpx_net_mlp_parts): one of THEIR launches covers M / parts rows
+    mlp_parts = int(L.cpx_net_mlp_parts(bt * eng.n_sub, _lib.DTYPE_CODE["bf16"]))
+    M_of = lambda name: M // mlp_parts if name in ("fc1", "fc2") else M
     avg_ms = ms_k[0] / max(cnt_k[0], 1)
-    achieved = FLOPS["fc1"](M) / (avg_ms * 1e-3) / 1e12 if fc1_launches else 0.0
+    achieved = FLOPS["fc1"](M_of("fc1")) / (avg_ms * 1e-3) / 1e12 if fc1_launches else 0.0
     flop_per_tile = 727.3e9 * eng.n_sub
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so rank 0 of
     # a 1-GPU run collects them NOW through two rocprofv3 --pmc child passes over that kernel alone (measure_traffic_live);
@@ -443,7 +446,7 @@ def main():
     if rank == 0 and not args.no_stages:
         stages = {}
         n6 = min(6, n_distinct)
-        cap = n6 * (args.depth * 5 + 2) + 8
+        cap = n6 * (args.depth * 7 + 2) + 8
         prof2 = C.c_void_p()
         _lib.check(L.cpx_prof_create(cap, 1, 0x7F, C.byref(prof2)), "prof_create")
         eng.stage_timing = []
@@ -469,8 +472,8 @@ def main():
             if not v:
                 continue
             med = v[len(v) // 2]
-            tf = FLOPS[name](M) / (med * 1e-3) / 1e12
-            kernel_time_sum += med * args.depth
+            tf = FLOPS[name](M_of(name)) / (med * 1e-3) / 1e12
+            kernel_time_sum += med * args.depth * (M // M_of(name))
             stages[name] = {"bound": "mfma", "launch_ms": {"min": round(v[0], 4), "median": round(med, 4), "max": round(v[-1], 4)},
                             "avg_launch_ms": round(sum(v) / len(v), 4), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_timed": len(v),
@@ -536,12 +539,13 @@ def main():
                    # (of `steps`) may already sit decoded in pinned host memory when the clock starts, as at any moment of the steady
                    # state.  Rounds 1-3 also timed their decoding (worth ~1.3 % at 20 steps, nothing over the whole slide)
                    "decode_ahead_batches_at_t0": decode_ahead},
-        "roofline": {"bound": "mfma", "kernel": "%s (mlp.lin1 %dx4096x1024)" % (_lib.FC1_KERNEL_NAME, M),
+        "roofline": {"bound": "mfma", "kernel": "%s (mlp.lin1 %dx4096x1024%s)" % (
+                         _lib.FC1_KERNEL_NAME, M_of("fc1"), "" if mlp_parts == 1 else "; the %d token rows of a step in %d launches per layer" % (M, mlp_parts)),
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; %s" % traffic_src,
                      "traffic_detail": traffic_detail,
-                     "algorithmic_bytes": 2.0 * (M * 1024 + 4096 * 1024 + M * 4096),
+                     "algorithmic_bytes": 2.0 * (M_of("fc1") * 1024 + 4096 * 1024 + M_of("fc1") * 4096),
                      "launches_timed": fc1_launches, "avg_launch_ms": avg_ms},
     }
     if stages is not None:

@@ -95,6 +95,7 @@ SIGNATURES = {
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
     "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i, _i]),
     "cpx_unet_head_forward": (_i, [C.POINTER(CpxConvOp), _i, _p, _i, _p, _i, _i, _i, _p, _sz, _p]),
+    "cpx_net_mlp_parts": (_i, [_i, _i]),
     "cpx_prof_create": (_i, [_i, _i, C.c_uint, C.POINTER(C.c_void_p)]),
     "cpx_prof_collect": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "cpx_prof_collect_launches": (_i, [_p, C.POINTER(C.c_float), C.POINTER(C.c_int), _i, C.POINTER(C.c_int)]),
@@ -152,6 +153,7 @@ _PRIVATE = {
     "cpx_gemm4w": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "cpx_gemm4w_set_variant": (None, [_i]),
     "cpx_gemm_set_4w": (None, [_i]),
+    "cpx_net_set_mlp_parts": (None, [_i]),
     "cpx_gemm_set_balanced": (None, [_i]),
     "cpx_gemm_set_dbg": (None, [_i]),
     "cpx_gemm_set_l2_block": (None, [_i]),

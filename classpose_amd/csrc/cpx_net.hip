@@ -1200,6 +1200,18 @@ extern "C" void cpx_prof_destroy(void *prof) {
     delete[] p->ev; delete[] p->kind; delete p;
 }
 
+// number of row parts the MLP of a layer runs in (mlp.lin1 -> mlp.lin2 per part): parts of 16 sub-tiles = 16 384 token rows when the batch is a
+// larger multiple of that (the hidden activations of a part, 134 MB at 2 bytes, then stay in the Infinity Cache between the two GEMMs), else 1.
+// bench.py prices an mlp.lin1 / mlp.lin2 launch with n_subtiles / parts * 1024 rows.
+CPX_SWITCH(g_mlp_parts, 1);        // 1 = the MLP in row parts (production), 0 = one launch pair over all rows (A/B)
+#ifdef CPX_DEBUG
+extern "C" void cpx_net_set_mlp_parts(int on) { g_mlp_parts = on; }
+#endif
+extern "C" int cpx_net_mlp_parts(int n_subtiles, int dtype) {
+    if (!g_mlp_parts || dtype == CPX_DT_F32 || n_subtiles <= 16 || n_subtiles % 16) return 1;
+    return n_subtiles / 16;
+}
+
 extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, int nS, float *head,
                                void *workspace, size_t workspace_bytes, void *stream) {
     CPX_REQUIRE(w && patches && head && workspace && nS > 0);
@@ -1242,8 +1254,17 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
             TIMED(CPX_PROF_ATTN, i, cpx_attention_half(dt, qkv, b.rel_h, b.rel_w, nS, vt, ao, stream, false));
             TIMED(CPX_PROF_PROJ, i, cpx_gemm_half(dt, ao, b.proj_w, M, 1024, 1024, CPX_EPI_RESID_BF16, b.proj_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
             if (!big_stats) RUN(cpx_row_stats_half(dt, x, M, st, stream));
-            TIMED(CPX_PROF_FC1, i, cpx_gemm_half(dt, x, b.fc1_w, M, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, st, b.fc1_colsum, nullptr, stream));
-            TIMED(CPX_PROF_FC2, i, cpx_gemm_half(dt, hb, b.fc2_w, M, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, x, x, 1024, nullptr, nullptr, big_stats ? st : nullptr, stream));
+            // the MLP in row parts of 16 384 tokens (cpx_net_mlp_parts): a part's hidden activations (134 MB) are written by mlp.lin1 and read
+            // back by mlp.lin2 straight away, from the 256 MB Infinity Cache, and every part re-uses the SAME hidden rows -- over all 32 768 rows
+            // the 268 MB hidden tensor goes out to HBM and comes back (one-process A/B, tools/ab_mlp_msplit.py: 451.8 -> 444.0 us per layer's
+            // MLP; with a hidden buffer of its own per part 457.5).  Rows are independent: same bits.
+            const int parts = big_stats ? cpx_net_mlp_parts(nS, dt) : 1, Mp = M / parts;
+            for (int pt = 0; pt < parts; ++pt) {
+                char *xp = (char *)x + (size_t)pt * Mp * 1024 * 2;
+                float *stp = st + (size_t)pt * Mp * 8;
+                TIMED(CPX_PROF_FC1, i, cpx_gemm_half(dt, xp, b.fc1_w, Mp, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, stp, b.fc1_colsum, nullptr, stream));
+                TIMED(CPX_PROF_FC2, i, cpx_gemm_half(dt, hb, b.fc2_w, Mp, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, xp, xp, 1024, nullptr, nullptr, big_stats ? stp : nullptr, stream));
+            }
             if (!big_stats) RUN(cpx_row_stats_half(dt, x, M, st, stream));
             continue;
         }

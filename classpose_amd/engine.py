@@ -390,7 +390,7 @@ class Engine:
         self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 65535)
         self.max_pts = nT * max(4096, H * W // 8)             # device vertex pool (f1), 16 B per vertex
         self.slots = [_Slot(self) for _ in range(self.N_SLOTS)]
-        self.s_net = torch.cuda.Stream(d)
+        self.s_net = torch.cuda.Stream(d, priority=int(os.environ.get("CPX_NET_STREAM_PRIORITY", "0")))
         # the post-processing chain is ~38 short kernels that run beside persistent network kernels holding every CU: a
         # higher stream priority lets their workgroups take a CU the moment one frees instead of queueing behind the
         # network's next tiles (CPX_POST_STREAM_PRIORITY: -1 high, 0 normal; A/B in tools/ab_post_priority.py)

@@ -30,6 +30,7 @@ void cpx_gemm_set_4w(int mask);             /* 1 (default): mlp.lin1 (bf16, fold
 void cpx_gemm4w_set_variant(int v);         /* experiment switches of cpx_gemm4w (0 default) */
 void cpx_gemm_set_split(int on);            /* 0 (default): 1 = counted LDS waits inside the main-loop phases of the persistent 256^2 kernel (experiment) */
 void cpx_gemm_set_dbg(int mask);            /* timing-only ablations of the 256^2 epilogue (0 default)   */
+void cpx_net_set_mlp_parts(int on);         /* 1 (default): the MLP of a layer in row parts of 16 384 tokens (hidden activations stay in the Infinity Cache); 0: one launch pair */
 void cpx_attention_set_xcd_order(int on);   /* 1 (default): (sub-tile, head) pairs pinned to one XCD     */
 void cpx_attention_set_variant(int v);      /* 2: 4-wave, LDS-DMA ring + pipelined S; 0: 4-wave register ring; 1: 8-wave ping-pong; 3: one wave per SIMD, two query rows per wave (LDS ring); 4: the same with fragments straight from global memory; 5: 4 without the per-half-step overflow vote (bf16); 6: fragments two tiles ahead in AGPR sets */
 void cpx_attention_set_lsum(int on);        /* 0 (default): 1 = softmax denominators by an all-ones MFMA (experiment)           */

@@ -11,6 +11,10 @@ engs = {}
 for pr in (0, -1):
     os.environ["CPX_POST_STREAM_PRIORITY"] = str(pr)
     engs[pr] = engine.Engine(w, 256, batch_tiles=8)
+# round 5: the NETWORK stream at high priority, the post stream normal (key 1)
+os.environ["CPX_POST_STREAM_PRIORITY"] = "0"; os.environ["CPX_NET_STREAM_PRIORITY"] = "-1"
+engs[1] = engine.Engine(w, 256, batch_tiles=8)
+os.environ["CPX_NET_STREAM_PRIORITY"] = "0"
 tiles = torch.from_numpy(np.stack([synth.render_region(1234, 224 * i, 0, 256, 256) for i in range(8)])).to(dev)
 f = [synth.analytic_fields(1234, 224 * i, 0, 256, 256, 7) for i in range(8)]
 inj = tuple(torch.from_numpy(np.stack([a[k] for a in f])).to(dev) for k in range(3))
@@ -21,12 +25,12 @@ def steps(eng, n):
         if prev is not None: eng.result(prev)
         prev = sid
     return eng.result(prev)
-res = {0: [], -1: []}; outs = {}
-for pr in (0, -1): steps(engs[pr], 3)
+res = {0: [], -1: [], 1: []}; outs = {}
+for pr in (0, -1, 1): steps(engs[pr], 3)
 for rnd in range(5):
-    for pr in (0, -1):
+    for pr in (0, -1, 1):
         steps(engs[pr], 2); torch.cuda.synchronize(); t = time.perf_counter(); o = steps(engs[pr], 20); torch.cuda.synchronize()
         res[pr].append((time.perf_counter() - t) / 20 * 1e3); outs[pr] = o.masks.clone()
 print("identical outputs:", torch.equal(outs[0], outs[-1]))
-for pr in (0, -1):
-    print(f"post stream priority {pr:2d}: engine ms/step min {min(res[pr]):.3f} median {sorted(res[pr])[2]:.3f}  {[round(x, 2) for x in res[pr]]}")
+for pr in (0, -1, 1):
+    print(f"{'network stream HIGH, post normal' if pr == 1 else 'post stream priority %2d' % pr}: engine ms/step min {min(res[pr]):.3f} median {sorted(res[pr])[2]:.3f}  {[round(x, 2) for x in res[pr]]}")

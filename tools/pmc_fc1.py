@@ -1,11 +1,12 @@
-"""The dominant kernel alone -- mlp.lin1 of one 8-tile batch: 32768 x 4096 x 1024, folded LayerNorm + erf-GELU epilogue, random
-bf16 operands -- for rocprofv3 --pmc passes (bench.py starts it twice as a child: FETCH_SIZE, WRITE_SIZE)."""
+"""The dominant kernel alone -- an mlp.lin1 launch of one 8-tile batch: (32768 / cpx_net_mlp_parts) x 4096 x 1024 (the engine runs the MLP of 32
+sub-tiles in two row parts of 16 384 tokens), folded LayerNorm + erf-GELU epilogue, random bf16 operands -- for rocprofv3 --pmc passes
+(bench.py starts it twice as a child: FETCH_SIZE, WRITE_SIZE)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from classpose_amd import _lib, ops
 dev = torch.device("cuda:0"); L = _lib.lib()
-M, N, K = 32768, 4096, 1024
+M, N, K = 32768 // int(L.cpx_net_mlp_parts(32, 0)), 4096, 1024
 g = torch.Generator().manual_seed(0)
 A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
 W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
