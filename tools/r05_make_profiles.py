@@ -15,12 +15,13 @@ gemm_flops = lambda n, k: 2.0 * M * n * k
 gemm_bytes = lambda n, k, extra=0: 2.0 * (M * k + n * k + M * n) + extra
 # kernel-name prefix -> (what, algorithmic flops per launch, algorithmic bytes per launch)
 KERNELS = [
-    ("void k_gemm4w<1, 0>", "mlp.lin1 (fc1, GELU + folded LayerNorm): one wave per SIMD, persistent (round 5)", gemm_flops(HID, C), gemm_bytes(HID, C)),
+    # round 5: the MLP runs in two row parts of 16 384 tokens (cpx_net_mlp_parts): an mlp.lin1 / mlp.lin2 LAUNCH covers M / 2 rows
+    ("void k_gemm4w<1, 0>", "mlp.lin1 (fc1, GELU + folded LayerNorm): one wave per SIMD, persistent; 16 384 rows per launch (two launches per layer)", gemm_flops(HID, C) / 2, gemm_bytes(HID, C) / 2 + HID * C),
     ("void k_gemm256p<1, false, 33>", "mlp.lin1 (fc1, GELU + folded LayerNorm, direct-store epilogue), 8-wave kernel", gemm_flops(HID, C), gemm_bytes(HID, C)),
     ("void k_gemm256p<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), persistent with the balanced tile list", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
     ("void k_gemm256<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), one workgroup per tile", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
-    ("void k_gemm256p<2, false, 66>", "attn.proj and mlp.lin2 (residual + row statistics, balanced fragment-read schedule), average of both",
-     (gemm_flops(C, C) + gemm_flops(C, HID)) / 2, (gemm_bytes(C, C, 2 * M * C) + gemm_bytes(C, HID, 2 * M * C)) / 2),
+    ("void k_gemm256p<2, false, 66>", "attn.proj (32 768 rows) and mlp.lin2 (two launches of 16 384 rows): residual + row statistics, balanced fragment-read schedule; average over the three launches per layer",
+     (gemm_flops(C, C) + gemm_flops(C, HID)) / 3, (gemm_bytes(C, C, 2 * M * C) + gemm_bytes(C, HID, 2 * M * C)) / 3),
     ("void k_attention4p<false", "rel-pos flash attention (4-wave, LDS-DMA ring; production variant 2)",
      4.0 * 32 * 16 * 1024 * 1024 * 64 + 4.0 * 32 * 16 * 1024 * 32 * 64, 2.0 * 4 * M * C),      # algorithmic: 4 T^2 hd heads + 4 heads T sqrt(T) hd
     ("void k_attention<false, false, false>", "rel-pos flash attention (variant 0)",
@@ -90,7 +91,7 @@ traffic = {
              "counts 64 B per 128-B request for wide coalesced / LDS-DMA reads -> doubled. FETCH_SIZE is the L2's fabric-side "
              "traffic and includes Infinity-Cache hits (the W panels, 8.4 MB, and most of the 67 MB activation panel stay "
              "resident in the 256 MiB MALL), so it bounds HBM traffic from above."),
-    "dominant_kernel": "k_gemm4w<GELU + folded LayerNorm> (mlp.lin1, M=32768 N=4096 K=1024): one wave per SIMD, persistent",
+    "dominant_kernel": "k_gemm4w<GELU + folded LayerNorm> (mlp.lin1, 16 384 rows per launch, N=4096 K=1024): one wave per SIMD, persistent",
     "fetch_bytes_per_launch_corrected": fetch,
     "write_bytes_per_launch": write,
     "traffic_bytes_per_launch": fetch + write,
