@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -264,3 +265,86 @@ def test_isa_lint_no_lds_load_is_consumed_before_its_wait():
         assert os.path.exists(path), path
         found = lint.findings(path)
         assert not found, found[:5]
+
+
+def test_hostinfo_caps_thread_pools_by_the_cgroup_quota(tmp_path, monkeypatch):
+    """hostinfo.usable_cpus = affinity mask capped by the cgroup CPU quota (a 256-CPU box with cpu.max = 1600000 100000 grants 16 cores)."""
+    import builtins
+    from classpose_amd import hostinfo
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text(fake_open.content)
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    fake_open.content = "1600000 100000\n"
+    assert hostinfo.cgroup_cpu_limit() == 16.0 and hostinfo.usable_cpus() == 16
+    fake_open.content = "max 100000\n"
+    assert hostinfo.cgroup_cpu_limit() is None and hostinfo.usable_cpus() == 256
+    fake_open.content = "50000 100000\n"                      # half a core still gets one thread
+    assert hostinfo.usable_cpus() == 1
+
+
+def test_bench_profiler_guard_looks_at_values_not_names():
+    """bench.py's live-traffic pass must not be switched off by an unrelated LD_PRELOAD (round 4's driver line lost its measurement to the
+    guard library the GPU boxes preload); it is switched off under rocprofv3, and says which variable told it so."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench._profiler_in_env({"LD_PRELOAD": "/usr/lib/libexecguard.so", "PATH": "/usr/bin"}) is None
+    assert bench._profiler_in_env({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})[0] == "LD_PRELOAD"
+    assert bench._profiler_in_env({"ROCPROF_OUTPUT_PATH": "/tmp/x"})[0] == "ROCPROF_OUTPUT_PATH"
+    assert bench._profiler_in_env({"HSA_TOOLS_LIB": "libroctracer64.so"})[0] == "HSA_TOOLS_LIB"
+    assert bench._profiler_in_env({"ROCP_TOOL_LIBRARIES": ""}) is None
+
+
+def test_bench_gpus_n_without_gpus_exits_nonzero():
+    """`python bench.py --gpus 2` on a node without two GPUs (and no gloo dry run asked for) must not print a line at all: exit code 2."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CPX_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-300:])
+    assert "--gpus 2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_classpose_model_engine_pool_is_bounded(monkeypatch):
+    """ClassposeModel hands engines out of a bounded pool per (shape, options): at most max_engines exist however many threads call, a lease
+    returns its engine on exit (also when the body raises), and a failed construction gives its reservation back."""
+    import threading
+    import time
+    from classpose_amd import models
+    made = []
+
+    class FakeEngine:
+        def __init__(self, *a, **k):
+            made.append(self)
+    m = models.ClassposeModel.__new__(models.ClassposeModel)
+    m.max_engines, m._pool, m._cv, m.weights, m.max_batch_tiles = 2, {}, threading.Condition(), None, 8
+    monkeypatch.setattr(models.engine, "Engine", FakeEngine)
+    peak, live, lock = [0], [0], threading.Lock()
+
+    def work():
+        for _ in range(5):
+            with m._engine(256, 256, False, 0.1, {"niter": 200}):
+                with lock:
+                    live[0] += 1
+                    peak[0] = max(peak[0], live[0])
+                time.sleep(0.002)
+                with lock:
+                    live[0] -= 1
+    th = [threading.Thread(target=work) for _ in range(8)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert len(made) == 2 and peak[0] == 2 and m.engines_alive() == 2
+    with pytest.raises(RuntimeError):
+        with m._engine(256, 256, False, 0.1, {"niter": 200}):
+            raise RuntimeError("body failed")
+    assert len(m._pool[next(iter(m._pool))]["idle"]) == 2            # returned
+    monkeypatch.setattr(models.engine, "Engine", lambda *a, **k: (_ for _ in ()).throw(MemoryError("no memory")))
+    with pytest.raises(MemoryError):
+        with m._engine(512, 512, False, 0.1, {"niter": 200}):
+            pass
+    assert m.engines_alive() == 2                                     # the failed reservation was given back
