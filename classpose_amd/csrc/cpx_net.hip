@@ -716,7 +716,11 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
 // ERD ("early reads"): the K fragments of tile kh + 1 AND the V fragments of tile kh are requested right behind the barrier and
 // the softmax's vector stream runs under their LDS latency (gh is waited for with a counted lgkmcnt(8)); the eight MFMAs
 // follow in one block.  Without it the wave sits in lgkmcnt(0) twice per tile (in front of QK^T and in front of P.V).
-template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false>
+// NV ("no vote", round-5 experiment, bf16 only): the reference of the softmax is fixed by the FIRST key tile (its exact maximum + the headroom); later
+// tiles neither OR their packed probabilities nor vote nor branch.  bf16 has float32's exponent range, so a probability above 2 is as accurate as one
+// below (the rescale of the production kernel only matters for fp16's range); what is lost is the guard against float32 overflow when a later score
+// exceeds the first tile's maximum by > ~80 octaves -- a production form would have to test the row sums for finiteness and re-run such an item.
+template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false, bool NV = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
                                                                 const unsigned short *__restrict__ relh,
@@ -832,7 +836,9 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     // TAIL (compile time): 0 = any key tile up to 28 (every end-of-sequence condition below holds), 1 / 2 / 3 = tiles 29 / 30 / 31 -- the last four
     // tiles are peeled so that the steady-state body carries no scalar branch for them (round 4)
     auto tile = [&](const int kh, auto slot_tag, auto next_tag, auto tail_tag) {
-        constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value, TAIL = decltype(tail_tag)::value;
+        constexpr int SL = decltype(slot_tag)::value, SN = decltype(next_tag)::value, TAILV = decltype(tail_tag)::value;
+        constexpr bool FIRST_TILE = TAILV == 4;                  // (NV: tag 4 = the very first key tile, otherwise a steady-state tile)
+        constexpr int TAIL = FIRST_TILE ? 0 : TAILV;
         // tile kh + 1 (this thread's part) has landed; after the barrier every part has, and every wave is done with
         // slot (kh - 1) & 3, which the next request overwrites
         if constexpr (TAIL < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -872,7 +878,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
 #pragma unroll
             for (int j = 0; j < 8; ++j) pk[j] = pack2<F16>(p[2 * j], p[2 * j + 1]);
         }
-        if (__builtin_expect(__any(((pk[0] | pk[1] | pk[2]) | (pk[3] | pk[4] | pk[5]) | (pk[6] | pk[7])) & 0x40004000u), 0)) {
+        bool resc;
+        if constexpr (NV) resc = FIRST_TILE;
+        else resc = __builtin_expect(__any(((pk[0] | pk[1] | pk[2]) | (pk[3] | pk[4] | pk[5]) | (pk[6] | pk[7])) & 0x40004000u), 0);
+        if (resc) {
             float mx = __builtin_fmaxf(__builtin_fmaxf(S[0], S[1]), S[2]);
 #pragma unroll
             for (int i = 3; i < 15; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, S[i]), S[i + 1]);
@@ -928,7 +937,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         S = Sn;
     };
     using T0 = integral_constant<int, 0>;
-    for (int kh0 = 0; kh0 < 28; kh0 += 4) {
+    if constexpr (NV) {                                          // the first round peeled: its first tile fixes the reference
+        tile(0, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 4>{});
+        tile(1, integral_constant<int, 1>{}, integral_constant<int, 2>{}, T0{});
+        tile(2, integral_constant<int, 2>{}, integral_constant<int, 3>{}, T0{});
+        tile(3, integral_constant<int, 3>{}, integral_constant<int, 0>{}, T0{});
+    }
+    for (int kh0 = NV ? 4 : 0; kh0 < 28; kh0 += 4) {
         tile(kh0 + 0, integral_constant<int, 0>{}, integral_constant<int, 1>{}, T0{});
         tile(kh0 + 1, integral_constant<int, 1>{}, integral_constant<int, 2>{}, T0{});
         tile(kh0 + 2, integral_constant<int, 2>{}, integral_constant<int, 3>{}, T0{});
@@ -1076,6 +1091,14 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         (void)hipFuncSetAttribute((const void *)k_attention4p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
     });
 #ifdef CPX_DEBUG
+    if (g_att_lsum == 3 && dtype != CPX_DT_F16) {           // round-5 experiment: no overflow vote (k_attention4p<.., NV>), bf16
+        static CpxOncePerDevice once4n;
+        once4n([] { (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); });
+        hipLaunchKernelGGL((k_attention4p<false, false, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                           (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
     if (g_att_lsum == 2) {           // experiment: early fragment reads (k_attention4p<.., ERD>)
         static CpxOncePerDevice once4e;
         once4e([] {
