@@ -218,6 +218,10 @@ def _load(path: str, signatures: dict):
         raise CpxError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: it ships its own libamdhip64 and the host side hands us ITS streams and device pointers.  Loaded before torch, this library would
+    # bind the system HIP runtime instead, and a process would hold two runtimes -- ours without a device context ("no ROCm-capable device is
+    # detected" at the first launch; seen when build() and smoke() ran in one interpreter on a GPU box, round 5)
+    import torch  # noqa: F401
     L = C.CDLL(path)
     for name, (res, args) in signatures.items():
         fn = getattr(L, name)          # AttributeError if the symbol is absent -> loud
