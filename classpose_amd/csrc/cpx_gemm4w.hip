@@ -105,7 +105,7 @@ __device__ __forceinline__ f32x2_t g4_gelu2(f32x2_t x) {
 // VAR (debug build; 0 in production).  Timing-only ablations, results are garbage: 1 = no LDS-DMA requests inside the loop, 2 = no fragment
 // reads, 4 = no barriers, 8 = no MFMAs, 16 = the requests as ORDINARY buffer loads into 16 staging registers (consumed by an empty asm in the
 // second half), 32 = ... and written to LDS by ds_write_b128 there, 64 = every workgroup walks K from its own starting K tile.
-// 128 (results valid): all 16 requests of a K tile in its first half (the first form of this kernel), vmcnt(16) at mid.
+// 128 (results valid): all 16 requests of a K tile in its first half (the first form of this kernel), vmcnt(16) at mid.  256 (results valid): start skew (below).
 template <int EPI, int VAR>
 __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_gemm4w(Gemm4wArgs g) {
     constexpr bool LN = EPI == G4_EPI_GELU_LN;
@@ -238,6 +238,14 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
 
     int v = blockIdx.x, m0, n0;
     coords(v, m0, n0);
+    if constexpr ((VAR & 256) != 0) {
+        // experiment (timing + results valid): a start skew along the super-tile's diagonal -- workgroup (i, j) of an 8 x 4 super-tile starts
+        // (i + j) x ~2 500 cycles late, so that the four workgroups that share an activation panel (and the eight that share a weight panel) do not
+        // all wait for the same L2 fill but follow its first requester by one K tile
+        const int w_ = (int)(blockIdx.x >> 3) & 31;                              // position inside the XCD's group of 32 concurrently running workgroups
+        const int d = (w_ >> 2) + (w_ & 3);
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(40);
+    }
     // ---- prologue of the workgroup's first tile: tail, K tiles 0 and 1, the first two fragment sets
     G4_TAIL_REQUESTS(m0, n0)
     {
@@ -556,6 +564,7 @@ extern "C" int cpx_gemm4w(const void *A, const void *W, int M, int N, int K, con
         case 7: g4_launch<G4_EPI_BIAS, 7>(a, s); break;
         case 8: g4_launch<G4_EPI_BIAS, 8>(a, s); break;
         case 128: g4_launch<G4_EPI_BIAS, 128>(a, s); break;
+        case 256: g4_launch<G4_EPI_BIAS, 256>(a, s); break;
         default: g4_launch<G4_EPI_BIAS, 0>(a, s);
     }
     return hipGetLastError() == hipSuccess ? 0 : CPX_EHIP;
