@@ -1801,9 +1801,9 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
 #endif
             // mlp.lin1 of the bf16 network (folded LayerNorm + bias + erf-GELU) on the one-wave-per-SIMD kernel: bitwise equal to the
             // k_gemm256p instantiation below, its main loop and its epilogue both faster (profiles/r05_ab_gemm4w_*.txt)
-            if constexpr (EPI == CPX_EPI_GELU_BF16 && !F16) {
+            if constexpr (EPI == CPX_EPI_GELU_BF16) {
                 if ((g_gemm_4w & 1) && f1 && a.bias && a.K >= 256 && (a.K / 64) % 2 == 0 &&
-                    cpx_gemm4w_gelu_ln(a.A, a.W, a.M, a.N, a.K, a.bias, a.ln_stats, a.ln_colsum, a.out, a.ld_out, s))
+                    cpx_gemm4w_gelu_ln(F16 ? 1 : 0, a.A, a.W, a.M, a.N, a.K, a.bias, a.ln_stats, a.ln_colsum, a.out, a.ld_out, s))
                     return true;
             }
             // attn.proj / mlp.lin2 of the bf16 network (residual + row statistics, N = 1024) on that kernel: bitwise equal to k_gemm256p<.., F1 | G2F_BAL>

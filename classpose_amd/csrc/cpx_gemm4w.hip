@@ -38,6 +38,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// two f32 -> one dword of two halves (round to nearest even), bf16 or fp16
+template <bool F16>
+__device__ __forceinline__ unsigned g4_pack2(f32x2_t v) {
+    if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 
 #define G4_THREADS 256
 #define G4_ITEM 16384
@@ -106,7 +113,7 @@ __device__ __forceinline__ f32x2_t g4_gelu2(f32x2_t x) {
 // reads, 4 = no barriers, 8 = no MFMAs, 16 = the requests as ORDINARY buffer loads into 16 staging registers (consumed by an empty asm in the
 // second half), 32 = ... and written to LDS by ds_write_b128 there, 64 = every workgroup walks K from its own starting K tile.
 // 128 (results valid): all 16 requests of a K tile in its first half (the first form of this kernel), vmcnt(16) at mid.  256 (results valid): start skew (below).
-template <int EPI, int VAR>
+template <int EPI, int VAR, bool F16 = false>
 __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_gemm4w(Gemm4wArgs g) {
     constexpr bool LN = EPI == G4_EPI_GELU_LN;
     constexpr bool SPLIT = !(VAR & 128);
@@ -175,6 +182,8 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
 #define G4_MM(MB, NB, FX, FW, FIRST)                                                                             \
     {                                                                                                           \
         if (VAR & 8) { if (FIRST) asm volatile("; no mfma %0 %1 %2" : "=a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); else asm volatile("; no mfma %0 %1 %2" : "+a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); } \
+        else if (F16) { if (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); \
+                        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); } \
         else if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); \
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[MB][NB]) : "v"(FW[NB]), "v"(FX[MB])); \
     }
@@ -459,8 +468,7 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
                             p00 += bb00; p01 += bb01; p10 += bb10; p11 += bb11;
                         }
                         if constexpr (EPI == G4_EPI_GELU_LN) { p00 = g4_gelu2(p00); p01 = g4_gelu2(p01); p10 = g4_gelu2(p10); p11 = g4_gelu2(p11); }
-                        const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p00, bf16x2_t)), a1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2_t));
-                        const unsigned e0 = __builtin_bit_cast(unsigned, __builtin_convertvector(p10, bf16x2_t)), e1 = __builtin_bit_cast(unsigned, __builtin_convertvector(p11, bf16x2_t));
+                        const unsigned a0 = g4_pack2<F16>(p00), a1 = g4_pack2<F16>(p01), e0 = g4_pack2<F16>(p10), e1 = g4_pack2<F16>(p11);
                         const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);
                         const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);
                         const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
@@ -511,24 +519,25 @@ static bool g4_shape_ok(int M, int N, int K, int ld_out) {
     if (M % 256 || N % 256 || K % 128 || K < 256) return false;
     return (size_t)M * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 31) && (size_t)M * ld_out * 2 < ((size_t)1 << 31);
 }
-template <int EPI, int VAR>
+template <int EPI, int VAR, bool F16 = false>
 static void g4_launch(const Gemm4wArgs &a, hipStream_t s) {
     static CpxOncePerDevice once;
-    once([] { (void)hipFuncSetAttribute((const void *)k_gemm4w<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); });
+    once([] { (void)hipFuncSetAttribute((const void *)k_gemm4w<EPI, VAR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); });
     const int n_cu = g4_num_cus();
-    hipLaunchKernelGGL((k_gemm4w<EPI, VAR>), dim3(a.n_blocks < n_cu ? a.n_blocks : n_cu), dim3(G4_THREADS), G4_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_gemm4w<EPI, VAR, F16>), dim3(a.n_blocks < n_cu ? a.n_blocks : n_cu), dim3(G4_THREADS), G4_LDS_BYTES, s, a);
 }
 
-// mlp.lin1 of the bf16 network: out = gelu(LayerNorm-folded(A) W^T + bias), bf16.  Returns 1 when launched, 0 when the shape is not this
+// mlp.lin1 of the half-precision network (bf16, or fp16 when f16 != 0): out = gelu(LayerNorm-folded(A) W^T + bias).  Returns 1 when launched, 0 when the shape is not this
 // kernel's (the caller then takes k_gemm256p, which computes the same bits).
-int cpx_gemm4w_gelu_ln(const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
+int cpx_gemm4w_gelu_ln(int f16, const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
                        void *out, int ld_out, hipStream_t s) {
     if (!g4_shape_ok(M, N, K, ld_out) || !bias || !ln_stats || !ln_colsum) return 0;
     Gemm4wArgs a;
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = ln_stats; a.ln_colsum = ln_colsum;
     a.out = (unsigned short *)out; a.resid = nullptr; a.stats_out = nullptr;
     a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
-    g4_launch<G4_EPI_GELU_LN, 0>(a, s);
+    if (f16) g4_launch<G4_EPI_GELU_LN, 0, true>(a, s);
+    else g4_launch<G4_EPI_GELU_LN, 0, false>(a, s);
     return 1;
 }
 

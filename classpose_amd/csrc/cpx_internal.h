@@ -56,8 +56,8 @@ int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C
                    void *out, int ld_out, void *stream);
 int cpx_row_stats_half(int dtype, const void *x, int rows, float *stats, void *stream);
 int cpx_gemm_half_uses_big_tile(int M, int N, int K, int epilogue);
-// one-wave-per-SIMD 256^2 kernel (cpx_gemm4w.hip), bf16: gelu(folded-LayerNorm(A) W^T + bias); 1 = launched, 0 = not this kernel's shape
-int cpx_gemm4w_gelu_ln(const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
+// one-wave-per-SIMD 256^2 kernel (cpx_gemm4w.hip), bf16 / fp16: gelu(folded-LayerNorm(A) W^T + bias); 1 = launched, 0 = not this kernel's shape
+int cpx_gemm4w_gelu_ln(int f16, const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
                        void *out, int ld_out, hipStream_t s);
 // ... and bf16(bf16(A W^T + bias) + resid) with the partial row statistics of the output (N = 1024); resid may be out
 int cpx_gemm4w_resid_stats(const void *A, const void *W, int M, int N, int K, const float *bias, const void *resid, void *out, int ld_out,

@@ -628,6 +628,38 @@ def test_benched_path_depth24_32_subtiles_vs_oracle(cuda, precision):
     assert e_ours < 1.5 * e_ref + 2e-3
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_net_forward_is_bitwise_independent_of_the_round5_switches(cuda, precision):
+    """Round 5 changed HOW a forward runs, not what it computes: mlp.lin1 on the one-wave-per-SIMD kernel (bf16 and fp16 instantiations) and the
+    MLP in row parts of 16 384 tokens.  The whole head tensor of a 32-sub-tile, 3-block forward is bit for bit the same with both switched off
+    (cpx_gemm_set_4w(0), cpx_net_set_mlp_parts(0): the round-4 path), each on alone, and both on (production)."""
+    import ctypes as C
+    nS, depth = 32, 3
+    sd = synth.make_state_dict(7, None, depth=depth, seed=5)
+    hd = engine.HALF_DTYPES[precision]
+    x = np.random.default_rng(1).random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5).reshape(nS * 1024, 192).to(hd).to(cuda)
+
+    def forward(L):
+        w = engine.NetWeights.from_state_dict(sd, precision, cuda, fuse_ln=True)
+        head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+        ws = torch.empty(L.cpx_net_workspace_bytes(nS, w.c.dtype), dtype=torch.uint8, device=cuda)
+        _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return head
+    prod = forward(_lib.lib())
+    assert bool(torch.isfinite(prod).all())
+    assert _lib.lib().cpx_net_mlp_parts(nS, w_dtype := _lib.DTYPE_CODE[precision]) == 2 and _lib.lib().cpx_net_mlp_parts(16, w_dtype) == 1
+    with _lib.use_debug_library() as L:
+        try:
+            for g4, parts in ((0, 0), (1, 0), (0, 1), (1, 1)):
+                L.cpx_gemm_set_4w(g4); L.cpx_net_set_mlp_parts(parts)
+                assert torch.equal(forward(L), prod), (g4, parts)
+        finally:
+            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1)
+
+
 def test_engine_fp16_512px_vs_oracle(cuda):
     """BASELINE configs[4] geometry on one GPU: Cellpose-SAM backbone + semantic head in fp16 on 512-px
     tiles (9 sub-tiles each), depth 2: network outputs vs the fp32 oracle, ids bit-exact on the device tensors"""
