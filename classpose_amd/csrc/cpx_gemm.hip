@@ -1806,6 +1806,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                     cpx_gemm4w_gelu_ln(F16 ? 1 : 0, a.A, a.W, a.M, a.N, a.K, a.bias, a.ln_stats, a.ln_colsum, a.out, a.ld_out, s))
                     return true;
             }
+#ifdef CPX_DEBUG
             // attn.proj / mlp.lin2 of the bf16 network (residual + row statistics, N = 1024) on that kernel: bitwise equal to k_gemm256p<.., F1 | G2F_BAL>
             // and 3 - 6 % SLOWER, so only the debug build's cpx_gemm_set_4w(3) takes this branch (g_gemm_4w is the constant 1 in the product)
             if constexpr (EPI == CPX_EPI_RESID_BF16 && !F16) {
@@ -1813,6 +1814,7 @@ static bool launch_gemm256(const GemmArgs &a0, hipStream_t s) {
                     cpx_gemm4w_resid_stats(a.A, a.W, a.M, a.N, a.K, a.bias, a.aux, a.out, a.ld_out, a.stats_out, s))
                     return true;
             }
+#endif
             // direct-store epilogue (G2F_DIRECT): production for the GELU epilogue (mlp.lin1 -3.5 %, bitwise equal); the lighter epilogues
             // measured equal or slower with it (qkv +1.2 %) and keep the staged rows -- cpx_gemm_set_direct(2) in the debug build forces it
             constexpr bool DIRECT_OK = EPI == CPX_EPI_GELU_BF16

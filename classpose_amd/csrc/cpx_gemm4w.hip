@@ -541,6 +541,8 @@ int cpx_gemm4w_gelu_ln(int f16, const void *A, const void *W, int M, int N, int 
     return 1;
 }
 
+#ifdef CPX_DEBUG
+// (debug build only: measured 3 - 6 % slower than k_gemm256p, profiles/r05_ab_gemm4w_resid.txt -- the product library does not carry this instantiation)
 // attn.proj / mlp.lin2 of the bf16 network: out = bf16(bf16(A W^T + bias) + resid) and the row statistics of out (N = 1024: 4 column tiles = the
 // 4 slots).  Returns 1 when launched, 0 when the shape is not this kernel's.
 int cpx_gemm4w_resid_stats(const void *A, const void *W, int M, int N, int K, const float *bias, const void *resid, void *out, int ld_out,
@@ -554,7 +556,6 @@ int cpx_gemm4w_resid_stats(const void *A, const void *W, int M, int N, int K, co
     return 1;
 }
 
-#ifdef CPX_DEBUG
 static int g_gemm4w_var = 0;
 extern "C" void cpx_gemm4w_set_variant(int v) { g_gemm4w_var = v; }
 // out[M][ld_out] (bf16) = A[M][K] . W[N][K]^T + bias; M, N multiples of 256, K a multiple of 128, every operand below 2 GiB
