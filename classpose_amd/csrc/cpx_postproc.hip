@@ -27,7 +27,7 @@ extern "C" unsigned long long cpx_postproc_launch_count(void) { return g_pp_laun
 // workspace layout
 // ---------------------------------------------------------------------------
 struct PPLayout {
-    int H, W, HW, Hp, Wp, HWp, L, TW, TH, THW;
+    int H, W, HW, Hp, Wp, HWp, L, TW, TH, THW, nbx, nseg;
     size_t off_h1, off_M1, off_tmp, off_im, off_fg, off_fgcnt, off_T, off_e, off_seed_pos, off_seed_cnt,
         off_rank, off_cnt, off_first, off_remap, off_flag, off_bbox, off_sumy, off_sumx,
         off_d2, off_center, off_err, off_cls, off_scal, per_tile, tab0, tab_bytes;
@@ -44,6 +44,7 @@ struct PPLayout {
 #define PP_MAXCLS 32
 
 #define FG_BLOCK 1024       // k_prep_flow workgroup = one segment of the foreground list
+#define FG_SIDE 32          // ... which is a FG_SIDE x FG_SIDE block of cells of the bordered flow field (k_follow stages its neighbourhood in LDS)
 static PPLayout pp_layout(int H, int W) {
     PPLayout p;
     p.H = H; p.W = W; p.HW = H * W; p.Hp = H + 2 * RPAD; p.Wp = W + 2 * RPAD;
@@ -54,8 +55,9 @@ static PPLayout pp_layout(int H, int W) {
     p.off_M1 = take(sizeof(int) * p.HWp);
     p.off_tmp = take(sizeof(int) * p.HW);
     p.off_im = take(sizeof(float) * 2 * p.THW);      // zero-bordered interleaved flow field [H+2][W+2][dx, dy]
-    p.off_fg = take(sizeof(int) * FG_BLOCK * cpx_cdiv(p.THW, FG_BLOCK));   // foreground pixels, one segment per k_prep_flow block
-    p.off_fgcnt = take(sizeof(int) * cpx_cdiv(p.THW, FG_BLOCK));
+    p.nbx = cpx_cdiv(p.TW, FG_SIDE); p.nseg = p.nbx * cpx_cdiv(p.TH, FG_SIDE);   // (>= cdiv(THW, FG_BLOCK), the linear segmentation's count)
+    p.off_fg = take(sizeof(int) * FG_BLOCK * p.nseg);   // foreground pixels, one segment per k_prep_flow block
+    p.off_fgcnt = take(sizeof(int) * p.nseg);
     p.off_T = take(sizeof(double) * 2 * p.THW);
     p.off_e = take(sizeof(double) * 2 * p.HW);
     p.off_cls = take(sizeof(int) * (size_t)p.L * PP_MAXCLS);
@@ -132,7 +134,9 @@ __device__ __forceinline__ void pp_init_stats_entry(char *tb, const PPLayout &la
     ((int *)(tb + lay.off_flag + d))[v] = 0;
     ((int *)(tb + lay.off_first + d))[v] = 0x7FFFFFFF;
 }
-template <bool INIT>
+// B2D: the workgroup's 1024 cells are a 32 x 32 block of the bordered field (segment = block; k_follow<.., true> stages the block's
+// neighbourhood in LDS) instead of 1024 consecutive cells of its row-major order.
+template <bool INIT, bool B2D>
 __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict__ dP, const float *__restrict__ cp,
                                                         float thr, float kx, float ky, int32_t *__restrict__ p_final,
                                                         float *__restrict__ p_float, PPLayout lay, void *ws) {
@@ -151,13 +155,23 @@ __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict_
             if (i < PP_NSCAL * PP_NSETS) ((int *)(tb + lay.off_scal + (size_t)(i / PP_NSCAL) * lay.tab_bytes))[i % PP_NSCAL] = 0;
         }
     }
-    const int c = blockIdx.x * FG_BLOCK + threadIdx.x;
+    int c, py, px;
+    bool cell;
+    if constexpr (B2D) {
+        const int by = blockIdx.x / lay.nbx, bx = blockIdx.x - by * lay.nbx;
+        py = by * FG_SIDE + (threadIdx.x >> 5); px = bx * FG_SIDE + (threadIdx.x & 31);
+        c = py * lay.TW + px;
+        cell = py < lay.TH && px < lay.TW;
+    } else {
+        c = blockIdx.x * FG_BLOCK + threadIdx.x;
+        py = c / lay.TW; px = c - py * lay.TW;
+        cell = c < lay.THW;
+    }
     size_t t = blockIdx.y;
-    const int py = c / lay.TW, px = c - py * lay.TW;
     float2 v = make_float2(0.f, 0.f);
     bool fg = false;
     int idx = 0;
-    if (c < lay.THW && py >= 1 && py <= lay.H && px >= 1 && px <= lay.W) {
+    if (cell && py >= 1 && py <= lay.H && px >= 1 && px <= lay.W) {
         idx = (py - 1) * lay.W + (px - 1);
         fg = cp[t * lay.HW + idx] > thr;
         float m = fg ? 1.0f : 0.0f;
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict_
             if (p_float) { p_float[(t * 2) * lay.HW + idx] = -1.f; p_float[(t * 2 + 1) * lay.HW + idx] = -1.f; }
         }
     }
-    if (c < lay.THW) reinterpret_cast<float2 *>(WS(float, off_im))[c] = v;
+    if (cell) reinterpret_cast<float2 *>(WS(float, off_im))[c] = v;
     const unsigned long long bal = __ballot(fg);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) sW[wave] = __popcll(bal);
@@ -185,54 +199,151 @@ __global__ void __launch_bounds__(FG_BLOCK) k_prep_flow(const float *__restrict_
 typedef float flow4 __attribute__((ext_vector_type(4), aligned(8)));
 
 // HIST (fused chain): the final position goes straight into the padded histogram of get_masks (k_hist's pass)
-// (Round 5 measured TWO Euler chains per lane -- entries e and e + 128 of a quarter segment in one instruction stream, half as many waves, the
-// per-chain operation order untouched -- as the round-4 review suggested for a latency-bound loop: 194-207 us against 120-123 us for this
-// kernel on the analytic fields, 264 against 217-229 on random ones (profiles/r05_ab_follow_two_chains.txt).  The loop is not waiting for one
-// wave's gather: every step is two wave-wide gathers of 64 different cache lines each, i.e. the CU's texture addresser is the busy unit, and
-// fewer, fatter waves only take away what overlapped it.)
-template <bool HIST>
-__global__ void k_follow(int niter, float shx, float shy,
+// What the Euler loop costs and why (round 5; profiles/r05_micro_follow_step.txt, r05_follow_niter_scan.txt, r05_ab_follow_segments_window_grouped.txt):
+// the kernel lasted 0.53 us per step on the bench's fields although a lone wave needs 534 cycles for one (0.22 us), for three reasons found in
+// this order.  (1) Row-major foreground segments (1024 consecutive cells = 4 rows of the field) put the pixels of ~20 different cells into one
+// wave, so each of its two gathers per step touches up to 64 different cache lines and the CU's one texture addresser serialises them: 32 x 32
+// -cell segments give a wave the pixels of two rows of ONE block, which converge onto a handful of centres (84.6 against 118.4 us for a11).
+// (2) The per-lane, per-step orbit tests were a third of the lone wave's step (GROUPED below: 67.1 us).  (3) The workgroups that had anything
+// to do were the multiples of four, i.e. all on two of the eight XCDs (see the index arithmetic at the top of the kernel).  An earlier attempt
+// at the same loop -- TWO chains per lane in half as many waves, as the round-4 review suggested for a latency-bound loop -- made it slower
+// (194-207 against 120-123 us, profiles/r05_ab_follow_two_chains.txt): with eight waves to a SIMD on the two busy XCDs the loop was bound by
+// instruction issue there, not by any wave's latency.
+// LDSWIN (production, with k_prep_flow<.., true>'s 32 x 32-cell segments): the workgroup first copies the segment's neighbourhood of the
+// flow field -- the block and FW_HALO cells around it, clipped to the bordered field: at most 66 x 66 cells, 34 KB -- into LDS, and a step
+// of a wave whose taps ALL lie inside it reads them there (two ds_read2_b64 per lane: ~70 cycles in the dependent chain of a step instead of
+// the ~160 of two 16-byte gathers, and nothing for the CU's one texture addresser to serialise).  The values are the same values and so is
+// every operation on them; a wave of which some lane has left the window (a pixel further than FW_HALO cells from its segment: a long cell,
+// a noise field) takes the memory path for that step, all lanes together -- the decision is one ballot, the loop has no divergent branch.
+// GROUPED (production): the orbit-closure test is made once per four steps and for the wave as a whole.  tools/micro/follow_step.hip: of the
+// 534 cycles a lone wave spent per step, 190 were the dependent arithmetic, 158 the gathers and 186 the per-lane, per-step orbit tests
+// (four compares whose results travel vector -> scalar -> exec mask and back, two divergent breaks and the register copies of a
+// loop-carried (q, p) pair).  A lane whose orbit has closed recomputes its fixed point or 2-cycle at no cost to anyone until the last lane of
+// its wave has closed too -- the wave lasted that long before as well.
+#define FW_HALO 16
+#define FW_SIDE (FG_SIDE + 2 * FW_HALO + 2)
+struct FollowCtx {
+    const float *im; const float2 *win;
+    float hw, hh;
+    int W, H, TW, wx0, wy0, ww1, wh1;
+};
+// one Euler step: (px, py) -> (nx, ny)
+template <int LDSWIN>
+__device__ __forceinline__ void follow_step(const FollowCtx &c, float px, float py, float &nx, float &ny) {
+    float fx = __fmaf_rn(px + 1.0f, c.hw, -0.5f);
+    float fy = __fmaf_rn(py + 1.0f, c.hh, -0.5f);
+    float x_w = floorf(fx), y_n = floorf(fy);
+    float w = fx - x_w, e = 1.0f - w, n = fy - y_n, s = 1.0f - n;
+    float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+    flow4 a, b;                                                            // (dx, dy) at x0, (dx, dy) at x0+1; the row below
+    const int lx = (int)x_w + 1 - c.wx0, ly = (int)y_n + 1 - c.wy0;        // the north-west tap relative to the window
+    bool inside = LDSWIN && (unsigned)lx < (unsigned)c.ww1 && (unsigned)ly < (unsigned)c.wh1;
+    if constexpr (LDSWIN == 1) inside = __builtin_amdgcn_ballot_w64(!inside) == 0;        // the whole wave one way
+    if (inside) {
+        // inside the window is inside the bordered field: the clamps of the memory path are the identity here
+        // (volatile: without it the two paths' loads are merged into ONE flat load through a selected generic pointer)
+        typedef const volatile flow4 __attribute__((address_space(3))) *lds_taps;
+        a = *(lds_taps)((const __attribute__((address_space(3))) float2 *)c.win + ly * FW_SIDE + lx);
+        b = *(lds_taps)((const __attribute__((address_space(3))) float2 *)c.win + (ly + 1) * FW_SIDE + lx);
+    } else {
+        // positions are clamped to [-1, 1], so x0 is in [-1, W-1] and the 2x2 taps lie inside the bordered
+        // field (the min/max only keeps a NaN position from addressing outside the buffer)
+        int x0 = min(max((int)x_w, -1), c.W - 1), y0 = min(max((int)y_n, -1), c.H - 1);
+        const float *r0 = c.im + ((size_t)(y0 + 1) * c.TW + (x0 + 1)) * 2;
+        a = *reinterpret_cast<const flow4 *>(r0);
+        b = *reinterpret_cast<const flow4 *>(r0 + (size_t)c.TW * 2);
+    }
+    float dx = __fmaf_rn(b[2], se, __fmaf_rn(b[0], sw, __fmaf_rn(a[2], ne, a[0] * nw)));
+    float dy = __fmaf_rn(b[3], se, __fmaf_rn(b[1], sw, __fmaf_rn(a[3], ne, a[1] * nw)));
+    nx = px + dx; nx = nx < -1.0f ? -1.0f : (nx > 1.0f ? 1.0f : nx);
+    ny = py + dy; ny = ny < -1.0f ? -1.0f : (ny > 1.0f ? 1.0f : ny);
+}
+// LDSWIN: 0 = taps from memory, 1 = LDS window, wave-uniform choice per step (production), 2 = LDS window, per-lane choice (A/B)
+template <bool HIST, int LDSWIN, bool GROUPED>
+__global__ void __launch_bounds__(NTHR) k_follow(int niter, float shx, float shy,
                          float hw, float hh, int32_t *__restrict__ p_final,
                          float *__restrict__ p_float, PPLayout lay, void *ws, int early_exit) {
-    // workgroup b handles entries [256 (b & 3), 256 (b & 3) + 256) of foreground segment b >> 2
-    const int seg = blockIdx.x >> 2, ent = (blockIdx.x & 3) * NTHR + threadIdx.x;
-    if (ent >= WS(int, off_fgcnt)[seg]) return;
+    // workgroup b handles entries [256 q, 256 q + 256) of foreground segment b % nsegs, q = b / nsegs.  (Until round 5 it was segment b >> 2,
+    // q = b & 3.  With a fifth of the pixels in the foreground nearly every segment has fewer than 256 entries, i.e. the workgroups that run
+    // the 200 steps were the multiples of 4 -- and workgroups go round the 8 XCDs by their index: all of them sat on XCDs 0 and 4, eight
+    // waves to a SIMD, while six XCDs ran the ones that return at once.  That, not the gathers, was the 1 300 - 1 550 cycles per step.)
+    const int nsegs = gridDim.x / (FG_BLOCK / NTHR), quarter = blockIdx.x / nsegs;
+    const int seg = blockIdx.x - quarter * nsegs, ent = quarter * NTHR + threadIdx.x;
+    const int cnt = WS(int, off_fgcnt)[seg];
+    __shared__ float2 win[LDSWIN ? FW_SIDE * FW_SIDE : 1];
+    FollowCtx c;
+    c.im = WS(float, off_im); c.win = win; c.hw = hw; c.hh = hh; c.W = lay.W; c.H = lay.H; c.TW = lay.TW;
+    c.wx0 = 0; c.wy0 = 0; c.ww1 = 0; c.wh1 = 0;      // window origin (bordered-field cell) and its extent minus one
+    if constexpr (LDSWIN != 0) {
+        if (quarter * NTHR >= cnt) return;                  // (the whole workgroup: no barrier is skipped by a part of it)
+        const int by = seg / lay.nbx, bx = seg - by * lay.nbx;
+        c.wx0 = max(bx * FG_SIDE - FW_HALO, 0); c.wy0 = max(by * FG_SIDE - FW_HALO, 0);
+        const int ww = min(bx * FG_SIDE + FG_SIDE + FW_HALO + 2, c.TW) - c.wx0, wh = min(by * FG_SIDE + FG_SIDE + FW_HALO + 2, lay.TH) - c.wy0;
+        c.ww1 = ww - 1; c.wh1 = wh - 1;
+        const float2 *src = reinterpret_cast<const float2 *>(c.im) + (size_t)c.wy0 * c.TW + c.wx0;
+        // all of a thread's loads are issued before the first is stored: the field was written by the launch before this one, on whatever
+        // XCD, so every load is a trip to the Infinity Cache -- 18 of them one behind the other cost more than the window saves
+        constexpr int FW_LOADS = (FW_SIDE * FW_SIDE + NTHR - 1) / NTHR;
+        float2 v[FW_LOADS];
+#pragma unroll
+        for (int k = 0; k < FW_LOADS; ++k) {
+            const int i = threadIdx.x + k * NTHR, r = i / FW_SIDE, cc = i - r * FW_SIDE;
+            v[k] = src[(size_t)min(r, c.wh1) * c.TW + min(cc, c.ww1)];
+        }
+#pragma unroll
+        for (int k = 0; k < FW_LOADS; ++k) {
+            const int i = threadIdx.x + k * NTHR, r = i / FW_SIDE, cc = i - r * FW_SIDE;
+            if (i < FW_SIDE * FW_SIDE && r < wh && cc < ww) win[i] = v[k];
+        }
+        __syncthreads();
+    }
+    if (ent >= cnt) return;
     const int idx = WS(int, off_fg)[seg * FG_BLOCK + ent];
     size_t t = blockIdx.y;
-    const int H = lay.H, W = lay.W;
-    const float *im = WS(float, off_im);
-    const int TW = lay.TW;
+    const int W = lay.W;
     int y = idx / W, x = idx - y * W;
     float px = __fdiv_rn((float)x, shx);
     float py = __fdiv_rn((float)y, shy);
     px = px * 2.0f; px = px - 1.0f;
     py = py * 2.0f; py = py - 1.0f;
-    float qx = __int_as_float(0x7fc00000), qy = qx;      // position two steps back (NaN: never equal)
-    for (int it = 0; it < niter; ++it) {
-        float fx = __fmaf_rn(px + 1.0f, hw, -0.5f);
-        float fy = __fmaf_rn(py + 1.0f, hh, -0.5f);
-        float x_w = floorf(fx), y_n = floorf(fy);
-        float w = fx - x_w, e = 1.0f - w, n = fy - y_n, s = 1.0f - n;
-        float nw = s * e, ne = s * w, sw = n * e, se = n * w;
-        // positions are clamped to [-1, 1], so x0 is in [-1, W-1] and the 2x2 taps lie inside the bordered
-        // field (the min/max only keeps a NaN position from addressing outside the buffer)
-        int x0 = min(max((int)x_w, -1), W - 1), y0 = min(max((int)y_n, -1), H - 1);
-        const float *r0 = im + ((size_t)(y0 + 1) * TW + (x0 + 1)) * 2;
-        const flow4 a = *reinterpret_cast<const flow4 *>(r0);                 // (dx, dy) at x0, (dx, dy) at x0+1
-        const flow4 b = *reinterpret_cast<const flow4 *>(r0 + (size_t)TW * 2);
-        float dx = __fmaf_rn(b[2], se, __fmaf_rn(b[0], sw, __fmaf_rn(a[2], ne, a[0] * nw)));
-        float dy = __fmaf_rn(b[3], se, __fmaf_rn(b[1], sw, __fmaf_rn(a[3], ne, a[1] * nw)));
-        float nx = px + dx; nx = nx < -1.0f ? -1.0f : (nx > 1.0f ? 1.0f : nx);
-        float ny = py + dy; ny = ny < -1.0f ? -1.0f : (ny > 1.0f ? 1.0f : ny);
-        // The step is a pure function of the position, so the remaining iterations can be skipped EXACTLY
-        // once the orbit closes: a fixed point repeats forever, a 2-cycle alternates (+0 / -0 compare equal
-        // and behave identically: the next step starts with p + 1).  Anything else runs all niter steps.
-        if (early_exit && nx == px && ny == py) break;
-        if (early_exit && nx == qx && ny == qy) {                       // s[it+1] == s[it-1]
-            if (((niter - (it + 1)) & 1) == 0) { px = nx; py = ny; }
-            break;
+    // The step is a pure function of the position, so the remaining iterations can be skipped EXACTLY
+    // once the orbit closes: a fixed point repeats forever, a 2-cycle alternates (+0 / -0 compare equal
+    // and behave identically: the next step starts with p + 1).  Anything else runs all niter steps.
+    if constexpr (GROUPED) {
+        int it = 0;
+        for (; it + 4 <= niter; it += 4) {
+            float x1, y1, x2, y2, x3, y3, x4, y4;
+            follow_step<LDSWIN>(c, px, py, x1, y1);
+            follow_step<LDSWIN>(c, x1, y1, x2, y2);
+            follow_step<LDSWIN>(c, x2, y2, x3, y3);
+            follow_step<LDSWIN>(c, x3, y3, x4, y4);
+            px = x4; py = y4;
+            // s[it+4] == s[it+3] (fixed point) or == s[it+2] (2-cycle), in EVERY lane of the wave: the state after the niter - (it + 4)
+            // steps that remain is s[it+4] if that many is even, s[it+3] if odd (the same value for a fixed point)
+            const bool closed = (x4 == x3 && y4 == y3) || (x4 == x2 && y4 == y2);
+            if (early_exit && __builtin_amdgcn_ballot_w64(!closed) == 0) {
+                if ((niter - (it + 4)) & 1) { px = x3; py = y3; }
+                it = niter;
+                break;
+            }
         }
-        qx = px; qy = py; px = nx; py = ny;
+        for (; it < niter; ++it) {                  // niter % 4 steps
+            float nx, ny;
+            follow_step<LDSWIN>(c, px, py, nx, ny);
+            px = nx; py = ny;
+        }
+    } else {
+        float qx = __int_as_float(0x7fc00000), qy = qx;      // position two steps back (NaN: never equal)
+        for (int it = 0; it < niter; ++it) {
+            float nx, ny;
+            follow_step<LDSWIN>(c, px, py, nx, ny);
+            if (early_exit && nx == px && ny == py) break;
+            if (early_exit && nx == qx && ny == qy) {                       // s[it+1] == s[it-1]
+                if (((niter - (it + 1)) & 1) == 0) { px = nx; py = ny; }
+                break;
+            }
+            qx = px; qy = py; px = nx; py = ny;
+        }
     }
     px = px + 1.0f; px = px * 0.5f; px = px * shx;
     py = py + 1.0f; py = py * 0.5f; py = py * shy;
@@ -1676,9 +1787,42 @@ static int pp_check(int nT, int H, int W) {
 }
 
 CPX_SWITCH(g_follow_early, 1);      // exact orbit-closure early exit of the Euler loop (debug / A-B switch)
+CPX_SWITCH(g_follow_lds, 3);        // bit 0 = 32 x 32-cell segments + the LDS window, bit 1 = the orbit test once per four steps and per wave; 3 = production, 0 = round 4 (A/B)
 #ifdef CPX_DEBUG
 extern "C" void cpx_follow_set_early_exit(int on) { g_follow_early = on; }
+extern "C" void cpx_follow_set_lds_window(int on) { g_follow_lds = on; }
 #endif
+// a11's two launches (INIT / HIST: the fused chain's forms)
+template <bool FUSED>
+static void pp_launch_follow(const float *dP, const float *cellprob, int nT, int H, int W, float thr, int niter, int32_t *p_final,
+                             float *p_float, const PPLayout &lay, void *ws, hipStream_t s) {
+    const float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
+    const float shx = (float)(W - 1), shy = (float)(H - 1), hw = (float)W / 2.0f, hh = (float)H / 2.0f;
+    const dim3 g2(lay.nseg, nT), g2f(lay.nseg * (FG_BLOCK / NTHR), nT);
+#define FOLLOW_ARGS niter, shx, shy, hw, hh, p_final, p_float, lay, ws, g_follow_early
+    if (g_follow_lds == 3) {                // production: LDS window (wave-uniform choice), grouped orbit test
+        PP_LAUNCH((k_prep_flow<FUSED, true>), g2, dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
+        PP_LAUNCH((k_follow<FUSED, 1, true>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS);
+        return;
+    }
+#ifdef CPX_DEBUG
+    const int nlin = cpx_cdiv(lay.THW, FG_BLOCK);
+    const dim3 g1(nlin, nT), g1f(nlin * (FG_BLOCK / NTHR), nT);
+    if (g_follow_lds & 1) PP_LAUNCH((k_prep_flow<FUSED, true>), g2, dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
+    else PP_LAUNCH((k_prep_flow<FUSED, false>), g1, dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
+    switch (g_follow_lds) {
+    case 0: PP_LAUNCH((k_follow<FUSED, 0, false>), g1f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;      // round 4
+    case 1: PP_LAUNCH((k_follow<FUSED, 1, false>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;      // the window alone
+    case 2: PP_LAUNCH((k_follow<FUSED, 0, true>), g1f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;       // the grouped test alone
+    case 9: PP_LAUNCH((k_follow<FUSED, 0, false>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;      // 32 x 32 segments, taps from memory
+    case 11: PP_LAUNCH((k_follow<FUSED, 0, true>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;      // 32 x 32 segments, taps from memory, grouped test
+    case 5: PP_LAUNCH((k_follow<FUSED, 2, false>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;      // window, per-lane choice
+    case 7: PP_LAUNCH((k_follow<FUSED, 2, true>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;       // window, per-lane choice, grouped test
+    default: PP_LAUNCH((k_follow<FUSED, 1, true>), g2f, dim3(NTHR), 0, s, FOLLOW_ARGS); break;
+    }
+#endif
+#undef FOLLOW_ARGS
+}
 
 extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, int H, int W,
                                 float thr, int niter, int32_t *p_final, float *p_float, void *ws,
@@ -1688,11 +1832,7 @@ extern "C" int cpx_follow_flows(const float *dP, const float *cellprob, int nT, 
     hipStream_t s = (hipStream_t)stream;
     PPLayout lay = pp_layout(H, W);
     ws = pp_tiles(ws, nT, H, W);
-    float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
-    PP_LAUNCH(k_prep_flow<false>, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, p_float, lay, ws);
-    PP_LAUNCH(k_follow<false>, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
-                       (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final,
-                       p_float, lay, ws, g_follow_early);
+    pp_launch_follow<false>(dP, cellprob, nT, H, W, thr, niter, p_final, p_float, lay, ws, s);
     CPX_CHECK_LAUNCH();
     return CPX_OK;
 }
@@ -1880,10 +2020,7 @@ static int compute_masks_fused(const float *dP, const float *cellprob, const flo
     void *ws = pp_tiles(ws0, nT, H, W);
     const PPLayout L0 = lay, L1 = lay_set(lay, 1), L2 = lay_set(lay, 2), L3 = lay_set(lay, 3), L4 = lay_set(lay, 4), L5 = lay_set(lay, 5);
     // a11: flow field + foreground list + the chain's one initialisation pass; Euler loop + histogram
-    const float kx = (float)(2.0 / (double)(W - 1)), ky = (float)(2.0 / (double)(H - 1));
-    PP_LAUNCH(k_prep_flow<true>, dim3(cpx_cdiv(lay.THW, FG_BLOCK), nT), dim3(FG_BLOCK), 0, s, dP, cellprob, thr, kx, ky, p_final, (float *)nullptr, lay, ws);
-    PP_LAUNCH(k_follow<true>, dim3(cpx_cdiv(lay.THW, FG_BLOCK) * (FG_BLOCK / NTHR), nT), dim3(NTHR), 0, s, niter,
-              (float)(W - 1), (float)(H - 1), (float)W / 2.0f, (float)H / 2.0f, p_final, (float *)nullptr, lay, ws, g_follow_early);
+    pp_launch_follow<true>(dP, cellprob, nT, H, W, thr, niter, p_final, (float *)nullptr, lay, ws, s);
     // a12: seeds, growth, gather (+ big-label removal and ranks in its last workgroup)
     PP_LAUNCH(k_seeds, GRID_PAD(lay, nT), dim3(NTHR), 0, s, L0, ws);
     PP_LAUNCH(k_seed_grow, dim3(SEED_WGS, nT), dim3(NTHR), 0, s, L0, ws);

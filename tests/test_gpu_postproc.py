@@ -51,6 +51,75 @@ def test_follow_flows_bit_exact(cuda, kind, H, W, seed):
     assert np.all(pf.cpu().numpy()[0].reshape(H, W)[cp <= 0] == -1)
 
 
+@pytest.mark.parametrize("niter", [0, 1, 2, 3, 4, 5, 7, 9, 38, 199, 201, 203])
+def test_follow_flows_step_counts_bit_exact(cuda, niter):
+    """The Euler loop runs in groups of four steps with the orbit-closure test once per group and per wave
+    (k_follow<.., GROUPED>): every remainder (niter % 4), counts below one group, and BOTH parities of the steps that
+    remain when a wave's orbits close (discs: fixed points and 2-cycles after ~10 steps) must land where the plain
+    loop does.  Reference: cellpose steps_interp through models.py:149-159."""
+    for kind, H, W, seed in (("discs", 96, 128, 11), ("noisy_discs", 67, 45, 12)):
+        dP, cp, _ = _fields(kind, H, W, seed)
+        _, fl = ops.follow_flows(torch.from_numpy(dP).to(cuda), torch.from_numpy(cp).to(cuda), niter=niter, return_float=True)
+        inds = np.nonzero(cp > 0)
+        ref = cref.follow_flows(dP * (cp > 0) / 5.0, inds, niter)
+        assert np.array_equal(fl.cpu().numpy()[0].reshape(2, H, W)[:, inds[0], inds[1]], ref), (kind, niter)
+
+
+@pytest.mark.parametrize("H,W", [(2, 2), (3, 70), (31, 33), (33, 31), (64, 64), (65, 130)])
+def test_follow_flows_long_travel_leaves_the_lds_window(cuda, H, W):
+    """A constant flow carries every pixel across the tile (far more than the 16-cell halo of the 32 x 32-cell
+    segment's LDS window), a vortex keeps them moving for all 200 steps: the steps of a wave that has left its window
+    read the field from memory, the result is the plain loop's.  Sizes around the segment grid (one cell short / over),
+    a single segment, and the 2 x 2 minimum."""
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    cases = {"constant": np.stack([np.full((H, W), 3.5, np.float32), np.full((H, W), -4.25, np.float32)]),
+             "vortex": np.stack([(xx - W / 2) * 0.4, -(yy - H / 2) * 0.4]).astype(np.float32)}
+    cp = np.ones((H, W), np.float32)
+    cp[::7, ::5] = -1.0
+    for name, dP in cases.items():
+        _, fl = ops.follow_flows(torch.from_numpy(dP).to(cuda), torch.from_numpy(cp).to(cuda), niter=200, return_float=True)
+        inds = np.nonzero(cp > 0)
+        ref = cref.follow_flows(dP * (cp > 0) / 5.0, inds, 200)
+        assert np.array_equal(fl.cpu().numpy()[0].reshape(2, H, W)[:, inds[0], inds[1]], ref), name
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (97, 131)])
+def test_follow_flows_variants_are_bitwise_equal(cuda, H, W):
+    """Round 5's Euler loop (32 x 32-cell foreground segments, taps from an LDS window with a wave-uniform choice per step,
+    orbit test once per four steps and per wave) against every form it replaced or was measured against (debug-build switch
+    cpx_follow_set_lds_window: 0 = round 4's loop, 2 / 9 / 11 = one change at a time, 1 / 5 / 7 = the window with the per-step test
+    / per-lane choice), with and without the early exit: end points bit-identical on discs, noisy discs and smooth random
+    fields; product library == debug library at its defaults."""
+    from classpose_amd import _lib
+    tiles = [_fields(k, H, W, s) for k, s in (("discs", 31), ("noisy_discs", 32), ("random", 33))]
+    dP = torch.from_numpy(np.stack([t[0] for t in tiles])).to(cuda)
+    cp = torch.from_numpy(np.stack([t[1] for t in tiles])).to(cuda)
+
+    def run(L, niter):
+        pf = torch.empty((3, H * W), dtype=torch.int32, device=cuda)
+        fl = torch.empty((3, 2, H * W), dtype=torch.float32, device=cuda)
+        ws = torch.empty(L.cpx_postproc_workspace_bytes(3, H, W), dtype=torch.uint8, device=cuda)
+        _lib.check(L.cpx_follow_flows(dP.data_ptr(), cp.data_ptr(), 3, H, W, 0.0, niter, pf.data_ptr(), fl.data_ptr(), ws.data_ptr(),
+                                      torch.cuda.current_stream(cuda).cuda_stream), "follow_flows")
+        torch.cuda.synchronize(cuda)
+        return pf.cpu().numpy(), fl.cpu().numpy()
+
+    product = {n: run(_lib.lib(), n) for n in (200, 37)}
+    with _lib.use_debug_library() as L:
+        try:
+            for n in (200, 37):
+                assert all(np.array_equal(a, b) for a, b in zip(product[n], run(L, n)))
+                for early in (1, 0):
+                    L.cpx_follow_set_early_exit(early)
+                    for v in (0, 1, 2, 3, 5, 7, 9, 11):
+                        L.cpx_follow_set_lds_window(v)
+                        got = run(L, n)
+                        assert all(np.array_equal(a, b) for a, b in zip(product[n], got)), (n, early, v)
+        finally:
+            L.cpx_follow_set_early_exit(1)
+            L.cpx_follow_set_lds_window(3)
+
+
 def test_follow_flows_torch_pin_small(cuda):
     """the literal torch path, not only its C restatement"""
     dP, cp, _ = _fields("noisy_discs", 64, 80, 7)
