@@ -847,7 +847,9 @@ __global__ void k_center_pick(const int32_t *__restrict__ masks, PPLayout lay, v
 
 // heat diffusion from the centre inside one label (fp64 Jacobi, 9-neighbour mean
 // summed in neighbour order 0..8 then / 9).  One workgroup per (label, tile).
-#define DIFF_LDS_CELLS 3584     // (bh+2)*(bw+2) <= this -> T ping-pong in LDS (56 KB) + flags
+#define DIFF_LDS_CELLS 2944     // (bh+2)*(bw+2) <= this -> T ping-pong in LDS (46 KB) + the cell list (6 KB) = 52 KB: THREE workgroups per CU.  (3584 until round 5:
+                                // 64.5 KB, two per CU = 512 slots for the ~650 labels of the bench's 8-tile batch, i.e. a second round: 43.6 -> 32.9 us.
+                                // A cell list in raster order instead of the order an LDS atomic hands out slots changed nothing: 34.2 us.)
 // s / 9.0 correctly rounded without the IEEE division sequence (v_div_scale / v_rcp_f64 / v_div_fmas / v_div_fixup):
 // q = RN(s * c) with c = RN(1/9) is within 1 ulp of s / 9, r = s - 9 q is exact in one fma, and RN(q + r * c) is the
 // correctly rounded quotient (Markstein's FMA division finish; a quotient of two doubles is never a rounding tie).
