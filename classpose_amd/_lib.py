@@ -21,7 +21,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 DTYPE_CODE = {"bf16": DT_BF16, "fp16": DT_F16, "fp32": DT_F32}
 PROF_KINDS = ("fc1", "attention", "qkv", "proj", "fc2", "patch_embed", "neck_head")
 # the kernel behind kind "fc1" (the dominant launch of the network; its name as rocprofv3 prints it)
-FC1_KERNEL_NAME = "k_gemm4w<GELU + folded LayerNorm, one wave per SIMD> = void k_gemm4w<1, 0>(Gemm4wArgs)"
+FC1_KERNEL_NAME = "k_gemm4w<GELU + folded LayerNorm, one wave per SIMD> = void k_gemm4w<1, 0, false>(Gemm4wArgs)"
 
 
 class CpxTiling(C.Structure):

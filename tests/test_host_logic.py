@@ -247,6 +247,20 @@ def test_library_reports_the_sources_it_was_built_from():
     assert L.cpx_build_id().decode() == _lib.source_build_id()
 
 
+def test_dominant_kernel_name_the_bench_searches_for_is_a_kernel_of_the_product_library():
+    """bench.py's live roofline.traffic passes (rocprofv3 --pmc over tools/pmc_fc1.py) and tools/r05_make_profiles.py pick the
+    dominant kernel's rows by the name rocprofv3 prints, _lib.FC1_KERNEL_NAME.  When the fp16 instantiation gave the kernel a third
+    template argument the name went stale and the driver line fell back to the committed profile (with its reason, but fell back):
+    the name must be a kernel symbol of the library as built."""
+    import subprocess
+    name = _lib.FC1_KERNEL_NAME.split(" = ")[1]
+    so = os.path.join(os.path.dirname(_lib.__file__), "libclasspose_hip.so")
+    syms = subprocess.run(["nm", "-C", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert re.search(r"\b[VW] " + re.escape(name) + r"$", syms, re.M), name
+    src = open(os.path.join(os.path.dirname(os.path.dirname(_lib.__file__)), "tools", "r05_make_profiles.py")).read()
+    assert name.split("(")[0] in src
+
+
 def test_isa_lint_no_lds_load_is_consumed_before_its_wait():
     """tools/lint_isa.py on the built libraries (CPU only: llvm-objdump of the bundled gfx950 code objects): no instruction reads the
     destination of an LDS load before an s_waitcnt lgkmcnt that covers it.  The inline-asm fragment reads of the hot kernels are only kept

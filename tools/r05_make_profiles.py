@@ -16,7 +16,7 @@ gemm_bytes = lambda n, k, extra=0: 2.0 * (M * k + n * k + M * n) + extra
 # kernel-name prefix -> (what, algorithmic flops per launch, algorithmic bytes per launch)
 KERNELS = [
     # round 5: the MLP runs in two row parts of 16 384 tokens (cpx_net_mlp_parts): an mlp.lin1 / mlp.lin2 LAUNCH covers M / 2 rows
-    ("void k_gemm4w<1, 0>", "mlp.lin1 (fc1, GELU + folded LayerNorm): one wave per SIMD, persistent; 16 384 rows per launch (two launches per layer)", gemm_flops(HID, C) / 2, gemm_bytes(HID, C) / 2 + HID * C),
+    ("void k_gemm4w<1, 0, false>", "mlp.lin1 (fc1, GELU + folded LayerNorm): one wave per SIMD, persistent; 16 384 rows per launch (two launches per layer)", gemm_flops(HID, C) / 2, gemm_bytes(HID, C) / 2 + HID * C),
     ("void k_gemm256p<1, false, 33>", "mlp.lin1 (fc1, GELU + folded LayerNorm, direct-store epilogue), 8-wave kernel", gemm_flops(HID, C), gemm_bytes(HID, C)),
     ("void k_gemm256p<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), persistent with the balanced tile list", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
     ("void k_gemm256<6, false, 1>", "attn.qkv (+ V^T epilogue, folded LayerNorm), one workgroup per tile", gemm_flops(3 * C, C), gemm_bytes(3 * C, C)),
