@@ -94,3 +94,30 @@ def test_resize_tile_to_target_mpp_bit_exact(cuda, shape, factor):
     for k in range(2):
         want = otiling.resize_linear_u8(tiles[k], dw, dh) if factor != 1.0 else tiles[k]
         assert np.array_equal(got[k], want)
+
+
+def test_tile_stream_gate_holds_all_but_the_first_gated_batch_off_the_device(cuda):
+    """bench.py's timed region starts with ONE batch resident on the device and none handed over (TileStream gate_at / parked /
+    release): batches before the gate flow, the reader parks with the gated batch copied, nothing reaches the consumer until
+    release(), and afterwards every batch arrives in order with the slide's pixels (entrypoints/predict_wsi.py: TileStream._run)."""
+    import queue
+    import time
+    from classpose_amd import wsi
+    from classpose_amd.entrypoints.predict_wsi import TileStream
+    slide = synth.SyntheticSlide(2048, 2048, mpp=0.5, seed=7)
+    plan = wsi.plan_slide(slide, 256, 32, 0.5)
+    idxs = list(range(24))                                   # 6 batches of 4 tiles
+    with TileStream(slide, plan, idxs, 4, 256, 256, cuda, autostart=False, gate_at=2) as ts:
+        ts.start()
+        it = iter(ts)
+        got = [next(it) for _ in range(2)]                   # the two batches in front of the gate
+        assert ts.parked.wait(timeout=60.0)                  # batch 2: decoded, copied, waiting at the gate
+        time.sleep(0.3)
+        assert ts.q.empty() and not ts.gate.is_set()         # ... and not handed over; batch 3 not even copied (the reader thread is parked)
+        ts.release()
+        got += list(it)
+        assert [list(g[0]) for g in got] == [idxs[4 * b:4 * b + 4] for b in range(6)]
+        for chunk, tiles_dev, ev, _extra in got:
+            ev.synchronize()
+            want = np.stack([wsi.read_tile(slide, plan, plan.coords[ti]) for ti in chunk])
+            assert np.array_equal(tiles_dev.cpu().numpy(), want)
