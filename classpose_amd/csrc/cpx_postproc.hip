@@ -205,7 +205,8 @@ typedef float flow4 __attribute__((ext_vector_type(4), aligned(8)));
 // wave, so each of its two gathers per step touches up to 64 different cache lines and the CU's one texture addresser serialises them: 32 x 32
 // -cell segments give a wave the pixels of two rows of ONE block, which converge onto a handful of centres (84.6 against 118.4 us for a11).
 // (2) The per-lane, per-step orbit tests were a third of the lone wave's step (GROUPED below: 67.1 us).  (3) The workgroups that had anything
-// to do were the multiples of four, i.e. all on two of the eight XCDs (see the index arithmetic at the top of the kernel).  An earlier attempt
+// to do were the multiples of four, i.e. all on two of the eight XCDs (see the index arithmetic at the top of the kernel): worth 3 % while the
+// gathers bound every wave wherever it ran, and 113.6 -> 65.4 us for the kernel as it is now.  An earlier attempt
 // at the same loop -- TWO chains per lane in half as many waves, as the round-4 review suggested for a latency-bound loop -- made it slower
 // (194-207 against 120-123 us, profiles/r05_ab_follow_two_chains.txt): with eight waves to a SIMD on the two busy XCDs the loop was bound by
 // instruction issue there, not by any wave's latency.
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(NTHR) k_follow(int niter, float shx, float shy
     // workgroup b handles entries [256 q, 256 q + 256) of foreground segment b % nsegs, q = b / nsegs.  (Until round 5 it was segment b >> 2,
     // q = b & 3.  With a fifth of the pixels in the foreground nearly every segment has fewer than 256 entries, i.e. the workgroups that run
     // the 200 steps were the multiples of 4 -- and workgroups go round the 8 XCDs by their index: all of them sat on XCDs 0 and 4, eight
-    // waves to a SIMD, while six XCDs ran the ones that return at once.  That, not the gathers, was the 1 300 - 1 550 cycles per step.)
+    // waves to a SIMD, while six XCDs ran the ones that return at once.)
     const int nsegs = gridDim.x / (FG_BLOCK / NTHR), quarter = blockIdx.x / nsegs;
     const int seg = blockIdx.x - quarter * nsegs, ent = quarter * NTHR + threadIdx.x;
     const int cnt = WS(int, off_fgcnt)[seg];
