@@ -136,6 +136,7 @@ _PRIVATE = {
     "cpx_attention_set_trv": (None, [_i]),
     "cpx_attention_set_lsum": (None, [_i]),
     "cpx_attention_set_variant": (None, [_i]),
+    "cpx_gemm_set_nt": (None, [_i]),
     "cpx_follow_set_early_exit": (None, [_i]),
     "cpx_follow_set_lds_window": (None, [_i]),
     "cpx_gemm_set_reverse": (None, [_i]),

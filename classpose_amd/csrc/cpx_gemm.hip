@@ -31,6 +31,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define TILE_BYTES (128 * 128)          // one operand tile: 128 rows x 64 k x 2 B
 #define STAGE_BYTES (2 * TILE_BYTES)
 
+// 16-byte store of an epilogue, optionally non-temporal.  Production for the qkv projection (g.nt_out): its 268 MB of output (q | k rows and
+// the V^T image) pass through the 256 MB Infinity Cache once on their way to the attention kernel and push everything else out of it -- the
+// residual stream that attn.proj's epilogue adds, the weights; with the hint they do not stay.  In situ (tools/ab_stage_switch.py
+// cpx_gemm_set_nt=0,1, launch medians): qkv 181.2 -> 177.5 us, attn.proj 72.6 -> 70.4, attention 181.9 -> 183.6 (its K / V^T tiles now
+// come from HBM): -4 us per layer, engine step 21.34 -> 21.24 ms, same bits.  (The same hint on the attention kernel's K / V^T REQUESTS
+// loses the L2 sharing of the eight query blocks of a head: 184 -> 199 us, profiles/r05_ab_nontemporal.txt.)
+template <bool NT_POSSIBLE>
+__device__ __forceinline__ void st16(void *p, uint4 v, bool nt) {
+    if (NT_POSSIBLE && nt) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+    } else {
+        *reinterpret_cast<uint4 *>(p) = v;
+    }
+}
 struct GemmArgs {
     const unsigned short *A;
     const unsigned short *W;
@@ -43,6 +59,7 @@ struct GemmArgs {
     int l2_block;           // 1 / 2: 8 x 4 super-tile order per XCD, N-sweep / M-sweep (debug switch, default 1)
     int rev_m;              // 1: walk the M tiles from the last row block to the first (see gemm_launch)
     int dbg;                // timing-only ablations of the 256^2 epilogue (0 in production)
+    int nt_out;             // qkv epilogue: 1 = the output leaves by non-temporal stores (production; 0: debug-build A/B)
     // LayerNorm folded into the GEMM (consumer side): out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
     // with W pre-multiplied by gamma, bias = b + W.beta, colsum[n] = sum_k W'[n][k]
     const float *ln_stats;   // [M][4][2] partial (sum, sum of squares) of the K = 1024 input row, or null
@@ -1094,7 +1111,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                 const int row = it * 16 + (tid >> 5);
                 const int c = n0 - 2048 + row;
                 uint4 vv = *reinterpret_cast<const uint4 *>(smem + row * G2_EPI_LD + c16 * 16);
-                *reinterpret_cast<uint4 *>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8) = vv;
+                st16<EPI == CPX_EPI_QKV_BF16>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8, vv, g.nt_out != 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G2_BAR();
@@ -1317,7 +1334,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                         }
                         vv = make_uint4(a[0], a[1], a[2], a[3]);
                     }
-                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) *reinterpret_cast<uint4 *>((unsigned short *)g.out + go) = vv;
+                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16>((unsigned short *)g.out + go, vv, g.nt_out != 0);
                     if constexpr (STATS) {
                         unsigned a[4] = {vv.x, vv.y, vv.z, vv.w};
                         float sm = 0.f, sq = 0.f;
@@ -1645,6 +1662,7 @@ CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of th
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
+CPX_SWITCH(g_gemm_nt, 1);           // 1 = the qkv projection's outputs leave by non-temporal stores (production), 0 = ordinary stores (A/B)
 CPX_SWITCH(g_gemm_4w, 1);           // bit 0 (production): mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel (cpx_gemm4w.hip), 0.98 of k_gemm256p;
                                     // bit 1 (debug build, measured and NOT shipped): attn.proj / mlp.lin2 (residual + row statistics) on it as well -- 1.06 / 1.03 of
                                     // k_gemm256p (profiles/r05_ab_gemm4w_resid.txt): that epilogue is unpacked integer / f32 vector work, which a lone wave issues at
@@ -1666,6 +1684,7 @@ extern "C" void cpx_gemm_set_direct(int on) { g_gemm_direct = on; }
 extern "C" void cpx_gemm_set_balanced(int on) { g_gemm_bal = on; }
 extern "C" void cpx_gemm_set_pingpong(int on) { g_gemm_pp = on; }
 extern "C" void cpx_gemm_set_4w(int on) { g_gemm_4w = on; }
+extern "C" void cpx_gemm_set_nt(int on) { g_gemm_nt = on; }
 extern "C" void cpx_gemm_set_pingpong_opts(int persistent, int delay) { g_gemm_pp_persist = persistent; g_gemm_pp_delay = delay; }
 #endif
 
@@ -1920,7 +1939,7 @@ int cpx_gemm_half(int dtype, const void *A, const void *Wt, int M, int N, int K,
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.aux = aux; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
-    a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg;
+    a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.stats_out = stats_out; a.l2_block = g_gemm_l2; a.dbg = g_gemm_dbg; a.nt_out = g_gemm_nt;
     a.rev_m = (g_gemm_rev && K >= 4096) ? 1 : 0;
     a.conv_c = 0; a.pp_delay = 0; a.epi4 = g_gemm_epi4;
     hipStream_t s = (hipStream_t)stream;
@@ -1951,7 +1970,7 @@ int cpx_conv3_half(int dtype, const void *x, const void *Wt, int M, int N, int C
     a.A = (const unsigned short *)x; a.W = (const unsigned short *)Wt;
     a.M = M; a.N = N; a.K = 9 * C; a.bias = bias; a.aux = nullptr; a.out = out; a.ld_out = ld_out;
     a.tiles_n = N / BN; a.n_blocks = (M / BM) * (N / BN);
-    a.ln_stats = nullptr; a.ln_colsum = nullptr; a.stats_out = nullptr; a.l2_block = 0; a.dbg = 0; a.rev_m = 0;
+    a.ln_stats = nullptr; a.ln_colsum = nullptr; a.stats_out = nullptr; a.l2_block = 0; a.dbg = 0; a.rev_m = 0; a.nt_out = 0;
     a.conv_c = C; a.pp_delay = 0; a.epi4 = 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(a.n_blocks), block(GEMM_THREADS);

@@ -720,7 +720,8 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
 // tiles neither OR their packed probabilities nor vote nor branch.  bf16 has float32's exponent range, so a probability above 2 is as accurate as one
 // below (the rescale of the production kernel only matters for fp16's range); what is lost is the guard against float32 overflow when a later score
 // exceeds the first tile's maximum by > ~80 octaves -- a production form would have to test the row sums for finiteness and re-run such an item.
-template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false, bool NV = false>
+// NTL (round-5 experiment, debug build): the K / V^T ring requests carry the non-temporal hint
+template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false, bool NV = false, bool NTL = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
                                                                 const unsigned short *__restrict__ relh,
@@ -753,9 +754,9 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     auto issue = [&](int kh) {
         char *d = dma_dst + (kh & 3) * A4_SLOT;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ksrc + (size_t)kh * 32 * 3072),
-                                         (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)d, 16, 0, NTL ? 2 : 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc + kh * 32),
-                                         (__attribute__((address_space(3))) void *)(d + 4096), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(d + 4096), 16, 0, NTL ? 2 : 0);
     };
     issue(0); issue(1); issue(2);
 
@@ -1095,6 +1096,14 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         static CpxOncePerDevice once4n;
         once4n([] { (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); });
         hipLaunchKernelGGL((k_attention4p<false, false, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                           (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
+    if (g_att_lsum == 4 && dtype != CPX_DT_F16) {           // round-5 experiment: non-temporal K / V^T requests (k_attention4p<.., NTL>), bf16
+        static CpxOncePerDevice once4t;
+        once4t([] { (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); });
+        hipLaunchKernelGGL((k_attention4p<false, false, false, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
                            (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
         CPX_CHECK_LAUNCH();
         return CPX_OK;

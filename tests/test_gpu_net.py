@@ -631,8 +631,9 @@ def test_benched_path_depth24_32_subtiles_vs_oracle(cuda, precision):
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_net_forward_is_bitwise_independent_of_the_round5_switches(cuda, precision):
     """Round 5 changed HOW a forward runs, not what it computes: mlp.lin1 on the one-wave-per-SIMD kernel (bf16 and fp16 instantiations) and the
-    MLP in row parts of 16 384 tokens.  The whole head tensor of a 32-sub-tile, 3-block forward is bit for bit the same with both switched off
-    (cpx_gemm_set_4w(0), cpx_net_set_mlp_parts(0): the round-4 path), each on alone, and both on (production)."""
+    MLP in row parts of 16 384 tokens, the qkv projection's outputs by non-temporal stores.  The whole head tensor of a 32-sub-tile, 3-block
+    forward is bit for bit the same with all switched off (cpx_gemm_set_4w(0), cpx_net_set_mlp_parts(0), cpx_gemm_set_nt(0): the round-4
+    path), in mixed settings, and all on (production)."""
     import ctypes as C
     nS, depth = 32, 3
     sd = synth.make_state_dict(7, None, depth=depth, seed=5)
@@ -653,11 +654,11 @@ def test_net_forward_is_bitwise_independent_of_the_round5_switches(cuda, precisi
     assert _lib.lib().cpx_net_mlp_parts(nS, w_dtype := _lib.DTYPE_CODE[precision]) == 2 and _lib.lib().cpx_net_mlp_parts(16, w_dtype) == 1
     with _lib.use_debug_library() as L:
         try:
-            for g4, parts in ((0, 0), (1, 0), (0, 1), (1, 1)):
-                L.cpx_gemm_set_4w(g4); L.cpx_net_set_mlp_parts(parts)
-                assert torch.equal(forward(L), prod), (g4, parts)
+            for g4, parts, nt in ((0, 0, 0), (1, 0, 1), (0, 1, 1), (1, 1, 0), (1, 1, 1)):
+                L.cpx_gemm_set_4w(g4); L.cpx_net_set_mlp_parts(parts); L.cpx_gemm_set_nt(nt)
+                assert torch.equal(forward(L), prod), (g4, parts, nt)
         finally:
-            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1)
+            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1); L.cpx_gemm_set_nt(1)
 
 
 def test_engine_fp16_512px_vs_oracle(cuda):
