@@ -59,7 +59,7 @@ struct GemmArgs {
     int l2_block;           // 1 / 2: 8 x 4 super-tile order per XCD, N-sweep / M-sweep (debug switch, default 1)
     int rev_m;              // 1: walk the M tiles from the last row block to the first (see gemm_launch)
     int dbg;                // timing-only ablations of the 256^2 epilogue (0 in production)
-    int nt_out;             // qkv epilogue: 1 = the output leaves by non-temporal stores (production; 0: debug-build A/B)
+    int nt_out;             // qkv epilogue: bits 0 / 1 / 2 = the q / k / V^T tiles leave by non-temporal stores (7 in production; debug-build A/B)
     // LayerNorm folded into the GEMM (consumer side): out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
     // with W pre-multiplied by gamma, bias = b + W.beta, colsum[n] = sum_k W'[n][k]
     const float *ln_stats;   // [M][4][2] partial (sum, sum of squares) of the K = 1024 input row, or null
@@ -1111,7 +1111,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                 const int row = it * 16 + (tid >> 5);
                 const int c = n0 - 2048 + row;
                 uint4 vv = *reinterpret_cast<const uint4 *>(smem + row * G2_EPI_LD + c16 * 16);
-                st16<EPI == CPX_EPI_QKV_BF16>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8, vv, g.nt_out != 0);
+                st16<EPI == CPX_EPI_QKV_BF16>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8, vv, (g.nt_out & 4) != 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G2_BAR();
@@ -1334,7 +1334,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                         }
                         vv = make_uint4(a[0], a[1], a[2], a[3]);
                     }
-                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16>((unsigned short *)g.out + go, vv, g.nt_out != 0);
+                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16>((unsigned short *)g.out + go, vv, (g.nt_out & (n0 < 1024 ? 1 : 2)) != 0);
                     if constexpr (STATS) {
                         unsigned a[4] = {vv.x, vv.y, vv.z, vv.w};
                         float sm = 0.f, sq = 0.f;
@@ -1662,7 +1662,7 @@ CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of th
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
-CPX_SWITCH(g_gemm_nt, 1);           // 1 = the qkv projection's outputs leave by non-temporal stores (production), 0 = ordinary stores (A/B)
+CPX_SWITCH(g_gemm_nt, 7);           // bits 0 / 1 / 2: the q / k / V^T thirds of the qkv projection's output leave by non-temporal stores (7 = production), 0 = ordinary stores (A/B)
 CPX_SWITCH(g_gemm_4w, 1);           // bit 0 (production): mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel (cpx_gemm4w.hip), 0.98 of k_gemm256p;
                                     // bit 1 (debug build, measured and NOT shipped): attn.proj / mlp.lin2 (residual + row statistics) on it as well -- 1.06 / 1.03 of
                                     // k_gemm256p (profiles/r05_ab_gemm4w_resid.txt): that epilogue is unpacked integer / f32 vector work, which a lone wave issues at

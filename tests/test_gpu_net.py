@@ -654,11 +654,11 @@ def test_net_forward_is_bitwise_independent_of_the_round5_switches(cuda, precisi
     assert _lib.lib().cpx_net_mlp_parts(nS, w_dtype := _lib.DTYPE_CODE[precision]) == 2 and _lib.lib().cpx_net_mlp_parts(16, w_dtype) == 1
     with _lib.use_debug_library() as L:
         try:
-            for g4, parts, nt in ((0, 0, 0), (1, 0, 1), (0, 1, 1), (1, 1, 0), (1, 1, 1)):
+            for g4, parts, nt in ((0, 0, 0), (1, 0, 1), (0, 1, 6), (1, 1, 0), (1, 1, 7)):
                 L.cpx_gemm_set_4w(g4); L.cpx_net_set_mlp_parts(parts); L.cpx_gemm_set_nt(nt)
                 assert torch.equal(forward(L), prod), (g4, parts, nt)
         finally:
-            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1); L.cpx_gemm_set_nt(1)
+            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1); L.cpx_gemm_set_nt(7)
 
 
 def test_engine_fp16_512px_vs_oracle(cuda):
