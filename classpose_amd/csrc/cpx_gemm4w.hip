@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
                         const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);
                         const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);
                         const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, (VAR & 512) ? 2 : 0);   // (VAR & 512, debug build: non-temporal)
                         G4_SB();                                                 // (keeps the scheduler from hoisting all 256 accumulator reads: the next tile's two fragment sets are live here)
                     }
             }
@@ -529,6 +529,10 @@ static void g4_launch(const Gemm4wArgs &a, hipStream_t s) {
 
 // mlp.lin1 of the half-precision network (bf16, or fp16 when f16 != 0): out = gelu(LayerNorm-folded(A) W^T + bias).  Returns 1 when launched, 0 when the shape is not this
 // kernel's (the caller then takes k_gemm256p, which computes the same bits).
+#ifdef CPX_DEBUG
+static int g_gemm4w_var = 0;
+extern "C" void cpx_gemm4w_set_variant(int v) { g_gemm4w_var = v; }
+#endif
 int cpx_gemm4w_gelu_ln(int f16, const void *A, const void *W, int M, int N, int K, const float *bias, const float *ln_stats, const float *ln_colsum,
                        void *out, int ld_out, hipStream_t s) {
     if (!g4_shape_ok(M, N, K, ld_out) || !bias || !ln_stats || !ln_colsum) return 0;
@@ -536,6 +540,9 @@ int cpx_gemm4w_gelu_ln(int f16, const void *A, const void *W, int M, int N, int 
     a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.ln_stats = ln_stats; a.ln_colsum = ln_colsum;
     a.out = (unsigned short *)out; a.resid = nullptr; a.stats_out = nullptr;
     a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
+#ifdef CPX_DEBUG
+    if (!f16 && g_gemm4w_var == 512) { g4_launch<G4_EPI_GELU_LN, 512, false>(a, s); return 1; }     // experiment: non-temporal output stores
+#endif
     if (f16) g4_launch<G4_EPI_GELU_LN, 0, true>(a, s);
     else g4_launch<G4_EPI_GELU_LN, 0, false>(a, s);
     return 1;
@@ -556,8 +563,6 @@ int cpx_gemm4w_resid_stats(const void *A, const void *W, int M, int N, int K, co
     return 1;
 }
 
-static int g_gemm4w_var = 0;
-extern "C" void cpx_gemm4w_set_variant(int v) { g_gemm4w_var = v; }
 // out[M][ld_out] (bf16) = A[M][K] . W[N][K]^T + bias; M, N multiples of 256, K a multiple of 128, every operand below 2 GiB
 extern "C" int cpx_gemm4w(const void *A, const void *W, int M, int N, int K, const float *bias, void *out, int ld_out, void *stream) {
     if (!g4_shape_ok(M, N, K, ld_out) || !bias) return CPX_EINVAL;
