@@ -130,6 +130,31 @@ def test_follow_flows_torch_pin_small(cuda):
     assert np.array_equal(fl.cpu().numpy()[0].reshape(2, 64, 80)[:, inds[0], inds[1]], ref)
 
 
+def test_flow_errors_across_the_diffusion_kernels_lds_threshold(cuda):
+    """k_diffuse keeps a label's padded box in LDS when it has at most 2944 cells (52 KB per workgroup: three per CU; 3584 until round 5)
+    and walks the global planes otherwise: labels whose boxes sit on both sides of BOTH thresholds -- squares of 50 .. 60 pixels, a 40 x 70
+    and a 20 x 150 bar, an L-shape in a 58 x 58 box -- in one tile, flow errors against the oracle's fp64 diffusion (rtol 1e-12) and the ids the
+    filter keeps.  Reference: cellpose masks_to_flows_gpu / flow_error through models.py:149-159."""
+    H = W = 400
+    m = np.zeros((H, W), np.int32)
+    boxes = [(5, 5, 50, 50), (5, 70, 52, 52), (5, 135, 53, 53), (5, 200, 54, 54), (5, 265, 56, 56), (5, 330, 58, 58),
+             (80, 5, 60, 60), (80, 80, 40, 70), (150, 5, 20, 150), (200, 200, 58, 58)]
+    for lab, (y, x, h, w) in enumerate(boxes, 1):
+        m[y:y + h, x:x + w] = lab
+    m[200 + 20:200 + 58, 200 + 20:200 + 58] = 0                      # label 10: an L in a 58 x 58 box
+    cells = [(h + 2) * (w + 2) for _, _, h, w in boxes]
+    assert sum(c <= 2944 for c in cells) >= 2 and sum(2944 < c <= 3584 for c in cells) >= 3 and sum(c > 3584 for c in cells) >= 2
+    rng = np.random.default_rng(3)
+    dP = (rng.standard_normal((2, H, W)) * 2).astype(np.float32)
+    want_masks, want_err = dynamics.remove_bad_flow_masks(m, dP, 0.4, return_errors=True)
+    masks = torch.from_numpy(m.copy()).to(cuda)[None]
+    got_masks, errs = ops.remove_bad_flow_masks(masks, torch.from_numpy(dP).to(cuda)[None], 0.4, return_errors=True)
+    e = errs.cpu().numpy()[0][: len(want_err)]
+    assert np.allclose(e, want_err, rtol=1e-12, atol=1e-14)
+    assert not (np.abs(want_err - 0.4) < 1e-9).any()
+    assert np.array_equal(got_masks.cpu().numpy()[0], want_masks.astype(np.int32))
+
+
 @pytest.mark.parametrize("kind,H,W,seed", CASES)
 def test_stagewise_masks_bit_exact(cuda, kind, H, W, seed):
     dP, cp, lg = _fields(kind, H, W, seed)
