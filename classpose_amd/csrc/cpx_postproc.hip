@@ -12,6 +12,7 @@
 // and stores are coalesced; small per-label tables live in the caller's
 // workspace (no hidden allocation).
 #include "cpx_common.h"
+#include "cpx_internal.h"
 
 #define RPAD 20
 #define NTHR 256
@@ -848,9 +849,14 @@ __global__ void k_center_pick(const int32_t *__restrict__ masks, PPLayout lay, v
 
 // heat diffusion from the centre inside one label (fp64 Jacobi, 9-neighbour mean
 // summed in neighbour order 0..8 then / 9).  One workgroup per (label, tile).
-#define DIFF_LDS_CELLS 2944     // (bh+2)*(bw+2) <= this -> T ping-pong in LDS (46 KB) + the cell list (6 KB) = 52 KB: THREE workgroups per CU.  (3584 until round 5:
-                                // 64.5 KB, two per CU = 512 slots for the ~650 labels of the bench's 8-tile batch, i.e. a second round: 43.6 -> 32.9 us.
-                                // A cell list in raster order instead of the order an LDS atomic hands out slots changed nothing: 34.2 us.)
+#define DIFF_LDS_CELLS 2944     // LDS of the first launch: T ping-pong (46 KB) + the cell list (6 KB) = 52 KB, i.e. THREE workgroups of 256 threads per CU.  The size is
+                                // an occupancy choice: 3584 cells (64.5 KB, two per CU = 512 slots for the ~650 labels of the bench's 8-tile batch) meant a second round,
+                                // 43.6 us; 2944: 32.9 us; 2048 (36 KB, four per CU): 42.5 us -- the dispatcher packs a CU to its limit before it takes the next one, so
+                                // 650 workgroups at four per CU leave a third of the chip idle and share 160 CUs' LDS pipes.
+#define DIFF_SMALL_CELLS 2048   // (bh+2)*(bw+2) <= this -> first launch; larger boxes go to the second launch (k_diffuse<true>: 1024 threads per label, which is also
+                                // faster for them: nine 52 x 52 labels per tile took 723 us in the first launch, 327 us in the second).  43 x 43 pixels: above the
+                                // boxes of ordinary nuclei, which need the first launch's many slots.
+                                // (A cell list in raster order instead of the order an LDS atomic hands out slots changed nothing: 34.2 us.)
 // s / 9.0 correctly rounded without the IEEE division sequence (v_div_scale / v_rcp_f64 / v_div_fmas / v_div_fixup):
 // q = RN(s * c) with c = RN(1/9) is within 1 ulp of s / 9, r = s - 9 q is exact in one fma, and RN(q + r * c) is the
 // correctly rounded quotient (Markstein's FMA division finish; a quotient of two doubles is never a rounding tie).
@@ -863,11 +869,24 @@ __device__ __forceinline__ double div9(double s) {
     return fma(r, c, q);
 }
 
-__global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ masks, PPLayout lay,
-                                                  void *ws) {
-    __shared__ double sT[2 * DIFF_LDS_CELLS];
-    __shared__ unsigned short sIdx[DIFF_LDS_CELLS];
-    __shared__ int sN;
+// BIG: the second launch of the stage, for the labels the first one leaves out (padded box above DIFF_SMALL_CELLS): 1024 threads and
+// 147 KB of LDS per workgroup (one per CU) take boxes of up to DIFF_BIG_CELLS cells (88 x 88) through the same LDS path; only what is
+// larger still walks the global planes.  Until round 5 EVERY box above the small limit did, at ~30 us per iteration: nine labels of
+// 53 x 53 pixels in a tile cost 5.3 ms where nine of 52 x 52 cost 0.72 (tools/diffuse_size_scan.py) -- a cliff in front of exactly the
+// merged, oversized instances the flow-error filter exists to remove.
+#define DIFF_BIG_CELLS 8192
+#define DIFF_BIG_THREADS 1024
+#define DIFF_BIG_LDS (DIFF_BIG_CELLS * 18 + 16)
+template <bool BIG>
+__global__ void __launch_bounds__(BIG ? DIFF_BIG_THREADS : NTHR) k_diffuse(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
+    constexpr int CAP = BIG ? DIFF_BIG_CELLS : DIFF_LDS_CELLS;
+    extern __shared__ __attribute__((aligned(16))) char diff_dyn[];
+    __shared__ __attribute__((aligned(16))) char diff_static[BIG ? 16 : DIFF_LDS_CELLS * 18 + 16];
+    char *raw = BIG ? diff_dyn : diff_static;
+    double *sT = reinterpret_cast<double *>(raw);                                   // two planes of CAP cells
+    unsigned short *sIdx = reinterpret_cast<unsigned short *>(raw + (size_t)CAP * 16);
+    int &sN = *reinterpret_cast<int *>(raw + (size_t)CAP * 18);
+    const int nthr = blockDim.x;
     // persistent over labels: a fixed grid of workgroups strides through 1..vmax (k_center_d2 left the largest
     // occupied label in SC_VMAX) instead of one 60 KB-LDS workgroup per POSSIBLE label (L-1 = H*W/11 of them,
     // ~99 % of which exited at once but still had to be dispatched and kept the GEMM workgroups off their CUs)
@@ -886,19 +905,20 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
     const int cy = cidx / lay.W - y0 + 1, cx = cidx % lay.W - x0 + 1;
     double *Tg = WS(double, off_T);                      // [THW] final T (shared by all labels)
     const int off9[9] = {0, -pw, pw, -1, 1, -pw - 1, -pw + 1, pw - 1, pw + 1};
-    if (cells <= DIFF_LDS_CELLS) {
+    if (BIG ? cells <= DIFF_SMALL_CELLS : cells > DIFF_SMALL_CELLS) continue;      // the other launch's label (uniform: no barrier is skipped by a part of the workgroup)
+    if (cells <= CAP) {
         // Cells outside the label hold 0.0 in both planes for the whole run (only label cells are ever written), and
         // s + 0.0 == s exactly, so the 9-term sum needs no neighbour flags: the label's cells are compacted once into
         // sIdx and every iteration is 9 LDS reads + 8 adds + the division per label cell, with ONE barrier (the
         // reference's `T[centre] += 1` in front of iteration it+1 is applied by the centre's owner when it writes
         // iteration it's value -- the same addition on the same value).
         if (threadIdx.x == 0) sN = 0;
-        for (int c = threadIdx.x; c < cells; c += NTHR) {
+        for (int c = threadIdx.x; c < cells; c += nthr) {
             sT[c] = 0.0;
-            sT[DIFF_LDS_CELLS + c] = 0.0;
+            sT[CAP + c] = 0.0;
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < cells; c += NTHR) {
+        for (int c = threadIdx.x; c < cells; c += nthr) {
             int ly = c / pw, lx = c - ly * pw;
             int gy = y0 + ly - 1, gx = x0 + lx - 1;
             if (ly >= 1 && ly <= bh && lx >= 1 && lx <= bw && m[gy * lay.W + gx] == lab)
@@ -911,10 +931,10 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
         const int c0 = (int)threadIdx.x < nl ? (int)sIdx[threadIdx.x] : -1;
         int cur = 0;
         for (int it = 0; it < niter; ++it) {
-            const double *To = sT + cur * DIFF_LDS_CELLS;
-            double *Tn = sT + (cur ^ 1) * DIFF_LDS_CELLS;
+            const double *To = sT + cur * CAP;
+            double *Tn = sT + (cur ^ 1) * CAP;
             const bool more = it + 1 < niter;
-            for (int j = threadIdx.x; j < nl; j += NTHR) {
+            for (int j = threadIdx.x; j < nl; j += nthr) {
                 const int c = j == (int)threadIdx.x ? c0 : (int)sIdx[j];
                 double s = To[c];
 #pragma unroll
@@ -926,8 +946,8 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
             __syncthreads();
             cur ^= 1;
         }
-        const double *Tf = sT + cur * DIFF_LDS_CELLS;
-        for (int j = threadIdx.x; j < nl; j += NTHR) {
+        const double *Tf = sT + cur * CAP;
+        for (int j = threadIdx.x; j < nl; j += nthr) {
             const int c = sIdx[j];
             int ly = c / pw, lx = c - ly * pw;
             Tg[(y0 + ly) * lay.TW + (x0 + lx)] = Tf[c];     // padded coords: (gy+1, gx+1)
@@ -940,7 +960,7 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
             double *To = cur ? T1 : T0, *Tn = cur ? T0 : T1;
             if (threadIdx.x == 0) To[(y0 + cy) * lay.TW + (x0 + cx)] += 1.0;
             __syncthreads();
-            for (int c = threadIdx.x; c < bh * bw; c += NTHR) {
+            for (int c = threadIdx.x; c < bh * bw; c += nthr) {
                 int ly = c / bw, lx = c - ly * bw;
                 int gy = y0 + ly, gx = x0 + lx;
                 if (m[gy * lay.W + gx] != lab) continue;
@@ -961,7 +981,7 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
             cur ^= 1;
         }
         if (cur == 1) {     // final values sit in T1: copy own pixels to plane 0
-            for (int c = threadIdx.x; c < bh * bw; c += NTHR) {
+            for (int c = threadIdx.x; c < bh * bw; c += nthr) {
                 int ly = c / bw, lx = c - ly * bw;
                 int gy = y0 + ly, gx = x0 + lx;
                 if (m[gy * lay.W + gx] == lab) T0[(gy + 1) * lay.TW + gx + 1] = T1[(gy + 1) * lay.TW + gx + 1];
@@ -969,6 +989,14 @@ __global__ void __launch_bounds__(NTHR) k_diffuse(const int32_t *__restrict__ ma
         }
     }
   }
+}
+
+// a13's diffusion: the labels whose padded box fits 52 KB of LDS (three workgroups per CU), then the larger ones
+static void pp_launch_diffuse(const int32_t *masks, int nT, const PPLayout &lay, void *ws, hipStream_t s) {
+    static CpxOncePerDevice once;
+    once([] { (void)hipFuncSetAttribute((const void *)k_diffuse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIFF_BIG_LDS); });
+    PP_LAUNCH(k_diffuse<false>, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    PP_LAUNCH(k_diffuse<true>, dim3(lay.L - 1 < 32 ? lay.L - 1 : 32, nT), dim3(DIFF_BIG_THREADS), DIFF_BIG_LDS, s, masks, lay, ws);
 }
 
 // scipy.ndimage.mean: per-label sums accumulated in raster order (np.bincount), / count
@@ -1383,7 +1411,7 @@ __global__ void k_rec_write(const uint8_t *__restrict__ cm, int max_rec, cpx_rec
 }
 
 // ===========================================================================
-// the fused chain of cpx_compute_masks (round 4): 22 launches where the stage-wise sequence needs 38
+// the fused chain of cpx_compute_masks (round 4): 23 launches (22 until round 5 gave the diffusion a second launch for large boxes) where the stage-wise sequence needs 39
 // ===========================================================================
 // What made the chain long was never the pixel work (a 2 MB pass is ~5 us of dispatch) but its per-tile global dependencies:
 // a stage's per-label tables must be complete before its "light" step (rank the labels by first appearance, apply the size
@@ -1885,7 +1913,7 @@ static int bad_flow_impl(int32_t *masks, const float *dP, int nT, int H, int W, 
     PP_LAUNCH(k_lab_stats, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, 0, lay, ws);
     PP_LAUNCH(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     PP_LAUNCH(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    PP_LAUNCH(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
+    pp_launch_diffuse(masks, nT, lay, ws, s);
     PP_LAUNCH(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, dP, threshold, flow_errors, lay, ws);
     if (!defer_zero) PP_LAUNCH(k_zero_flagged, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, lay, ws);
     CPX_CHECK_LAUNCH();
@@ -1972,7 +2000,7 @@ extern "C" int cpx_remove_border_instances(int32_t *masks, uint8_t *class_masks,
     return CPX_OK;
 }
 
-CPX_SWITCH(g_pp_fused, 1);          // 1 = the 22-launch fused chain (production; the 16-launch ticket form was measured and abandoned, see above), 0 = the stage-wise sequence (38 launches; A/B)
+CPX_SWITCH(g_pp_fused, 1);          // 1 = the 23-launch fused chain (production; the 16-launch ticket form was measured and abandoned, see above), 0 = the stage-wise sequence (38 launches; A/B)
 #ifdef CPX_DEBUG
 extern "C" void cpx_postproc_set_fused(int on) { g_pp_fused = on; }
 #endif
@@ -2010,8 +2038,9 @@ static int compute_masks_staged(const float *dP, const float *cellprob, const fl
     return CPX_OK;
 }
 
-// the fused chain (see "the fused chain of cpx_compute_masks" above): 22 launches with the class vote and the records (the
-// stage-wise sequence: 38), 21 without records, 19 without the vote, 4 fewer without the flow-error filter
+// the fused chain (see "the fused chain of cpx_compute_masks" above): 23 launches with the class vote and the records (the
+// stage-wise sequence: 39), 22 without records, 20 without the vote, 5 fewer without the flow-error filter (round 5: + the diffusion's
+// second launch for labels with large boxes)
 static int compute_masks_fused(const float *dP, const float *cellprob, const float *logits, int nT,
                                int ncls, int H, int W, float thr, double flow_threshold, int niter, int min_size,
                                double max_size_fraction, uint16_t *masks_u16, uint8_t *class_masks, int32_t *nlabels,
@@ -2035,7 +2064,7 @@ static int compute_masks_fused(const float *dP, const float *cellprob, const flo
     if (flow_threshold > 0) {
         PP_LAUNCH(k_center_d2, GRID_RUN(lay, nT), dim3(NTHR), 0, s, masks, L1, ws);
         PP_LAUNCH(k_center_pick, GRID_PIX(lay, nT), dim3(NTHR), 0, s, masks, L1, ws);
-        PP_LAUNCH(k_diffuse, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, L1, ws);
+        pp_launch_diffuse(masks, nT, L1, ws, s);
         PP_LAUNCH(k_flow_err_label, dim3(cpx_cdiv(lay.L, NTHR / 64), nT), dim3(NTHR), 0, s, masks, dP, flow_threshold, (double *)nullptr, L1, ws);
     }
     // a14: size filter, hole fill, size filter

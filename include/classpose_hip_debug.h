@@ -35,7 +35,7 @@ void cpx_attention_set_xcd_order(int on);   /* 1 (default): (sub-tile, head) pai
 void cpx_attention_set_variant(int v);      /* 2: 4-wave, LDS-DMA ring + pipelined S; 0: 4-wave register ring; 1: 8-wave ping-pong; 3: one wave per SIMD, two query rows per wave (LDS ring); 4: the same with fragments straight from global memory; 5: 4 without the per-half-step overflow vote (bf16); 6: fragments two tiles ahead in AGPR sets */
 void cpx_attention_set_lsum(int on);        /* 0 (default): 1 = softmax denominators by an all-ones MFMA (experiment)           */
 void cpx_attention_set_trv(int on);         /* 0 (default): V through ds_read_b64_tr_b16                  */
-void cpx_postproc_set_fused(int on);        /* 1 (default): the 22-launch fused chain of cpx_compute_masks / cpx_compute_masks_records; 0: the stage-wise sequence (38 launches) */
+void cpx_postproc_set_fused(int on);        /* 1 (default): the 23-launch fused chain of cpx_compute_masks / cpx_compute_masks_records; 0: the stage-wise sequence (39 launches) */
 void cpx_gemm_set_nt(int on);               /* bits 0 / 1 / 2: non-temporal stores for the q / k / V^T thirds of the qkv projection's output (7 = default); 0: ordinary stores */
 void cpx_follow_set_early_exit(int on);     /* 1 (default): Euler loop leaves when its orbit closes      */
 void cpx_follow_set_lds_window(int on);     /* 1 (default): 32 x 32-cell foreground segments, the Euler loop's taps from an LDS copy of the segment's neighbourhood; 0: round 4 */

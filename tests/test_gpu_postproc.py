@@ -131,19 +131,21 @@ def test_follow_flows_torch_pin_small(cuda):
 
 
 def test_flow_errors_across_the_diffusion_kernels_lds_threshold(cuda):
-    """k_diffuse keeps a label's padded box in LDS when it has at most 2944 cells (52 KB per workgroup: three per CU; 3584 until round 5)
-    and walks the global planes otherwise: labels whose boxes sit on both sides of BOTH thresholds -- squares of 50 .. 60 pixels, a 40 x 70
-    and a 20 x 150 bar, an L-shape in a 58 x 58 box -- in one tile, flow errors against the oracle's fp64 diffusion (rtol 1e-12) and the ids the
-    filter keeps.  Reference: cellpose masks_to_flows_gpu / flow_error through models.py:149-159."""
+    """The diffusion runs a label in the LDS of a 256-thread workgroup when its padded box has at most 2048 cells (first launch), in the
+    147 KB of a 1024-thread workgroup up to 8192 cells (second launch, round 5), and on the global planes beyond: labels on every side of
+    every limit, old (2944, 3584) and new -- squares of 30 .. 60 and 100 pixels, a 40 x 70 and a 20 x 150 bar, an L-shape in a 58 x 58 box --
+    in one tile, flow errors against the oracle's fp64 diffusion (rtol 1e-12) and the ids the filter keeps.
+    Reference: cellpose masks_to_flows_gpu / flow_error through models.py:149-159."""
     H = W = 400
     m = np.zeros((H, W), np.int32)
     boxes = [(5, 5, 50, 50), (5, 70, 52, 52), (5, 135, 53, 53), (5, 200, 54, 54), (5, 265, 56, 56), (5, 330, 58, 58),
-             (80, 5, 60, 60), (80, 80, 40, 70), (150, 5, 20, 150), (200, 200, 58, 58)]
+             (80, 5, 60, 60), (80, 80, 40, 70), (150, 5, 20, 150), (200, 200, 58, 58), (270, 5, 100, 100), (270, 150, 30, 30), (320, 150, 43, 43)]
     for lab, (y, x, h, w) in enumerate(boxes, 1):
         m[y:y + h, x:x + w] = lab
     m[200 + 20:200 + 58, 200 + 20:200 + 58] = 0                      # label 10: an L in a 58 x 58 box
     cells = [(h + 2) * (w + 2) for _, _, h, w in boxes]
-    assert sum(c <= 2944 for c in cells) >= 2 and sum(2944 < c <= 3584 for c in cells) >= 3 and sum(c > 3584 for c in cells) >= 2
+    assert sum(c <= 2048 for c in cells) >= 2 and sum(2048 < c <= 2944 for c in cells) >= 2 and sum(2944 < c <= 3584 for c in cells) >= 3
+    assert sum(3584 < c <= 8192 for c in cells) >= 2 and sum(c > 8192 for c in cells) >= 1
     rng = np.random.default_rng(3)
     dP = (rng.standard_normal((2, H, W)) * 2).astype(np.float32)
     want_masks, want_err = dynamics.remove_bad_flow_masks(m, dP, 0.4, return_errors=True)
@@ -396,9 +398,9 @@ def _chain(L, dP, cp, lg, want_records=True, flow_threshold=0.4):
 
 @pytest.mark.parametrize("vote,flow_thr", [(True, 0.4), (False, 0.4), (True, 0.0)])
 def test_fused_chain_equals_stagewise_chain(cuda, vote, flow_thr):
-    """The 22-launch fused chain of cpx_compute_masks_records (one initialisation, relabel on the next stage's pass, removals
+    """The 23-launch fused chain of cpx_compute_masks_records (one initialisation, relabel on the next stage's pass, removals
     through the rank table, histogram in the Euler loop, records in the final pass) against the stage-wise sequence it replaces
-    (38 launches; cpx_postproc_set_fused(0) in the debug library): ids, class maps, label counts and per-cell records
+    (39 launches; cpx_postproc_set_fused(0) in the debug library): ids, class maps, label counts and per-cell records
     bit-identical on analytic, noisy and random fields incl. an empty tile, both equal to the oracle."""
     from classpose_amd import _lib
     tiles = [_fields(k, 256, 256, s) for k, s in (("discs", 21), ("noisy_discs", 22), ("random", 23), ("discs", 24),
@@ -407,7 +409,7 @@ def test_fused_chain_equals_stagewise_chain(cuda, vote, flow_thr):
     cp = torch.from_numpy(np.stack([t[1] for t in tiles] + [np.full((256, 256), -1.0, np.float32)])).to(cuda)
     lg = torch.from_numpy(np.stack([t[2] for t in tiles] + [np.zeros((7, 256, 256), np.float32)])).to(cuda) if vote else None
     product = _chain(_lib.lib(), dP, cp, lg, flow_threshold=flow_thr)
-    assert product[5] == (22 if vote else 20) - (0 if flow_thr > 0 else 4)
+    assert product[5] == (23 if vote else 21) - (0 if flow_thr > 0 else 5)
     with _lib.use_debug_library() as L:
         L.cpx_postproc_set_fused(0)
         try:
