@@ -42,6 +42,7 @@ struct PPLayout {
 #define SC_HASBIG 4
 #define SC_HASBG 5
 #define SC_VMAX 6
+#define SC_HASMID 7
 #define PP_MAXCLS 32
 
 #define FG_BLOCK 1024       // k_prep_flow workgroup = one segment of the foreground list
@@ -1170,10 +1171,105 @@ __device__ __forceinline__ unsigned long long hfill(unsigned long long o, unsign
     return y;
 }
 
-// Parallel hole fill: one wave per label, lanes = bbox rows, 64-bit row masks.
+// The same flood for a label whose box is wider or taller than 64 pixels, up to 256 x 256 (round 5): the wave keeps FOUR rows per lane (row
+// lane + 64 j) of FOUR 64-bit words each in registers; the horizontal fill carries across the words of a row (one sweep left to right, one right to
+// left), the vertical step takes the rows above / below from the neighbouring lane (lane 0 / 63: from the adjacent row block).  Until round 5
+// ONE such label in a tile sent the whole tile to k_fill_serial (every label again, one after the other, from global memory): nine discs of
+// radius 32 per tile cost 1.07 ms where nine of radius 28 cost 15 us (tools/chain_size_scan.py).
+__device__ __forceinline__ void fill_label_big(int lab, int lane, int y0, int x0, int bh, int bw, const int32_t *__restrict__ src,
+                                               int32_t *__restrict__ dst, const PPLayout &lay, int *conflict) {
+    typedef unsigned long long u64;
+    const int nr = (bh + 63) >> 6, nw = (bw + 63) >> 6;
+    u64 fr[4][4], ot[4][4], o[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            fr[j][w] = 0; ot[j][w] = 0; o[j][w] = 0;
+            const int r = lane + 64 * j;
+            if (j < nr && w < nw && r < bh) {
+                const int32_t *row = src + (size_t)(y0 + r) * lay.W + x0 + 64 * w;
+                const int n = min(64, bw - 64 * w);
+                u64 m = 0, oth = 0;
+                for (int c = 0; c < n; ++c) {
+                    const int v = row[c];
+                    m |= (u64)(v == lab) << c;
+                    oth |= (u64)(v != lab && v != 0) << c;
+                }
+                const u64 wmask = n == 64 ? ~0ull : ((1ull << n) - 1);
+                fr[j][w] = ~m & wmask; ot[j][w] = oth;
+                // seeds: every free cell of the first / last row, the first / last column of the others
+                u64 seed = 0;
+                if (r == 0 || r == bh - 1) seed = fr[j][w];
+                else {
+                    if (w == 0) seed |= 1ull;
+                    if (w == nw - 1) seed |= 1ull << ((bw - 1) & 63);
+                    seed &= fr[j][w];
+                }
+                o[j][w] = seed;
+            }
+        }
+    // horizontal fill of one row (4 words): left-to-right sweep with the carry out of bit 63, then right-to-left with the carry out of bit 0
+    auto row_fill = [&](u64 (&x)[4], const u64 (&f)[4]) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w > 0) x[w] |= (x[w - 1] >> 63) & f[w] & 1ull;
+            x[w] = hfill(x[w], f[w]);
+        }
+#pragma unroll
+        for (int w = 2; w >= 0; --w) {
+            const u64 carry = (x[w + 1] & 1ull) << 63;
+            if (carry & f[w] & ~x[w]) x[w] = hfill(x[w] | carry, f[w]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row_fill(o[j], fr[j]);
+    while (true) {
+        bool ch = false;
+        u64 nn[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                u64 up = __shfl_up(o[j][w], 1), dn = __shfl_down(o[j][w], 1);
+                const u64 up_blk = j > 0 ? __shfl(o[j > 0 ? j - 1 : 0][w], 63) : 0ull;     // row 64 j - 1 lives in lane 63 of the block above
+                const u64 dn_blk = j < 3 ? __shfl(o[j < 3 ? j + 1 : 3][w], 0) : 0ull;      // row 64 j + 64 in lane 0 of the block below
+                if (lane == 0) up = up_blk;
+                if (lane == 63) dn = dn_blk;
+                nn[j][w] = o[j][w] | ((up | dn) & fr[j][w]);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            row_fill(nn[j], fr[j]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { ch |= nn[j][w] != o[j][w]; o[j][w] = nn[j][w]; }
+        }
+        if (!__any(ch)) break;
+    }
+    bool cf = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            u64 holes = fr[j][w] & ~o[j][w];
+            cf |= (holes & ot[j][w]) != 0;
+            const int r = lane + 64 * j;
+            if (r < bh) {
+                int32_t *row = dst + (size_t)(y0 + r) * lay.W + x0 + 64 * w;
+                while (holes) {
+                    const int c = __ffsll((long long)holes) - 1;
+                    holes &= holes - 1;
+                    row[c] = lab;
+                }
+            }
+        }
+    if (cf) *conflict = 1;
+}
+
+// Parallel hole fill: one wave per label, lanes = bbox rows, 64-bit row masks (boxes up to 64 x 64; fill_label_big up to 256 x 256).
 // Reads `src` (pre-fill copy), writes holes into `masks`.  Exact w.r.t. the
 // sequential reference loop iff no hole contains a pixel of another label; that
-// case (and bboxes > 64) is flagged and redone sequentially by k_fill_serial.
+// case (and bboxes > 256) is flagged and redone sequentially by k_fill_serial.
 __global__ void __launch_bounds__(NTHR) k_fill_parallel(int32_t *__restrict__ masks, PPLayout lay,
                                                         void *ws) {
     const int lane = threadIdx.x & 63;
@@ -1183,7 +1279,8 @@ __global__ void __launch_bounds__(NTHR) k_fill_parallel(int32_t *__restrict__ ma
     const int *bb = WS(int, off_bbox) + 4 * lab;
     if (WS(int, off_cnt)[lab] <= 0) return;
     const int y0 = bb[0], x0 = bb[1], bh = bb[2] - y0 + 1, bw = bb[3] - x0 + 1;
-    if (bh > 64 || bw > 64) { if (lane == 0) WS(int, off_scal)[SC_HASBIG] = 1; return; }
+    if (bh > 256 || bw > 256) { if (lane == 0) WS(int, off_scal)[SC_HASBIG] = 1; return; }
+    if (bh > 64 || bw > 64) { if (lane == 0) WS(int, off_scal)[SC_HASMID] = 1; return; }     // k_fill_serial's waves take these (fill_label_big: 500 registers)
     const int32_t *src = WS(int32_t, off_tmp);
     int32_t *dst = masks + (size_t)blockIdx.y * lay.HW;
     unsigned long long m = 0, other = 0;
@@ -1300,9 +1397,31 @@ __device__ void fill_serial_body(int32_t *__restrict__ masks, const PPLayout &la
         __syncthreads();
     }
 }
+// One workgroup per tile, behind k_fill_parallel: (1) the labels with boxes of 65 .. 256 pixels, four at a time (one per wave, fill_label_big) --
+// unless the tile goes to the sequential loop anyway; (2) the sequential loop over ALL labels when a hole of any label holds another label's
+// pixels (the one case in which the reference's label-by-label order shows) or a box exceeds 256 pixels.
 __global__ void __launch_bounds__(NTHR) k_fill_serial(int32_t *__restrict__ masks, PPLayout lay,
                                                       void *ws) {
-    if (!(WS(int, off_scal)[SC_CONFLICT] || WS(int, off_scal)[SC_HASBIG])) return;
+    int *scal = WS(int, off_scal);
+    const int hasmid = scal[SC_HASMID];
+    if (!(scal[SC_CONFLICT] || scal[SC_HASBIG] || hasmid)) return;
+    if (hasmid && !(scal[SC_CONFLICT] || scal[SC_HASBIG])) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nlab = scal[SC_NLAB];
+        const int32_t *src = WS(int32_t, off_tmp);
+        int32_t *dst = masks + (size_t)blockIdx.y * lay.HW;
+        int k = 0;
+        for (int lab = 1; lab <= nlab; ++lab) {
+            if (WS(int, off_cnt)[lab] <= 0) continue;
+            const int *bb = WS(int, off_bbox) + 4 * lab;
+            const int y0 = bb[0], x0 = bb[1], bh = bb[2] - y0 + 1, bw = bb[3] - x0 + 1;
+            if (bh <= 64 && bw <= 64) continue;
+            if ((k++ & (NTHR / 64 - 1)) != wave) continue;
+            fill_label_big(lab, lane, y0, x0, bh, bw, src, dst, lay, &scal[SC_CONFLICT]);
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+    if (!(__hip_atomic_load(&scal[SC_CONFLICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || scal[SC_HASBIG])) return;
     fill_serial_body(masks, lay, ws);
 }
 

@@ -245,10 +245,29 @@ def _fill_cases():
     m = np.ones((20, 20), np.int32)              # no background pixel at all
     m[5:15, 5:15] = 2; m[8:10, 8:10] = 3
     cases.append(m)
+    # ---- round 5: boxes of 65 .. 256 pixels are filled by a wave with four rows per lane and four 64-bit words per row (fill_label_big)
+    m = np.zeros((300, 420), np.int32)           # holes across word (64-column) and row-block (64-row) boundaries, no label inside a hole
+    yy, xx = np.mgrid[:300, :420]
+    m[np.hypot(yy - 100, xx - 100) < 95] = 1                       # 189 x 189 disc ...
+    m[(np.hypot(yy - 100, xx - 100) < 60) & (np.hypot(yy - 100, xx - 100) > 30)] = 0     # ... with an annular hole around an island of itself
+    m[38:44, 60:70] = 0; m[62:66, 62:66] = 0; m[126:130, 126:131] = 0; m[100:101, 5:35] = 0   # small holes; a slit from the border that stops short of the annulus (a bay, not a hole)
+    m[5:70, 210:410] = 2                                           # 65 x 200 bar with a row of holes through every word
+    m[30:40, 215:405:7] = 0
+    m[100:290, 215:290] = 3                                        # 190 x 75: a comb -- deep bays open to the outside stay background
+    m[110:280, 225:280:10] = 0; m[100:110, 225:280:10] = 0
+    m[120:126, 300:306] = 4                                        # ordinary small labels beside them
+    m[140:170, 300:340] = 5; m[150:160, 310:330] = 0
+    m[200:290, 300:400] = 6; m[263:265, 300:390] = 0; m[205:262, 363:365] = 0; m[210:250, 310:350] = 0    # 90 x 100 spiral-ish: one real hole, two slits
+    cases.append(m)
+    m = np.zeros((330, 330), np.int32)           # a 300 x 300 frame (box > 256: sequential path) around mid-size labels with holes
+    m[10:310, 10:310] = 1; m[20:300, 20:300] = 0
+    m[40:140, 40:240] = 2; m[60:120, 60:220] = 0
+    m[160:290, 160:290] = 3; m[200:250, 200:250] = 0
+    cases.append(m)
     return cases
 
 
-@pytest.mark.parametrize("idx", range(5))
+@pytest.mark.parametrize("idx", range(7))
 def test_fill_holes_and_remove_small_masks(cuda, idx):
     m = _fill_cases()[idx]
     ref = dynamics.fill_holes_and_remove_small_masks(m.astype(np.uint16), 15)
