@@ -871,13 +871,15 @@ __device__ __forceinline__ double div9(double s) {
 }
 
 // BIG: the second launch of the stage, for the labels the first one leaves out (padded box above DIFF_SMALL_CELLS): 1024 threads and
-// 147 KB of LDS per workgroup (one per CU) take boxes of up to DIFF_BIG_CELLS cells (88 x 88) through the same LDS path; only what is
-// larger still walks the global planes.  Until round 5 EVERY box above the small limit did, at ~30 us per iteration: nine labels of
+// 147 KB of LDS per workgroup (one per CU) take boxes of up to DIFF_BIG_CELLS cells (88 x 88) through the same LDS path, boxes of up to
+// DIFF_HUGE_CELLS (133 x 133) through a one-plane form of it; only what is larger still walks the global planes.  Until round 5 EVERY box above the small limit did, at ~30 us per iteration: nine labels of
 // 53 x 53 pixels in a tile cost 5.3 ms where nine of 52 x 52 cost 0.72 (tools/diffuse_size_scan.py) -- a cliff in front of exactly the
 // merged, oversized instances the flow-error filter exists to remove.
 #define DIFF_BIG_CELLS 8192
 #define DIFF_BIG_THREADS 1024
-#define DIFF_BIG_LDS (DIFF_BIG_CELLS * 18 + 16)
+#define DIFF_HUGE_PER_THREAD 18
+#define DIFF_HUGE_CELLS (DIFF_HUGE_PER_THREAD * DIFF_BIG_THREADS - 96)    // 18 336 cells (a 133 x 133 box): one plane of doubles = 143 KB
+#define DIFF_BIG_LDS ((DIFF_HUGE_CELLS * 8 > DIFF_BIG_CELLS * 18 ? DIFF_HUGE_CELLS * 8 : DIFF_BIG_CELLS * 18) + 16)
 template <bool BIG>
 __global__ void __launch_bounds__(BIG ? DIFF_BIG_THREADS : NTHR) k_diffuse(const int32_t *__restrict__ masks, PPLayout lay, void *ws) {
     constexpr int CAP = BIG ? DIFF_BIG_CELLS : DIFF_LDS_CELLS;
@@ -953,6 +955,54 @@ __global__ void __launch_bounds__(BIG ? DIFF_BIG_THREADS : NTHR) k_diffuse(const
             int ly = c / pw, lx = c - ly * pw;
             Tg[(y0 + ly) * lay.TW + (x0 + lx)] = Tf[c];     // padded coords: (gy+1, gx+1)
         }
+    } else if (BIG && cells <= DIFF_HUGE_CELLS) {
+        // ONE plane of doubles in the workgroup's 160 KB (boxes of up to ~140 x 140 pixels): a thread keeps the membership bits and the new values of its
+        // <= DIFF_HUGE_PER_THREAD cells in registers across a barrier, then writes them -- two barriers per Jacobi iteration instead of one, the same
+        // update on the same values.  (Round 5; these labels walked the global planes before: four 97 x 97 labels per tile 9 ms per 8-tile batch.)
+        for (int c = threadIdx.x; c < cells; c += nthr) sT[c] = 0.0;
+        __syncthreads();
+        unsigned mine = 0;                                      // bit k: cell threadIdx.x + k * nthr belongs to the label
+#pragma unroll
+        for (int k = 0; k < DIFF_HUGE_PER_THREAD; ++k) {
+            const int c = threadIdx.x + k * nthr;
+            if (c < cells) {
+                const int ly = c / pw, lx = c - ly * pw;
+                if (ly >= 1 && ly <= bh && lx >= 1 && lx <= bw && m[(y0 + ly - 1) * lay.W + (x0 + lx - 1)] == lab) mine |= 1u << k;
+            }
+        }
+        const int cc = cy * pw + cx;
+        if (threadIdx.x == 0 && niter > 0) sT[cc] = 1.0;
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const bool more = it + 1 < niter;
+            double v[DIFF_HUGE_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < DIFF_HUGE_PER_THREAD; ++k) {
+                v[k] = 0.0;
+                if (mine & (1u << k)) {
+                    int c = threadIdx.x + k * nthr;
+                    // (opaque to the optimiser: otherwise the 8 x 20 neighbour addresses are hoisted out of the iteration loop as invariants and the
+                    // kernel spills 119 of the 128 registers a 1024-thread workgroup leaves it)
+                    asm volatile("" : "+v"(c));
+                    double s_ = sT[c];
+#pragma unroll
+                    for (int q = 1; q < 9; ++q) s_ = s_ + sT[c + off9[q]];
+                    v[k] = div9(s_);
+                    if (c == cc && more) v[k] += 1.0;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < DIFF_HUGE_PER_THREAD; ++k)
+                if (mine & (1u << k)) sT[threadIdx.x + k * nthr] = v[k];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < DIFF_HUGE_PER_THREAD; ++k)
+            if (mine & (1u << k)) {
+                const int c = threadIdx.x + k * nthr, ly = c / pw, lx = c - ly * pw;
+                Tg[(y0 + ly) * lay.TW + (x0 + lx)] = sT[c];
+            }
     } else {
         // big bbox: ping-pong directly in the global padded T planes (own pixels only)
         double *T0 = Tg, *T1 = Tg + lay.THW;

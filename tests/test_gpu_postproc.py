@@ -132,20 +132,22 @@ def test_follow_flows_torch_pin_small(cuda):
 
 def test_flow_errors_across_the_diffusion_kernels_lds_threshold(cuda):
     """The diffusion runs a label in the LDS of a 256-thread workgroup when its padded box has at most 2048 cells (first launch), in the
-    147 KB of a 1024-thread workgroup up to 8192 cells (second launch, round 5), and on the global planes beyond: labels on every side of
-    every limit, old (2944, 3584) and new -- squares of 30 .. 60 and 100 pixels, a 40 x 70 and a 20 x 150 bar, an L-shape in a 58 x 58 box --
+    147 KB of a 1024-thread workgroup up to 8192 cells (second launch, round 5: two planes) or 18 336 cells (one plane, new values held in
+    registers across a barrier), and on the global planes beyond: labels on every side of every limit, old (2944, 3584) and new -- squares of
+    30 .. 60, 100 and 150 pixels, a 40 x 70 and a 20 x 150 bar, an L-shape in a 58 x 58 box --
     in one tile, flow errors against the oracle's fp64 diffusion (rtol 1e-12) and the ids the filter keeps.
     Reference: cellpose masks_to_flows_gpu / flow_error through models.py:149-159."""
-    H = W = 400
+    H, W = 560, 400
     m = np.zeros((H, W), np.int32)
     boxes = [(5, 5, 50, 50), (5, 70, 52, 52), (5, 135, 53, 53), (5, 200, 54, 54), (5, 265, 56, 56), (5, 330, 58, 58),
-             (80, 5, 60, 60), (80, 80, 40, 70), (150, 5, 20, 150), (200, 200, 58, 58), (270, 5, 100, 100), (270, 150, 30, 30), (320, 150, 43, 43)]
+             (80, 5, 60, 60), (80, 80, 40, 70), (150, 5, 20, 150), (200, 200, 58, 58), (270, 5, 100, 100), (270, 150, 30, 30), (320, 150, 43, 43)]            # (+ a 150 x 150 square below: a box above 18 336 cells)
+    boxes.append((400, 100, 150, 150))
     for lab, (y, x, h, w) in enumerate(boxes, 1):
         m[y:y + h, x:x + w] = lab
     m[200 + 20:200 + 58, 200 + 20:200 + 58] = 0                      # label 10: an L in a 58 x 58 box
     cells = [(h + 2) * (w + 2) for _, _, h, w in boxes]
     assert sum(c <= 2048 for c in cells) >= 2 and sum(2048 < c <= 2944 for c in cells) >= 2 and sum(2944 < c <= 3584 for c in cells) >= 3
-    assert sum(3584 < c <= 8192 for c in cells) >= 2 and sum(c > 8192 for c in cells) >= 1
+    assert sum(3584 < c <= 8192 for c in cells) >= 2 and sum(8192 < c <= 18336 for c in cells) >= 1 and sum(c > 18336 for c in cells) >= 1
     rng = np.random.default_rng(3)
     dP = (rng.standard_normal((2, H, W)) * 2).astype(np.float32)
     want_masks, want_err = dynamics.remove_bad_flow_masks(m, dP, 0.4, return_errors=True)
