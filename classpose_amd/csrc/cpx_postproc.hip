@@ -29,7 +29,7 @@ extern "C" unsigned long long cpx_postproc_launch_count(void) { return g_pp_laun
 // ---------------------------------------------------------------------------
 struct PPLayout {
     int H, W, HW, Hp, Wp, HWp, L, TW, TH, THW, nbx, nseg;
-    size_t off_h1, off_M1, off_tmp, off_im, off_fg, off_fgcnt, off_T, off_e, off_seed_pos, off_seed_cnt,
+    size_t off_h1, off_M1, off_tmp, off_im, off_fg, off_fgcnt, off_rankbits, off_T, off_e, off_seed_pos, off_seed_cnt,
         off_rank, off_cnt, off_first, off_remap, off_flag, off_bbox, off_sumy, off_sumx,
         off_d2, off_center, off_err, off_cls, off_scal, per_tile, tab0, tab_bytes;
 };
@@ -60,6 +60,7 @@ static PPLayout pp_layout(int H, int W) {
     p.nbx = cpx_cdiv(p.TW, FG_SIDE); p.nseg = p.nbx * cpx_cdiv(p.TH, FG_SIDE);   // (>= cdiv(THW, FG_BLOCK), the linear segmentation's count)
     p.off_fg = take(sizeof(int) * FG_BLOCK * p.nseg);   // foreground pixels, one segment per k_prep_flow block
     p.off_fgcnt = take(sizeof(int) * p.nseg);
+    p.off_rankbits = take(sizeof(unsigned) * 2 * cpx_cdiv(p.HW, 32));   // tail_rank: one bit per pixel + the words' prefix counts
     p.off_T = take(sizeof(double) * 2 * p.THW);
     p.off_e = take(sizeof(double) * 2 * p.HW);
     p.off_cls = take(sizeof(int) * (size_t)p.L * PP_MAXCLS);
@@ -1601,16 +1602,22 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long 
 // agent-scope release on this part writes back the XCD's whole L2 (the eight L2s are not coherent with each other) and every
 // workgroup of every pass paid for one: k_fill 689 us, the class vote 139 us (profiles/r04_post_fused_first_build.csv).
 // A launch boundary is the cheap device-wide release here (~5 us); what the fused chain keeps is everything else.
-#define TAIL_LDS 6144        // labels whose first-appearance index fits the tail's LDS copy (256^2 tiles: L = 5 959)
+#define TAIL_LDS 1024        // up to this many labels the tail ranks by comparing every label with every other through an LDS copy (the bench's tiles: ~80)
 // remap[v] = 1 + #{kept j : first[j] < first[v]} for kept v in 1..vmax, 0 otherwise (fastremap.renumber on the map with the
 // removed labels zeroed); *nlab = number of kept labels.  One workgroup (NTHR threads); `removed(v)` decides per label.
+// More labels than TAIL_LDS (dense 512 / 1024-px tiles) are ranked by position, not by comparison: first[] are distinct pixel indices, so a
+// bitmap of the tile with the kept labels' first pixels set, the prefix counts of its words, and rank = prefix + popcount below the bit --
+// O(HW / 32 + n) for the workgroup instead of O(n^2).  (Until round 5: every label against every other, through LDS chunks above 6 144
+// labels: 8 649 labels in a 1024-px tile cost 3.7 ms per call, six calls per chain = 22 of the chain's 24.5 ms, tools/chain_size_scan.py.)
+// `bits`: 2 x cdiv(hw, 32) words of the tile's workspace (off_rankbits); `scratch`: the stage's unused rank table.
 template <typename R>
-__device__ __forceinline__ void tail_rank(int vmax, const int *first, int *remap, int *nlab_slot, int *scratch, R &&removed) {
-    __shared__ int s_first[TAIL_LDS];
+__device__ __forceinline__ void tail_rank(int vmax, const int *first, int *remap, int *nlab_slot, int *scratch, unsigned *bits, int hw, R &&removed) {
+    __shared__ int s_first[TAIL_LDS + 1];
+    __shared__ int s_part[NTHR];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
     int kept = 0;
-    if (vmax < TAIL_LDS) {
+    if (vmax <= TAIL_LDS) {
         for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
             int f = ld_agent(&first[v]);
             if (f != 0x7FFFFFFF && removed(v)) f = 0x7FFFFFFF;
@@ -1626,34 +1633,41 @@ __device__ __forceinline__ void tail_rank(int vmax, const int *first, int *remap
             ++kept;
         }
     } else {
-        // more labels than the LDS copy holds (dense 512 / 1024-px tiles): the table is ranked against itself chunk by chunk THROUGH the
-        // LDS -- thread-private partial ranks accumulate in remap[], each label is written and re-read by its own thread only.  (Until
-        // round 5 this path compared every label with every other by agent-scope loads from global memory: ~vmax^2 / 256 uncached loads
-        // per thread, tens of milliseconds for 20 000 labels.)  `scratch` (the stage's unused rank table) holds the filtered first[].
+        const int nw = (hw + 31) >> 5, cw = (nw + NTHR - 1) / NTHR;        // words; words per thread (one contiguous chunk each)
+        unsigned *pref = bits + nw;
+        for (int w = threadIdx.x; w < nw; w += NTHR) bits[w] = 0u;
+        __threadfence_block();
+        __syncthreads();
         for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
             int f = ld_agent(&first[v]);
             if (f != 0x7FFFFFFF && removed(v)) f = 0x7FFFFFFF;
-            scratch[v] = f;                              // read back by this thread (own store) and, through the LDS chunks, by the others
-            remap[v] = f == 0x7FFFFFFF ? 0 : 1;
+            scratch[v] = f;                              // read back by this thread only
+            if (f != 0x7FFFFFFF) atomicOr(&bits[f >> 5], 1u << (f & 31));
         }
-        for (int base = 1; base <= vmax; base += TAIL_LDS) {
-            const int n = min(TAIL_LDS, vmax - base + 1);
-            __syncthreads();                             // the previous chunk has been read by everybody
-            for (int j = (int)threadIdx.x; j < n; j += NTHR) {
-                int f = ld_agent(&first[base + j]);      // (re-derived rather than read from scratch[]: written there by ANOTHER thread)
-                if (f != 0x7FFFFFFF && removed(base + j)) f = 0x7FFFFFFF;
-                s_first[j] = f;
-            }
+        __threadfence_block();
+        __syncthreads();
+        int run = 0;
+        for (int w = threadIdx.x * cw; w < min((int)(threadIdx.x + 1) * cw, nw); ++w) {
+            pref[w] = (unsigned)run;                     // kept first-pixels in this thread's chunk before word w
+            run += __popc(__hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        s_part[threadIdx.x] = run;
+        __threadfence_block();
+        __syncthreads();
+        for (int o = 1; o < NTHR; o <<= 1) {             // inclusive scan of the chunk totals
+            const int tv = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
             __syncthreads();
-            for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
-                const int f = scratch[v];
-                if (f == 0x7FFFFFFF) continue;
-                int r = 0;
-                for (int j = 0; j < n; ++j) r += s_first[j] < f;
-                remap[v] += r;
-            }
+            s_part[threadIdx.x] += tv;
+            __syncthreads();
         }
-        for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) kept += scratch[v] != 0x7FFFFFFF;
+        for (int v = 1 + (int)threadIdx.x; v <= vmax; v += NTHR) {
+            const int f = scratch[v];
+            if (f == 0x7FFFFFFF) { remap[v] = 0; continue; }
+            const int w = f >> 5, t = w / cw;
+            const unsigned below = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1u << (f & 31)) - 1u);
+            remap[v] = 1 + (t > 0 ? s_part[t - 1] : 0) + (int)__hip_atomic_load(&pref[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __popc(below);
+            ++kept;
+        }
     }
     if (kept) atomicAdd(&s_n, kept);
     __syncthreads();
@@ -1668,7 +1682,7 @@ __global__ void __launch_bounds__(NTHR) k_gather_f(const int32_t *__restrict__ p
     if (tail) {
         int *scal = WS(int, off_scal), *cnt = WS(int, off_cnt);
         const int vmax = min(scal[SC_NSEEDS], lay.L - 1);          // labels are the seed ranks 1..nseeds
-        tail_rank(vmax, WS(int, off_first), WS(int, off_remap), &scal[SC_NLAB], WS(int, off_rank),
+        tail_rank(vmax, WS(int, off_first), WS(int, off_remap), &scal[SC_NLAB], WS(int, off_rank), WS(unsigned, off_rankbits), lay.HW,
                   [&](int v) { return (double)cnt[v] > big; });
         return;
     }
@@ -1849,7 +1863,7 @@ __global__ void __launch_bounds__(NTHR) k_count_labels_f(int32_t *__restrict__ m
     }
     __threadfence();
     __syncthreads();
-    tail_rank(vm, first, WS(int, off_remap), &scal[SC_NLAB], WS(int, off_rank), [&](int v) { return ld_agent(&flag[v]) != 0; });
+    tail_rank(vm, first, WS(int, off_remap), &scal[SC_NLAB], WS(int, off_rank), WS(unsigned, off_rankbits), lay.HW, [&](int v) { return ld_agent(&flag[v]) != 0; });
     if (nlabels_out && threadIdx.x == 0) nlabels_out[blockIdx.y] = scal[SC_NLAB];
 }
 

@@ -463,16 +463,16 @@ def test_fused_chain_equals_stagewise_chain(cuda, vote, flow_thr):
     assert np.array_equal(norec[0], product[0]) and np.array_equal(norec[1], product[1]) and int(norec[4][0]) == -7
 
 
-@pytest.mark.parametrize("flow_thr", [0.0, 0.4])
-def test_fused_chain_with_more_labels_than_the_tail_lds_table(cuda, flow_thr):
-    """A dense 512 x 512 tile: sinks on a 6-px grid -> 85 x 85 = 7 225 labels, more than the 6 144 first-appearance entries the fused
-    chain's per-tile tail keeps in LDS, so its chunked ranking path runs (round 5: ranks through LDS chunks instead of ~vmax^2 / 256
-    uncached global loads per thread).  Ids, label counts and records bit-identical to the stage-wise chain; a second, sparse tile in
-    the same batch takes the LDS path."""
+@pytest.mark.parametrize("flow_thr,grid", [(0.0, 6), (0.4, 6), (0.0, 12)])
+def test_fused_chain_with_more_labels_than_the_tail_lds_table(cuda, flow_thr, grid):
+    """A dense 512 x 512 tile: sinks on a 6-px grid -> 85 x 85 = 7 225 labels (on a 12-px grid: 1 849), more than the 1 024 the fused
+    chain's per-tile tail ranks by comparison through LDS, so its positional ranking runs (round 5: a bitmap of the labels' first pixels and
+    the prefix counts of its words instead of every label against every other).  Ids, label counts and records bit-identical to the
+    stage-wise chain; a second, sparse tile in the same batch takes the LDS path."""
     from classpose_amd import _lib
     H = W = 512
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
-    cy, cx = (np.floor(yy / 6) * 6 + 2.5), (np.floor(xx / 6) * 6 + 2.5)
+    cy, cx = (np.floor(yy / grid) * grid + (grid - 1) / 2), (np.floor(xx / grid) * grid + (grid - 1) / 2)
     dense = np.stack([(cy - yy) * 2.5, (cx - xx) * 2.5]).astype(np.float32)
     sparse = _fields("discs", H, W, 41)
     dP = torch.from_numpy(np.stack([dense, sparse[0]])).to(cuda)
@@ -484,7 +484,7 @@ def test_fused_chain_with_more_labels_than_the_tail_lds_table(cuda, flow_thr):
             staged = _chain(L, dP, cp, None, flow_threshold=flow_thr)
         finally:
             L.cpx_postproc_set_fused(1)
-    assert int(staged[2][0]) > 6144 and 0 < int(staged[2][1]) < 6144, staged[2]
+    assert int(staged[2][0]) > (6144 if grid == 6 else 1024) and 0 < int(staged[2][1]) < 1024, staged[2]
     assert np.array_equal(product[0], staged[0]) and np.array_equal(product[2], staged[2]) and np.array_equal(product[4], staged[4])
     for a, b in zip(product[3], staged[3]):
         assert a.tobytes() == b.tobytes()
