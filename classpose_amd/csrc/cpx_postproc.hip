@@ -1048,7 +1048,9 @@ static void pp_launch_diffuse(const int32_t *masks, int nT, const PPLayout &lay,
     static CpxOncePerDevice once;
     once([] { (void)hipFuncSetAttribute((const void *)k_diffuse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIFF_BIG_LDS); });
     PP_LAUNCH(k_diffuse<false>, dim3(lay.L - 1 < 128 ? lay.L - 1 : 128, nT), dim3(NTHR), 0, s, masks, lay, ws);
-    PP_LAUNCH(k_diffuse<true>, dim3(lay.L - 1 < 32 ? lay.L - 1 : 32, nT), dim3(DIFF_BIG_THREADS), DIFF_BIG_LDS, s, masks, lay, ws);
+    // one 1024-thread workgroup per CU: 256 of them over the batch (32 per tile at 8 tiles, 128 at 2 tiles of 1024 px)
+    const int per_tile = nT >= 8 ? 32 : (nT <= 2 ? 128 : 256 / nT);
+    PP_LAUNCH(k_diffuse<true>, dim3(lay.L - 1 < per_tile ? lay.L - 1 : per_tile, nT), dim3(DIFF_BIG_THREADS), DIFF_BIG_LDS, s, masks, lay, ws);
 }
 
 // scipy.ndimage.mean: per-label sums accumulated in raster order (np.bincount), / count
