@@ -388,7 +388,11 @@ class Engine:
         # every label the dynamics can produce gets a record slot; ids are uint16, so 65535 bounds it
         # (fetch_* raise instead of dropping cells when a tile would exceed the buffer)
         self.max_rec = min(self.L.cpx_postproc_max_labels(H, W), 65535)
-        self.max_pts = nT * max(4096, H * W // 8)             # device vertex pool (f1), 16 B per vertex
+        # device vertex pool (f1), 16 B per vertex.  A contour visits a pixel at most twice (a one-pixel-wide limb is walked up one side and down the
+        # other), so 2 H W per tile can never overflow: 16.8 MB per slot for 8 tiles of 256 px.  (H W / 8 until round 5: a tile of 500 - 800 small
+        # nuclei produces 16 - 20 vertices each and overflowed it -- fetch_polygons then hands the whole batch to the host polygoniser,
+        # tools/poly_size_scan.py.)  Only the vertices a batch produced are copied back.
+        self.max_pts = nT * max(4096, 2 * H * W)
         self.slots = [_Slot(self) for _ in range(self.N_SLOTS)]
         self.s_net = torch.cuda.Stream(d, priority=int(os.environ.get("CPX_NET_STREAM_PRIORITY", "0")))
         # the post-processing chain is ~38 short kernels that run beside persistent network kernels holding every CU: a
