@@ -394,7 +394,9 @@ int cpx_polygonize_host(const uint16_t *masks_host, int H, int W, const cpx_reco
  * origins [nT][2] double (level-0 x, y of each tile); cells [nT][max_rec] (rows >= rec_counts[t]
  * untouched); vertex i of a cell = (x_px * scale + origin_x, y_px * scale + origin_y) at
  * xy_pool[2 * (offset + i)], offsets are an exclusive scan in (tile, record) order; n_pts_total [1]
- * receives the pool use (cells whose vertices would pass max_pts come back with n_pts = 0).
+ * receives the pool use (cells whose vertices would pass max_pts come back with n_pts = 0).  A contour visits a
+ * pixel at most twice, so max_pts = nT * 2 * H * W can never overflow (what classpose_amd.engine allocates: 16 B per
+ * vertex, 16.8 MB for 8 tiles of 256 px); only n_pts_total vertices need to leave the device.
  * Precondition: hole-free instances (what cpx_fill_holes_and_remove_small_masks produces); then the
  * outputs are bit-identical to cpx_polygonize_host.                                            */
 size_t cpx_polygonize_workspace_bytes(int nT, int H, int W, int max_rec);
