@@ -7,7 +7,7 @@ from classpose_amd import _lib, engine, synth
 dev = torch.device("cuda:0"); L = _lib.lib()
 sd = synth.make_state_dict(7, None, depth=24, seed=0)
 w = engine.NetWeights.from_state_dict(sd, "bf16", dev)
-for nS in (8, 16, 24, 32, 48, 64, 96):
+for nS in ([int(a) for a in sys.argv[1:]] or (8, 16, 24, 32, 48, 64, 96)):
     nbytes = L.cpx_net_workspace_bytes(nS, w.c.dtype)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     patches = (torch.randn(nS * 1024, 192, device=dev) * 0.5).to(torch.bfloat16)
