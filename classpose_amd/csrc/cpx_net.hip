@@ -720,7 +720,8 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
 // tiles neither OR their packed probabilities nor vote nor branch.  bf16 has float32's exponent range, so a probability above 2 is as accurate as one
 // below (the rescale of the production kernel only matters for fp16's range); what is lost is the guard against float32 overflow when a later score
 // exceeds the first tile's maximum by > ~80 octaves -- a production form would have to test the row sums for finiteness and re-run such an item.
-// NTL (round-5 experiment, debug build): the K / V^T ring requests carry the non-temporal hint
+// NTL (round-5 experiment, debug build): the query rows are loaded with the non-temporal hint (an earlier form put the hint on the K / V^T ring
+// requests: 184 -> 199 us, the eight query blocks of a head lose their L2 sharing)
 template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false, bool NV = false, bool NTL = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
@@ -754,16 +755,22 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
     auto issue = [&](int kh) {
         char *d = dma_dst + (kh & 3) * A4_SLOT;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ksrc + (size_t)kh * 32 * 3072),
-                                         (__attribute__((address_space(3))) void *)d, 16, 0, NTL ? 2 : 0);
+                                         (__attribute__((address_space(3))) void *)d, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc + kh * 32),
-                                         (__attribute__((address_space(3))) void *)(d + 4096), 16, 0, NTL ? 2 : 0);
+                                         (__attribute__((address_space(3))) void *)(d + 4096), 16, 0, 0);
     };
     issue(0); issue(1); issue(2);
 
     const unsigned short *qrow = qkv + (tok0 + qh * 32 + r) * 3072 + head * 64;
     uint4 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(qrow + 16 * ks + 8 * h2);
+    for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (NTL) {              // (experiment) the query rows are read once, by this workgroup only: non-temporal
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(qrow + 16 * ks + 8 * h2));
+            qf[ks] = make_uint4(q[0], q[1], q[2], q[3]);
+        } else qf[ks] = *reinterpret_cast<const uint4 *>(qrow + 16 * ks + 8 * h2);
+    }
     // G = Q . table^T -> this wave's fp16 scratch [q][j] (values are bias / scale, |G| < ~60: fp16 keeps 2^-11 relative)
     _Float16 *G = reinterpret_cast<_Float16 *>(a4_smem + 4 * A4_SLOT) + wave * 32 * A4_G_LD;
     auto compute_G = [&](const unsigned short *table) {
