@@ -360,6 +360,52 @@ def test_compute_masks_repeatable_under_load(cuda):
     assert np.array_equal(ops.masks_to_numpy(first[0][3]), want.astype(np.uint16))
 
 
+def test_compute_masks_with_large_instances_repeatable_under_load_and_equal_to_the_oracle(cuda):
+    """Race screen for round 5's large-instance paths -- the diffusion's second launch (two-plane and one-plane LDS forms, global
+    planes), the four-rows-per-lane hole fill, the LDS window of the Euler loop with positions that leave it: tiles of discs of radius
+    20 / 34 / 50 / 70 (boxes of 41 .. 141 pixels) with pinholes punched into the cell probability, 12 runs under a concurrent GEMM
+    stream must give bit-identical id maps and label counts; one tile is checked against the oracle."""
+    H = W = 256
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    tiles = []
+    for R in (20, 34, 50, 70):
+        dP = np.zeros((2, H, W), np.float32); cp = np.full((H, W), -5.0, np.float32)
+        step = 2 * R + 5
+        for cy in range(R + 2, H - R - 2, step):
+            for cx in range(R + 2, W - R - 2, step):
+                dy, dx = cy - yy, cx - xx
+                r = np.sqrt(dy * dy + dx * dx)
+                inside = r <= R
+                k = 5.0 / np.maximum(r, 1.0)
+                dP[0][inside] = (dy * k)[inside]; dP[1][inside] = (dx * k)[inside]
+                cp[inside] = 5.0
+                cp[cy - R // 2: cy - R // 2 + 2, cx + 3: cx + 6] = -5.0            # a pinhole: background pixels inside the disc
+        tiles.append((dP, cp))
+    dP = torch.from_numpy(np.stack([t[0] for t in tiles] * 2)).to(cuda)
+    cp = torch.from_numpy(np.stack([t[1] for t in tiles] * 2)).to(cuda)
+    side = torch.cuda.Stream(device=cuda)
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(8192, 1024, generator=g).to(torch.bfloat16).to(cuda)
+    Wt = torch.randn(4096, 1024, generator=g).to(torch.bfloat16).to(cuda)
+    first = None
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                ops.gemm(A, Wt, "gelu")
+        m, cm, nl = ops.compute_masks(dP, cp, None)
+        cur = (m.clone(), nl.clone())
+        if first is None:
+            first = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(cur, first)), f"run {it} differs"
+    torch.cuda.synchronize()
+    assert [int(v) for v in first[1][:4]] == [int(v) for v in first[1][4:]]
+    for t in (1, 3):
+        want = dynamics.compute_masks(tiles[t][0], tiles[t][1])
+        assert want.max() >= 1
+        assert np.array_equal(ops.masks_to_numpy(first[0][t]), want.astype(np.uint16)), t
+
+
 def test_compute_masks_equals_reference_eval_golden(cuda):
     """The HIP dynamics + class vote on the network fields of the reference's own ``ClassposeModel.eval`` run
     (tests/golden/reference_eval.npz, minted by make_golden_eval.py; the fields are regenerated with the oracle's
