@@ -722,7 +722,9 @@ __device__ __forceinline__ uint4 a4_read128(unsigned addr) {
 // exceeds the first tile's maximum by > ~80 octaves -- a production form would have to test the row sums for finiteness and re-run such an item.
 // NTL (round-5 experiment, debug build): the query rows are loaded with the non-temporal hint (an earlier form put the hint on the K / V^T ring
 // requests: 184 -> 199 us, the eight query blocks of a head lose their L2 sharing)
-template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false, bool NV = false, bool NTL = false>
+// PRIO (round-5 experiment, debug build): wave priority by phase -- s_setprio 3 around a tile's matrix instructions and 0 around its softmax stream
+// measured 189.2 -> 193.8 us, the inverse (this form: 0 around the MFMAs, 2 otherwise) 186.4 -> 189.2: the three waves of a SIMD arbitrate better unaided
+template <bool F16, bool DBG = false, bool LSUM = false, bool ERD = false, bool NV = false, bool NTL = false, bool PRIO = false>
 __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned short *__restrict__ qkv,
                                                                 const unsigned short *__restrict__ vT,
                                                                 const unsigned short *__restrict__ relh,
@@ -817,10 +819,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
         const uint4 k2 = a4_read128<SL * A4_SLOT>(ka[2]), k3 = a4_read128<SL * A4_SLOT>(ka[3]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         f32x16 S = mfma32<F16>(k0, qf[0], GW);
         S = mfma32<F16>(k1, qf[1], S);
         S = mfma32<F16>(k2, qf[2], S);
         S = mfma32<F16>(k3, qf[3], S);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
         return S;
     };
     using std::integral_constant;
@@ -935,11 +939,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) k_attention4p(const unsigned s
             const uint4 v10 = a4_read128<SL * A4_SLOT>(va[2]), v11 = a4_read128<SL * A4_SLOT>(va[3]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             O0 = mfma32<F16>(v00, pf0, O0);
             O1 = mfma32<F16>(v10, pf0, O1);
             O0 = mfma32<F16>(v01, pf1, O0);
             O1 = mfma32<F16>(v11, pf1, O1);
             if constexpr (LSUM) { Lacc = mfma32<F16>(ones, pf0, Lacc); Lacc = mfma32<F16>(ones, pf1, Lacc); }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
         }
         A4_STAMP(3);
         S = Sn;
@@ -1111,6 +1117,14 @@ int cpx_attention_half(int dtype, const void *qkv, const void *rel_h, const void
         static CpxOncePerDevice once4t;
         once4t([] { (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); });
         hipLaunchKernelGGL((k_attention4p<false, false, false, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
+                           (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
+        CPX_CHECK_LAUNCH();
+        return CPX_OK;
+    }
+    if (g_att_lsum == 5 && dtype != CPX_DT_F16) {           // round-5 experiment: wave priority around the matrix instructions (k_attention4p<.., PRIO>), bf16
+        static CpxOncePerDevice once4q;
+        once4q([] { (void)hipFuncSetAttribute((const void *)k_attention4p<false, false, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); });
+        hipLaunchKernelGGL((k_attention4p<false, false, false, false, false, false, true>), grid4, dim3(ATT_THREADS), A4_LDS_BYTES, s, (const unsigned short *)qkv, (const unsigned short *)vT_ws,
                            (const unsigned short *)rel_h, (const unsigned short *)rel_w, (unsigned short *)out, g_att_xcd);
         CPX_CHECK_LAUNCH();
         return CPX_OK;
