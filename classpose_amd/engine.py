@@ -420,8 +420,12 @@ class Engine:
             raise ValueError(f"Engine.submit: got {tuple(tiles_u8.shape)}, this engine takes at most {self.nT} tiles of {(self.H, self.W, 3)}")
         if tiles_u8.device != self.dev:
             raise ValueError(f"Engine.submit: tiles live on {tiles_u8.device}, the engine on {self.dev}")
-        if inject is not None and (len(inject) != 3 or any(t.device != self.dev or not t.is_contiguous() for t in inject)):
-            raise ValueError("Engine.submit: inject = (dP, cellprob, logits) contiguous tensors on the engine's device")
+        if inject is not None:
+            # logits may be None for a model without a class head (ncls <= 1: the chain never takes its pointer); dP and cellprob may not
+            if len(inject) != 3 or inject[0] is None or inject[1] is None or (inject[2] is None and self.w.ncls > 1):
+                raise ValueError("Engine.submit: inject = (dP, cellprob, logits) device tensors (logits may be None only without a class head)")
+            if any(t is not None and (t.device != self.dev or not t.is_contiguous()) for t in inject):
+                raise ValueError("Engine.submit: inject = (dP, cellprob, logits) contiguous tensors on the engine's device")
         sid = self._next
         self._next = (self._next + 1) % self.N_SLOTS
         sl = self.slots[sid]

@@ -154,10 +154,13 @@ class TileStream:
                 with self._pe_lock:
                     pe = self.pinned_extra.get(slot)
                     if pe is None:
-                        pe = tuple(torch.empty((self.nT,) + tuple(a.shape), dtype=torch.from_numpy(np.asarray(a)).dtype).pin_memory() for a in arrs)
+                        # (a side input may be None -- the class logits of a model without a class head: no buffer, None on the device side too)
+                        pe = tuple(None if a is None else
+                                   torch.empty((self.nT,) + tuple(a.shape), dtype=torch.from_numpy(np.asarray(a)).dtype).pin_memory() for a in arrs)
                         self.pinned_extra[slot] = pe
             for dst, a in zip(pe, arrs):
-                dst[k].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+                if dst is not None:
+                    dst[k].copy_(torch.from_numpy(np.ascontiguousarray(a)))
             return True
         return chunk, slot, [self.readers.submit(read, k, ti) for k, ti in enumerate(chunk)]
 
@@ -184,7 +187,7 @@ class TileStream:
                 with torch.cuda.stream(self.copy_stream):
                     dev = self.pinned[slot][: len(chunk)].to(self.dev, non_blocking=True)
                     if extras and extras[0] is not None:           # the side inputs of the batch, device tensors by the same event
-                        extras = tuple(t[: len(chunk)].to(self.dev, non_blocking=True) for t in self.pinned_extra[slot])
+                        extras = tuple(None if t is None else t[: len(chunk)].to(self.dev, non_blocking=True) for t in self.pinned_extra[slot])
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 self.copied[slot] = ev
@@ -400,7 +403,8 @@ def run_rank(args, rank: int, world: int, device: torch.device):
             if extra is not None:                # the plug-in's fields arrive as device tensors of the same copy-stream event (TileStream)
                 inject = tuple(f)
                 for t_ in inject:
-                    t_.record_stream(cur)
+                    if t_ is not None:
+                        t_.record_stream(cur)
             sid = eng.submit(tiles_dev, inject=inject, records=True,
                              polygons=(scale, [plan.coords[ti][0] for ti in chunk]))
             stage["resize + submit"] += time.time() - t_r

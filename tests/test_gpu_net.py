@@ -238,8 +238,9 @@ def test_gemm_lin1_one_wave_per_simd_equals_the_eight_wave_kernel(cuda, M, N):
 
 @pytest.mark.parametrize("M,K", [(65536, 256), (65536, 1024), (131072, 512), (65536, 4096)])
 def test_gemm_resid_stats_one_wave_per_simd_equals_the_eight_wave_kernel(cuda, M, K):
-    """PRODUCTION attn.proj / mlp.lin2 (bf16: bias, residual add with the reference's double rounding, partial LayerNorm statistics of the
-    output rows) on csrc/cpx_gemm4w.hip against k_gemm256p<RESID, STATS | BAL> (cpx_gemm_set_4w(0), debug build): outputs AND statistics bit
+    """DEBUG-BUILD ONLY path (cpx_gemm_set_4w(3); the product keeps attn.proj / mlp.lin2 on k_gemm256p, default switch value 1): bias,
+    residual add with the reference's double rounding, partial LayerNorm statistics of the
+    output rows on csrc/cpx_gemm4w.hip against k_gemm256p<RESID, STATS | BAL> (cpx_gemm_set_4w(0), debug build): outputs AND statistics bit
     for bit -- the 32-chunk summation tree of the staged epilogue is rebuilt from lane-row swaps, registers and one LDS hand-over --, one
     and two tiles per workgroup, K = 256 (only the peeled K tiles run) to 4096, and in place (out == residual, as the engine calls it)."""
     N = 1024
@@ -260,7 +261,7 @@ def test_gemm_resid_stats_one_wave_per_simd_equals_the_eight_wave_kernel(cuda, M
             L.cpx_gemm_set_4w(0)
             eight, est = ops.gemm_ln(A, W, "resid", bias, res, want_stats=True)
         finally:
-            L.cpx_gemm_set_4w(3)
+            L.cpx_gemm_set_4w(1)                                              # the production default (mlp.lin1 only on the one-wave kernel)
     assert torch.equal(prod, eight) and torch.equal(four, eight) and torch.equal(x, eight)
     assert torch.equal(pst, est) and torch.equal(fst, est) and torch.equal(st, est)
     ref = (A[:256].float() @ W.float().T + bias).to(torch.bfloat16).float() + res[:256].float()

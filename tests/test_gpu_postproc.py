@@ -536,6 +536,55 @@ def test_fused_chain_with_more_labels_than_the_tail_lds_table(cuda, flow_thr, gr
         assert a.tobytes() == b.tobytes()
     m = product[0][0].astype(np.int64)
     assert len(np.unique(m[m > 0])) == int(product[2][0])          # ids are 1..n without gaps
+    # ... and against the ORACLE (round-5 review: the positional ranking and the LDS-chunk tail had only been compared with another path
+    # through the same library): cellpose's get_masks_torch -> flow-error filter -> fill_holes_and_remove_small_masks -> fastremap.renumber
+    # restated in oracle/dynamics.py (reference: models.py:149-159), both tiles of the batch, ids and label counts bit for bit
+    for t, (a, b) in enumerate([(dense, np.ones((H, W), np.float32)), (sparse[0], sparse[1])]):
+        want = dynamics.compute_masks(a, b, flow_threshold=flow_thr if flow_thr > 0 else None)
+        assert int(want.max()) == int(product[2][t]), (t, int(want.max()), int(product[2][t]))
+        assert np.array_equal(product[0][t], want.astype(np.uint16)), t
+        r = product[3][t]
+        area = np.bincount(want.ravel().astype(np.int64), minlength=int(want.max()) + 1)[1:]
+        assert len(r) == want.max() and np.array_equal(r["label"], np.arange(1, want.max() + 1)) and np.array_equal(r["area"], area)
+
+
+@pytest.mark.parametrize("R,H", [(67, 256), (100, 512), (180, 512)])
+def test_fused_chain_large_box_diffusion_on_global_planes_equals_oracle(cuda, R, H):
+    """ONE label whose box (2R + 1 = 135 / 201 / 361 px) exceeds the 133 x 133 px the diffusion's LDS forms hold: inside the FUSED product chain
+    (cpx_compute_masks_records, flow_threshold 0.4) its fp64 heat diffusion runs on the global planes (k_diffuse, second launch).  Ids, label
+    count and the record against the oracle (cellpose remove_bad_flow_masks / masks_to_flows_gpu restated in oracle/dynamics.py, reference
+    call models.py:149-159).  The big disc is off-centre and has a pinhole; small discs sit in the corners, one of them with its flows turned by
+    90 degrees so that the filter has a label to remove beside the ones it keeps."""
+    from classpose_amd import _lib
+    W = H
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    dP = np.zeros((2, H, W), np.float32); cp = np.full((H, W), -5.0, np.float32)
+
+    def disc(cy, cx, rad, rotate=False):
+        dy, dx = cy - yy, cx - xx
+        r = np.sqrt(dy * dy + dx * dx)
+        inside = r <= rad
+        k = 5.0 / np.maximum(r, 1.0)
+        fy, fx = ((dx * k), (-dy * k)) if rotate else ((dy * k), (dx * k))
+        dP[0][inside] = fy[inside]; dP[1][inside] = fx[inside]
+        cp[inside] = 5.0
+    disc(H // 2 - 3, W // 2 + 2, R)
+    cp[H // 2 - R // 2: H // 2 - R // 2 + 2, W // 2 + 5: W // 2 + 9] = -5.0             # a pinhole inside the big disc
+    for cy, cx in ((12, 12), (12, W - 14), (H - 13, 13)):
+        if (cy - (H // 2 - 3)) ** 2 + (cx - (W // 2 + 2)) ** 2 > (R + 12) ** 2:
+            disc(cy, cx, 9)
+    if R < 150:
+        disc(H - 13, W - 14, 9, rotate=True)                                            # flows turned by 90 degrees: fails the flow-error test
+    sparse = _fields("discs", H, W, 17)
+    dPb = torch.from_numpy(np.stack([dP, sparse[0]])).to(cuda)
+    cpb = torch.from_numpy(np.stack([cp, sparse[1]])).to(cuda)
+    got = _chain(_lib.lib(), dPb, cpb, None, flow_threshold=0.4)
+    for t, (a, b) in enumerate([(dP, cp), (sparse[0], sparse[1])]):
+        want = dynamics.compute_masks(a, b, flow_threshold=0.4)
+        assert want.max() >= 1
+        assert int(got[2][t]) == int(want.max()) and np.array_equal(got[0][t], want.astype(np.uint16)), t
+    big = got[3][0][np.argmax(got[3][0]["area"])]
+    assert big["y1"] - big["y0"] + 1 > 133 and big["x1"] - big["x0"] + 1 > 133, big
 
 
 def test_fused_chain_repeatable_under_load_and_odd_sizes(cuda):
