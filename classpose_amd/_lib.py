@@ -91,6 +91,8 @@ SIGNATURES = {
     "cpx_blend_subtiles": (_i, [_p, _i, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
     "cpx_blend_subtiles_nchw": (_i, [_p, _p, _i, _i, C.POINTER(CpxTiling), _p, _p, _p, _p, _p]),
     "cpx_qc_forward": (_i, [C.POINTER(CpxQcOp), _i, _p, _i, _i, _i, _sz, _sz, _i, _i, _p, _p, _p, _sz, _p]),
+    "cpx_round_weights": (_i, [_p, _p, C.c_longlong, _i, _i, _p]),
+    "cpx_fold_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "cpx_net_workspace_bytes": (_sz, [_i, _i]),
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
     "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i, _i]),

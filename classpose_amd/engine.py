@@ -135,15 +135,39 @@ class NetWeights:
         self = cls()
         dev = torch.device(device)
 
+        # Round 6: the checkpoint is uploaded as stored (float32) and rounded / folded ON THE DEVICE (csrc/cpx_weights.hip:
+        # cpx_round_weights, cpx_fold_layernorm).  Until round 5 the host did both: 0.6 s at one rank, 3.5 - 4.7 s per rank with
+        # eight ranks on a 16-core quota.  Kernels run on the calling thread's current stream; the float32 staging tensors are
+        # freed (back to torch's caching allocator) when this function returns.
+        L = _lib.lib()
+        dtc = _lib.DTYPE_CODE[precision]
+        if dev.type != "cuda" and precision != "fp32":
+            # (float32 on a CPU device is the host-side packing only -- tests/test_host_logic.py reads the op list back; nothing rounds)
+            raise _lib.CpxError("NetWeights: the half-precision operands are rounded and folded by HIP kernels; there is no CPU path")
+        sptr = lambda: torch.cuda.current_stream(dev).cuda_stream
+
+        def up32(t):        # float32 copy of a parameter on the device (any stored dtype; a bf16 / fp16 checkpoint widens exactly)
+            x = t.detach()
+            if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                x = x.float()
+            x = x.contiguous().to(dev)
+            return x if x.dtype == torch.float32 else x.float()
+
+        def rounded_on_device(t, keep_f32):
+            x = up32(t)
+            if hd == torch.float32 or x.numel() == 0:
+                self.keep.append(x)
+                return x if (keep_f32 or hd == torch.float32) else x.to(hd)
+            out = torch.empty(x.shape, dtype=torch.float32 if keep_f32 else hd, device=dev)
+            check(L.cpx_round_weights(x.data_ptr(), out.data_ptr(), x.numel(), dtc, int(keep_f32), sptr()), "round_weights")
+            self.keep.append(out)
+            return out
+
         def half(t):        # GEMM operand: stays in the half dtype
-            x = t.detach().to(hd).contiguous().to(dev)
-            self.keep.append(x)
-            return x.data_ptr()
+            return rounded_on_device(t, False).data_ptr()
 
         def vec(t):         # epilogue vector: rounded through the half dtype, kept as f32
-            x = t.detach().to(hd).float().contiguous().to(dev)
-            self.keep.append(x)
-            return x.data_ptr()
+            return rounded_on_device(t, True).data_ptr()
 
         c = self.c
         c.depth, c.ncls = depth, ncls
@@ -154,12 +178,17 @@ class NetWeights:
         c.fuse_ln = int(bool(fuse_ln))
 
         def fold_ln(w, b, gamma, beta):
-            """LayerNorm folded into the following Linear: (W diag(gamma), b + W beta, row sums of
-            the folded half-rounded W).  All inputs are first rounded to the half dtype (net.to(dtype))."""
-            wq, bq = w.detach().to(hd).float(), b.detach().to(hd).float()
-            gq, btq = gamma.detach().to(hd).float(), beta.detach().to(hd).float()
-            wf = (wq * gq[None, :]).to(hd)
-            return wf, bq + wq @ btq, wf.float().sum(1)
+            """LayerNorm folded into the following Linear: (W diag(gamma), b + W beta, row sums of the folded half-rounded W) as
+            device pointers.  All inputs are first rounded to the half dtype (net.to(dtype)); cpx_fold_layernorm, float64 sums."""
+            N, K = w.shape
+            wf = torch.empty((N, K), dtype=hd, device=dev)
+            bf = torch.empty(N, dtype=torch.float32, device=dev)
+            cs = torch.empty(N, dtype=torch.float32, device=dev)
+            src = [up32(t) for t in (w, b, gamma, beta)]       # (held until the launch is queued: a freed block is re-used in stream order)
+            check(L.cpx_fold_layernorm(*[t.data_ptr() for t in src], N, K, dtc,
+                                       wf.data_ptr(), bf.data_ptr(), cs.data_ptr(), sptr()), "fold_layernorm")
+            self.keep += [wf, bf, cs]
+            return wf.data_ptr(), bf.data_ptr(), cs.data_ptr()
 
         def vec32(t):       # already float32, no re-rounding
             x = t.detach().float().contiguous().to(dev)
@@ -176,7 +205,7 @@ class NetWeights:
             if fuse_ln:
                 wf, bf, cs = fold_ln(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"],
                                      sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-                b.qkv_w, b.qkv_b, b.qkv_colsum = half(wf), vec32(bf), vec32(cs)
+                b.qkv_w, b.qkv_b, b.qkv_colsum = wf, bf, cs
             else:
                 b.qkv_w, b.qkv_b = half(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
             b.proj_w, b.proj_b = half(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
@@ -190,7 +219,7 @@ class NetWeights:
             if fuse_ln:
                 wf, bf, cs = fold_ln(sd[p + "mlp.lin1.weight"], sd[p + "mlp.lin1.bias"],
                                      sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-                b.fc1_w, b.fc1_b, b.fc1_colsum = half(wf), vec32(bf), vec32(cs)
+                b.fc1_w, b.fc1_b, b.fc1_colsum = wf, bf, cs
             else:
                 b.fc1_w, b.fc1_b = half(sd[p + "mlp.lin1.weight"]), vec(sd[p + "mlp.lin1.bias"])
             b.fc2_w, b.fc2_b = half(sd[p + "mlp.lin2.weight"]), vec(sd[p + "mlp.lin2.bias"])
@@ -217,6 +246,8 @@ class NetWeights:
             self._build_unet_ops(sd, fts, ncls * 64, half, vec32)
         self.ncls, self.depth, self.precision, self.device = ncls, depth, precision, dev
         self.fts = fts
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()  # the operands are final before any other stream may read them
         return self
 
     def _build_unet_ops(self, sd, fts, out_ch, half, vec32):

@@ -188,6 +188,22 @@ typedef struct cpx_net_weights {
     void *prof;             /* NULL, or a handle from cpx_prof_create: per-launch HIP-event timing   */
 } cpx_net_weights;
 
+/* ------------------------------------------------------------------------
+ * a5  checkpoint -> kernel operands on the device (round 6, additive: no ABI bump)
+ * replaces the host-side `net.to(torch.bfloat16 | torch.float16)` of ClassposeModel.__init__ as driven by
+ * /root/reference/src/classpose/entrypoints/predict_wsi.py:659-727 (`resolve_precision`, models.py:37-69): the float32
+ * checkpoint is uploaded as stored and rounded here.
+ *   cpx_round_weights   dst[i] = round-to-nearest-even(src[i]) in `dtype`; keep_f32 = 0: stored as 2-byte elements (GEMM operands),
+ *                       keep_f32 = 1: widened back to float32 (epilogue vectors).  dtype = CPX_DT_F32: a copy (keep_f32 must be 1).
+ *                       src and dst 16-byte aligned; dst may not alias src unless keep_f32.
+ *   cpx_fold_layernorm  LayerNorm folded into the Linear that consumes it (cpx_net_weights.fuse_ln): with every input first rounded to
+ *                       `dtype`, w_folded[n][k] = round(w[n][k] * gamma[k]), b_folded[n] = b[n] + sum_k w[n][k] beta[k],
+ *                       colsum[n] = sum_k w_folded[n][k]; both sums in float64 (fixed order), rounded once to float32.
+ *                       w [N][K] float32, w_folded [N][K] 2-byte elements.                                                        */
+int cpx_round_weights(const float *src, void *dst, long long n, int dtype, int keep_f32, void *stream);
+int cpx_fold_layernorm(const float *w, const float *b, const float *gamma, const float *beta, int N, int K, int dtype,
+                       void *w_folded, float *b_folded, float *colsum, void *stream);
+
 size_t cpx_net_workspace_bytes(int n_subtiles, int dtype);
 /* extra bytes (appended to the network workspace) when w->n_unet_ops > 0 */
 size_t cpx_unet_workspace_bytes(const cpx_conv_op *ops_host, int n_ops, int n_subtiles, int dtype);

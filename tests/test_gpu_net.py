@@ -842,3 +842,82 @@ def test_benched_path_all_subtiles_vs_reference_style_torch_on_gpu(cuda):
           f"rel-L2 {e_torch:.4f}; speed-up {ms_torch / ms_ours:.2f}x")
     assert max(e_ours) < 2e-2
     assert np.mean(e_ours) < 1.5 * e_torch + 2e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_round_weights_on_the_device_equals_net_to_dtype(cuda, precision):
+    """cpx_round_weights == torch's `.to(torch.bfloat16 | torch.float16)` on the host (what `net.to(dtype)` does to every parameter of the
+    reference, models.py:37-69 / predict_wsi.py:659-727) bit for bit: random values over 40 binades, exact ties in both directions, the largest
+    finite values and beyond, denormals of the target type, +-0, +-inf; odd lengths (the scalar tail); both output forms."""
+    import ctypes as C
+    hd = {"bf16": torch.bfloat16, "fp16": torch.float16}[precision]
+    dtc = _lib.DTYPE_CODE[precision]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(100003, generator=g) * torch.exp2(torch.randint(-24, 17, (100003,), generator=g).float())
+    mant = 8 if precision == "bf16" else 11
+    ties = (torch.arange(1, 4097).float() * 2 + 1) * 2.0 ** -(mant + 1) * 2.0 ** 3          # odd multiples of half an ulp at 2^3 .. 2^4: exact ties
+    special = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), 65504.0, 65519.9, 65520.0, 70000.0, -70000.0, 3.3895e38, 3.4e38,
+                            6e-8, 2.9e-8, 3.1e-8, 1e-40, -1e-40, 5.96e-8, 6.1e-5, 9.2e-41])
+    x = torch.cat([x, ties, -ties, special])
+    L = _lib.lib()
+    xd = x.to(cuda)
+    for n in (x.numel(), 5, 3, 1):
+        out_h = torch.zeros(n, dtype=hd, device=cuda)
+        out_f = torch.zeros(n, dtype=torch.float32, device=cuda)
+        s = torch.cuda.current_stream(cuda).cuda_stream
+        _lib.check(L.cpx_round_weights(xd.data_ptr(), out_h.data_ptr(), n, dtc, 0, s), "round_weights")
+        _lib.check(L.cpx_round_weights(xd.data_ptr(), out_f.data_ptr(), n, dtc, 1, s), "round_weights")
+        want = x[:n].to(hd)
+        assert torch.equal(out_h.cpu().view(torch.int16), want.view(torch.int16))
+        assert torch.equal(out_f.cpu().view(torch.int32), want.float().view(torch.int32))
+
+
+@pytest.mark.parametrize("precision,N,K", [("bf16", 3072, 1024), ("fp16", 4096, 1024), ("bf16", 7, 100), ("fp16", 64, 4096)])
+def test_fold_layernorm_on_the_device(cuda, precision, N, K):
+    """cpx_fold_layernorm (LayerNorm folded into attn.qkv / mlp.lin1; the reference runs norm1 / norm2 as separate ops, vit_sam.py:30-33,
+    175-176): folded weights bit-identical to the host fold of rounds 2 - 5 (`(w.to(hd).float() * gamma.to(hd).float()).to(hd)`); folded
+    bias and row sums bit-identical to the float64 restatement rounded once to float32, and within float32 summation noise of the host fold."""
+    hd = {"bf16": torch.bfloat16, "fp16": torch.float16}[precision]
+    g = torch.Generator().manual_seed(N + K)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gamma = 1 + 0.2 * torch.randn(K, generator=g)
+    beta = 0.1 * torch.randn(K, generator=g)
+    L = _lib.lib()
+    wf = torch.empty((N, K), dtype=hd, device=cuda)
+    bf = torch.empty(N, dtype=torch.float32, device=cuda)
+    cs = torch.empty(N, dtype=torch.float32, device=cuda)
+    dev = [t.to(cuda) for t in (w, b, gamma, beta)]
+    _lib.check(L.cpx_fold_layernorm(*[t.data_ptr() for t in dev], N, K, _lib.DTYPE_CODE[precision], wf.data_ptr(), bf.data_ptr(),
+                                    cs.data_ptr(), torch.cuda.current_stream(cuda).cuda_stream), "fold_layernorm")
+    wq, bq, gq, btq = (t.to(hd).float() for t in (w, b, gamma, beta))
+    wf_host = (wq * gq[None, :]).to(hd)
+    assert torch.equal(wf.cpu().view(torch.int16), wf_host.view(torch.int16))
+    dot64 = (wq.double() * btq.double()[None, :]).sum(1)
+    bf64 = (bq + dot64.float())
+    cs64 = wf_host.double().sum(1).float()
+    assert torch.equal(bf.cpu(), bf64) and torch.equal(cs.cpu(), cs64)
+    assert torch.allclose(bf.cpu(), bq + wq @ btq, rtol=1e-5, atol=1e-6) and torch.allclose(cs.cpu(), wf_host.float().sum(1), rtol=1e-5, atol=1e-5)
+
+
+def test_net_weights_converted_on_the_device_equal_the_host_conversion(cuda):
+    """NetWeights.from_state_dict (round 6: upload float32, round / fold on the device) against the host-side conversion it replaced, tensor by
+    tensor on a depth-2 synthetic checkpoint in both half precisions and float32: every GEMM operand and every rounded vector bit-identical."""
+    sd = synth.make_state_dict(7, depth=2, seed=11)
+    for precision in ("bf16", "fp16", "fp32"):
+        hd = engine.NET_DTYPES[precision]
+        w = engine.NetWeights.from_state_dict(sd, precision, cuda)
+        kept = {t.data_ptr(): t for t in w.keep}
+        get = lambda p: kept[p].cpu()
+        b0 = w.blocks[0]
+        assert torch.equal(get(b0.proj_w).view(-1), sd["encoder.blocks.0.attn.proj.weight"].to(hd).reshape(-1))
+        assert torch.equal(get(b0.proj_b), sd["encoder.blocks.0.attn.proj.bias"].to(hd).float())
+        assert torch.equal(get(b0.fc2_w).view(-1), sd["encoder.blocks.0.mlp.lin2.weight"].to(hd).reshape(-1))
+        assert torch.equal(get(w.c.pos).view(-1), sd["encoder.pos_embed"].to(hd).float().reshape(-1))
+        assert torch.equal(get(w.c.pe_w).view(-1), sd["encoder.patch_embed.proj.weight"].to(hd).reshape(-1))
+        if precision != "fp32":
+            wq = sd["encoder.blocks.1.mlp.lin1.weight"].to(hd).float()
+            gq = sd["encoder.blocks.1.norm2.weight"].to(hd).float()
+            assert torch.equal(get(w.blocks[1].fc1_w), (wq * gq[None, :]).to(hd))
+        else:
+            assert torch.equal(get(w.blocks[1].fc1_w), sd["encoder.blocks.1.mlp.lin1.weight"])
