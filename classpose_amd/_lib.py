@@ -64,6 +64,14 @@ class CpxNetWeights(C.Structure):
                 ("n_unet_ops", C.c_int), ("unet_ops", C.POINTER(CpxConvOp)), ("prof", C.c_void_p)]
 
 
+class CpxWeightJob(C.Structure):
+    _fields_ = [("op", C.c_int), ("dtype", C.c_int), ("n", C.c_longlong), ("K", C.c_int), ("reserved", C.c_int),
+                ("src_host", C.c_void_p * 4), ("stage_off", C.c_size_t * 4), ("dst", C.c_void_p * 3)]
+
+
+WJ_ROUND_HALF, WJ_ROUND_F32, WJ_COPY_F32, WJ_FOLD_LN = 0, 1, 2, 3
+
+
 class CpxRecord(C.Structure):
     _fields_ = [("tile", C.c_int32), ("label", C.c_int32), ("cls", C.c_int32), ("area", C.c_int32),
                 ("y0", C.c_int32), ("x0", C.c_int32), ("y1", C.c_int32), ("x1", C.c_int32),
@@ -93,6 +101,7 @@ SIGNATURES = {
     "cpx_qc_forward": (_i, [C.POINTER(CpxQcOp), _i, _p, _i, _i, _i, _sz, _sz, _i, _i, _p, _p, _p, _sz, _p]),
     "cpx_round_weights": (_i, [_p, _p, C.c_longlong, _i, _i, _p]),
     "cpx_fold_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "cpx_weights_build": (_i, [C.POINTER(CpxWeightJob), _i, _p, _sz, _p]),
     "cpx_net_workspace_bytes": (_sz, [_i, _i]),
     "cpx_net_forward": (_i, [C.POINTER(CpxNetWeights), _p, _i, _p, _p, _sz, _p]),
     "cpx_unet_workspace_bytes": (_sz, [C.POINTER(CpxConvOp), _i, _i, _i]),

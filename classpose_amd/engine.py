@@ -135,39 +135,57 @@ class NetWeights:
         self = cls()
         dev = torch.device(device)
 
-        # Round 6: the checkpoint is uploaded as stored (float32) and rounded / folded ON THE DEVICE (csrc/cpx_weights.hip:
-        # cpx_round_weights, cpx_fold_layernorm).  Until round 5 the host did both: 0.6 s at one rank, 3.5 - 4.7 s per rank with
-        # eight ranks on a 16-core quota.  Kernels run on the calling thread's current stream; the float32 staging tensors are
-        # freed (back to torch's caching allocator) when this function returns.
+        # Round 6: the checkpoint is uploaded as stored (float32) and rounded / folded ON THE DEVICE (csrc/cpx_weights.hip).  Until
+        # round 5 the host did both: 0.6 s at one rank, 3.5 - 4.7 s per rank with eight ranks on a 16-core quota.  The helpers below
+        # only LIST what every parameter becomes (output tensors allocated, one cpx_weight_job each); ONE foreign call at the end
+        # (cpx_weights_build) streams the sources host -> staging and queues the kernels -- per-tensor calls re-acquired the
+        # interpreter lock ~600 times against the slide readers' threads: 2.5 s per rank at eight ranks for 0.3 s of work.
         L = _lib.lib()
         dtc = _lib.DTYPE_CODE[precision]
-        if dev.type != "cuda" and precision != "fp32":
+        on_gpu = dev.type == "cuda"
+        if not on_gpu and precision != "fp32":
             # (float32 on a CPU device is the host-side packing only -- tests/test_host_logic.py reads the op list back; nothing rounds)
             raise _lib.CpxError("NetWeights: the half-precision operands are rounded and folded by HIP kernels; there is no CPU path")
-        sptr = lambda: torch.cuda.current_stream(dev).cuda_stream
+        jobs, sources, stage_bytes = [], [], 0
 
-        def up32(t):        # float32 copy of a parameter on the device (any stored dtype; a bf16 / fp16 checkpoint widens exactly)
+        def host32(t):      # contiguous float32 host view of a parameter (a bf16 / fp16 checkpoint widens exactly), kept alive until the call
             x = t.detach()
-            if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
-                x = x.float()
-            x = x.contiguous().to(dev)
-            return x if x.dtype == torch.float32 else x.float()
+            x = (x if x.dtype == torch.float32 else x.float()).contiguous()
+            sources.append(x)
+            return x
 
-        def rounded_on_device(t, keep_f32):
-            x = up32(t)
-            if hd == torch.float32 or x.numel() == 0:
+        def job(op, srcs, dsts, n, K=0):
+            nonlocal stage_bytes
+            j = _lib.CpxWeightJob()
+            j.op, j.dtype, j.n, j.K = op, dtc, n, K
+            for k, x in enumerate(srcs):
+                j.src_host[k] = x.data_ptr()
+                if op != _lib.WJ_COPY_F32:
+                    j.stage_off[k] = stage_bytes
+                    stage_bytes += (x.numel() * 4 + 255) // 256 * 256
+            for k, d in enumerate(dsts):
+                j.dst[k] = d.data_ptr()
+            jobs.append(j)
+            self.keep += dsts
+
+        def on_device(t, keep_f32, exact=False):
+            x = host32(t)
+            if not on_gpu:
                 self.keep.append(x)
-                return x if (keep_f32 or hd == torch.float32) else x.to(hd)
-            out = torch.empty(x.shape, dtype=torch.float32 if keep_f32 else hd, device=dev)
-            check(L.cpx_round_weights(x.data_ptr(), out.data_ptr(), x.numel(), dtc, int(keep_f32), sptr()), "round_weights")
-            self.keep.append(out)
-            return out
+                return x.data_ptr()
+            as_is = exact or hd == torch.float32
+            out = torch.empty(x.shape, dtype=torch.float32 if (keep_f32 or as_is) else hd, device=dev)
+            if x.numel():
+                job(_lib.WJ_COPY_F32 if as_is else _lib.WJ_ROUND_F32 if keep_f32 else _lib.WJ_ROUND_HALF, [x], [out], x.numel())
+            else:
+                self.keep.append(out)
+            return out.data_ptr()
 
         def half(t):        # GEMM operand: stays in the half dtype
-            return rounded_on_device(t, False).data_ptr()
+            return on_device(t, False)
 
         def vec(t):         # epilogue vector: rounded through the half dtype, kept as f32
-            return rounded_on_device(t, True).data_ptr()
+            return on_device(t, True)
 
         c = self.c
         c.depth, c.ncls = depth, ncls
@@ -184,16 +202,11 @@ class NetWeights:
             wf = torch.empty((N, K), dtype=hd, device=dev)
             bf = torch.empty(N, dtype=torch.float32, device=dev)
             cs = torch.empty(N, dtype=torch.float32, device=dev)
-            src = [up32(t) for t in (w, b, gamma, beta)]       # (held until the launch is queued: a freed block is re-used in stream order)
-            check(L.cpx_fold_layernorm(*[t.data_ptr() for t in src], N, K, dtc,
-                                       wf.data_ptr(), bf.data_ptr(), cs.data_ptr(), sptr()), "fold_layernorm")
-            self.keep += [wf, bf, cs]
+            job(_lib.WJ_FOLD_LN, [host32(t) for t in (w, b, gamma, beta)], [wf, bf, cs], N, K)
             return wf.data_ptr(), bf.data_ptr(), cs.data_ptr()
 
         def vec32(t):       # already float32, no re-rounding
-            x = t.detach().float().contiguous().to(dev)
-            self.keep.append(x)
-            return x.data_ptr()
+            return on_device(t, True, exact=True)
         c.pe_w = half(sd["encoder.patch_embed.proj.weight"].reshape(1024, 192))
         c.pe_b = vec(sd["encoder.patch_embed.proj.bias"])
         c.pos = vec(sd["encoder.pos_embed"].reshape(1024, 1024))
@@ -246,8 +259,14 @@ class NetWeights:
             self._build_unet_ops(sd, fts, ncls * 64, half, vec32)
         self.ncls, self.depth, self.precision, self.device = ncls, depth, precision, dev
         self.fts = fts
-        if dev.type == "cuda":
-            torch.cuda.current_stream(dev).synchronize()  # the operands are final before any other stream may read them
+        if jobs:
+            stage = torch.empty(stage_bytes, dtype=torch.uint8, device=dev)
+            arr = (_lib.CpxWeightJob * len(jobs))(*jobs)
+            st = torch.cuda.current_stream(dev)
+            check(L.cpx_weights_build(arr, len(jobs), stage.data_ptr(), stage_bytes, st.cuda_stream), "weights_build")
+            st.synchronize()                              # the operands are final before any other stream may read them; sources + staging may go
+            del stage
+        sources.clear()
         return self
 
     def _build_unet_ops(self, sd, fts, out_ch, half, vec32):

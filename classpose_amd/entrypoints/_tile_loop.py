@@ -316,14 +316,19 @@ def run_rank(args, rank: int, world: int, device: torch.device):
         if provider is not None:                                 # plug-in supplied dynamics inputs (classpose_amd/hooks.py)
             def extra(ti, R=R, W=W, H=H):
                 return provider(ti, R, W, H)[:3]                 # (dP, cellprob, logits)
-        stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra)      # the readers start decoding now
+        # The readers start decoding now -- unless the checkpoint is still on its way to the device AND this rank has few cores to itself:
+        # the upload's host side is one thread copying 1.2 GB of mapped pages into the runtime's staging buffers, and with eight ranks on a
+        # 16-core quota the readers' threads starved it (0.3 s of work took 1.6 - 3.0 s; nothing can run before the weights are there anyway)
+        weights_first = weights is None and not weights_fut.done() and hostinfo.usable_cpus() // max(world, 1) < 8
+        stream = TileStream(slide, plan, idxs, nT, R, R, device, extra=extra, autostart=not weights_first)
         waited = 0.0
         if weights is None:
             t_w = time.time()
             weights, t_conv = weights_fut.result()
             waited = stage["wait for weights"] = time.time() - t_w
             logger.info(f"[rank {rank}] weights converted + uploaded in {t_conv:.2f} s on a background thread "
-                        f"(this thread waited {waited:.2f} s for them)")
+                        f"(this thread waited {waited:.2f} s for them{'; the readers start now' if weights_first else ''})")
+        stream.start()
         eng = engine.Engine(weights, H, W, batch_tiles=nT, augment=args.tta)
         stage["engine + stream setup"] += time.time() - t_s - waited
 

@@ -203,6 +203,27 @@ typedef struct cpx_net_weights {
 int cpx_round_weights(const float *src, void *dst, long long n, int dtype, int keep_f32, void *stream);
 int cpx_fold_layernorm(const float *w, const float *b, const float *gamma, const float *beta, int N, int K, int dtype,
                        void *w_folded, float *b_folded, float *colsum, void *stream);
+/* The whole checkpoint in one call: job i streams its float32 HOST source(s) into the device staging area (stage_base + stage_off[k],
+ * 16-byte aligned offsets, disjoint per job) with hipMemcpyAsync on `stream` and queues the kernel above behind the copy.
+ *   CPX_WJ_ROUND_HALF / CPX_WJ_ROUND_F32  src_host[0] [n] -> dst[0] (cpx_round_weights, keep_f32 = 0 / 1)
+ *   CPX_WJ_COPY_F32                       src_host[0] [n] -> dst[0] float32 as stored (no staging)
+ *   CPX_WJ_FOLD_LN                        src_host = {w [n][K], b [n], gamma [K], beta [K]} -> dst = {w_folded, b_folded, colsum}
+ * The sources may be pageable (the pages of a memory-mapped checkpoint); they must stay valid until the stream has run.       */
+#define CPX_WJ_ROUND_HALF 0
+#define CPX_WJ_ROUND_F32 1
+#define CPX_WJ_COPY_F32 2
+#define CPX_WJ_FOLD_LN 3
+typedef struct cpx_weight_job {
+    int op;                     /* CPX_WJ_*                                             */
+    int dtype;                  /* CPX_DT_BF16 / CPX_DT_F16 (CPX_WJ_COPY_F32: ignored)  */
+    long long n;                /* elements; CPX_WJ_FOLD_LN: rows N                     */
+    int K;                      /* CPX_WJ_FOLD_LN: columns                              */
+    int reserved;
+    const void *src_host[4];
+    size_t stage_off[4];
+    void *dst[3];
+} cpx_weight_job;
+int cpx_weights_build(const cpx_weight_job *jobs_host, int n_jobs, void *stage_base, size_t stage_bytes, void *stream);
 
 size_t cpx_net_workspace_bytes(int n_subtiles, int dtype);
 /* extra bytes (appended to the network workspace) when w->n_unet_ops > 0 */

@@ -5,7 +5,7 @@
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/r06; mkdir -p $O
-export CLASSPOSE_MODEL_DIR=/tmp/cpx_models CLASSPOSE_SYNTHETIC_WEIGHTS=1
+export CLASSPOSE_MODEL_DIR=/tmp/cpx_models CLASSPOSE_SYNTHETIC_WEIGHTS=1 LOG_LEVEL_NON_MAIN=INFO   # (every rank logs its stage table)
 [ -f /tmp/cpx_models/conic.pt ] || python $R/tools/make_synthetic_checkpoint.py conic > /dev/null
 for MODE in ${MODES:-plain plugin}; do
   if [ $MODE = plugin ]; then export CLASSPOSE_AMD_PLUGINS=classpose_amd.synth:flow; fi
