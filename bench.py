@@ -526,6 +526,15 @@ def main():
             "note": "--precision fp32 (what the reference's integration tests pass): exact-f32 MFMA network "
                     "(v_mfma_f32_32x32x2_f32, 1/16 of the bf16 matrix rate), same pipeline, flow injection"}
         del eng32, w32
+        torch.cuda.empty_cache()
+        # the reference's DEFAULT geometry (1024-px tiles, overlap 64: predict_wsi.py:92; configs[2] with puma's 10 classes) and configs[4]'s
+        # 512-px fp16 tiles, host out of the way exactly as for the headline (round-5 review item 4)
+        for key, a in (("configs2_geometry_1024px_puma_bf16", ("configs[2] geometry: 1024-px tiles / overlap 64, puma 10 classes", 10, 1024, 64, "bf16")),
+                       ("configs4_geometry_512px_fp16", ("configs[4] geometry: 512-px tiles / overlap 32, conic 7 classes, fp16", 7, 512, 32, "fp16"))):
+            try:
+                side[key] = geometry_side_line(L, dev, args.depth, *a)
+            except Exception as e:                                      # noqa: BLE001 -- a side line never takes the headline down
+                side[key] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     line = {
         "metric": "wsi_tiles_per_sec",
@@ -595,6 +604,109 @@ def main():
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def geometry_side_line(L, dev, depth, name, ncls, T, overlap, precision, n_steps=6, n_warm=2):
+    """The headline's pipeline (rendered tiles in host memory -> TileStream -> 2-stream engine with flow injection -> records read back per
+    step) on ANOTHER geometry of BASELINE.json: the reference's default 1024-px tile / overlap 64 (predict_wsi.py:92,1455-1458; configs[2],
+    puma's 10 classes) and the 512-px fp16 tiles of configs[4].  Tiles per launch by the CLI's rule (_tile_loop.run_rank).  Reports
+    sub-tiles/s (what to hold against configs[1]'s), tiles/s, cells/s and the post-processing chain alone at that tile size."""
+    import math
+    sd = synth.make_state_dict(ncls, None, depth=depth, seed=0)
+    w = engine.NetWeights.from_state_dict(sd, precision, dev)
+    del sd
+    n_sub = engine.make_tiling(T, T, 256, False).ny ** 2
+    nT = max(1, 96 // n_sub)
+    step = 8 // math.gcd(n_sub, 8)
+    nT = -(-nT // step) * step
+    eng = engine.Engine(w, T, batch_tiles=nT)
+    n_b = n_steps + n_warm
+    per_row = math.isqrt(n_b * nT - 1) + 1
+    S = (T - overlap) * per_row + overlap
+    slide = synth.SyntheticSlide(S, S, mpp=0.5, seed=SEED)
+    plan = wsi.plan_slide(slide, T, overlap, 0.5)
+    use = list(range(n_b * nT))
+    assert len(plan.coords) >= len(use) and all(plan.coords[i][1] == T for i in use)
+    with ThreadPoolExecutor(max_workers=max(2, min(32, hostinfo.usable_cpus()))) as pool:
+        rendered = list(pool.map(lambda ti: np.concatenate(
+            [synth.render_region(SEED, plan.coords[ti][0][0], plan.coords[ti][0][1], T, T), np.full((T, T, 1), 255, np.uint8)], -1), use))
+        fields_h = list(pool.map(lambda ti: synth.analytic_fields(SEED, plan.coords[ti][0][0], plan.coords[ti][0][1], T, T, ncls)[:3], use))
+    cached = CachedSlide(slide, {tuple(plan.coords[ti][0]): r for ti, r in zip(use, rendered)})
+    fields = [tuple(torch.from_numpy(np.stack([a[k] for a in fields_h[b * nT:(b + 1) * nT]])).to(dev) for k in range(3)) for b in range(n_b)]
+    del fields_h, rendered
+    rec_bytes = C.sizeof(_lib.CpxRecord)
+    cells_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    host_cnt = torch.empty(nT, dtype=torch.int32).pin_memory()
+
+    def collect(sid):
+        out = eng.result(sid)
+        host_cnt.copy_(out.rec_counts, non_blocking=True)
+        cells_acc.add_(out.nlabels.sum())
+        torch.cuda.current_stream(dev).synchronize()            # as the CLI's loop: a batch's counts are read back before the next is taken
+        if int(host_cnt.max()) >= eng.max_rec:
+            raise RuntimeError("side line: record table overflow")
+
+    with TileStream(cached, plan, use, nT, T, T, dev, autostart=False, gate_at=n_warm) as ts:
+        ts.start()
+        it = iter(ts)
+        prev = None
+
+        def run(n, b0):
+            nonlocal prev
+            for i in range(n):
+                chunk, tiles_dev, ev, _x = next(it)
+                torch.cuda.current_stream(dev).wait_event(ev)
+                sid = eng.submit(tiles_dev, inject=fields[b0 + i], records=True)
+                if prev is not None:
+                    collect(prev)
+                prev = sid
+        run(n_warm, 0)
+        collect(prev); prev = None
+        ts.parked.wait(timeout=120.0)
+        torch.cuda.synchronize(dev)
+        cells_acc.zero_()
+        t0 = time.perf_counter()
+        ts.release()
+        run(n_steps, n_warm)
+        collect(prev)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    cells = float(cells_acc.item())
+    post = post_chain_ms(L, eng, fields[n_warm], nT, ncls, T, dev)
+    flop_sub = 727.3e9
+    out = {"geometry": name, "precision": precision, "tile": T, "overlap": overlap, "classes": ncls, "subtiles_per_tile": n_sub, "tiles_per_step": nT,
+           "steps": n_steps, "ms_per_step": round(dt / n_steps * 1e3, 2), "tiles_per_s": round(n_steps * nT / dt, 2),
+           "subtiles_per_s": round(n_steps * nT * n_sub / dt, 1), "cells_per_s": round(cells / dt, 1), "cells_per_tile": round(cells / (n_steps * nT), 1),
+           "network_tflops": round(n_steps * nT * n_sub * flop_sub / dt / 1e12, 1),
+           "post_processing_ms_per_batch_alone": post["ms"], "post_processing_launches": post["launches"],
+           "post_processing_share_of_step_if_serial": round(post["ms"] / (dt / n_steps * 1e3), 4),
+           "note": "same pipeline as the headline (pre-rendered tiles in host memory -> TileStream -> engine, flow injection, records read back every step); "
+                   "the post-processing chain runs on its own stream beside the next batch's network: ms_per_step > network alone only if it does not fit"}
+    del eng, w, fields
+    torch.cuda.empty_cache()
+    return out
+
+
+def post_chain_ms(L, eng, fields0, bt, ncls, T, dev, reps=8):
+    """median device time (HIP events, back to back) of the fused post-processing chain alone on one batch of an arbitrary geometry"""
+    sl = eng.slots[0]
+    dP, cp, lg = fields0
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def once():
+        _lib.check(L.cpx_compute_masks_records(dP.data_ptr(), cp.data_ptr(), lg.data_ptr(), bt, ncls, T, T, 0.0, 0.4, 200, 15, 0.4,
+                                               sl.masks.data_ptr(), sl.class_masks.data_ptr(), sl.nlabels.data_ptr(), eng.max_rec,
+                                               sl.records.data_ptr(), sl.rec_counts.data_ptr(), sl.pp_ws.data_ptr(), st), "compute_masks_records")
+    n0 = L.cpx_postproc_launch_count()
+    once()
+    launches = int(L.cpx_postproc_launch_count() - n0)
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record(); once(); e1.record()
+    torch.cuda.synchronize(dev)
+    v = sorted(a.elapsed_time(b) for a, b in ev)
+    return {"ms": round(v[reps // 2], 4), "launches": launches}
 
 
 def post_stage(L, eng, fields0, bt, dev, reps=20):

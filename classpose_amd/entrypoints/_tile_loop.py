@@ -83,8 +83,9 @@ class TileStream:
         self.copy_stream = torch.cuda.Stream(device)
         self.readers = ThreadPoolExecutor(max_workers=n_workers)
         self.t = threading.Thread(target=self._run, daemon=True)
+        self._started = False
         if autostart:
-            self.t.start()
+            self.start()
 
     def release(self):
         self.gate.set()
@@ -108,7 +109,8 @@ class TileStream:
 
     def start(self):
         """begin reading / copying (``autostart=False``: buffers and threads exist, nothing has been read yet)"""
-        if not self.t.is_alive():
+        if not self._started:
+            self._started = True
             self.t.start()
 
     def _submit(self, b):
