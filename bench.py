@@ -444,7 +444,7 @@ def main():
             traffic, traffic_src = traffic_detail["traffic"], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over tools/pmc_fc1.py"
     if traffic is None:
         traffic_detail = {"fallback_reason": fallback_reason}
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["traffic_bytes_per_launch"]
@@ -481,8 +481,12 @@ def main():
             raise RuntimeError("bench.py stage pass: the launch profile filled its capacity (%d): samples were dropped" % cap)
         n_l = n_l.value
         per_kind = {k: [] for k in range(len(_lib.PROF_KINDS))}
+        per_fwd = args.depth * (3 + 2 * stage_parts) + 2
+        where_max = {}                                        # kind -> (ms, step of the pass incl. its two warm-up steps, launch index inside the forward)
         for i in range(n_l):
             per_kind[kind_l[i]].append(float(ms_l[i]))
+            if float(ms_l[i]) > where_max.get(kind_l[i], (0.0,))[0]:
+                where_max[kind_l[i]] = (float(ms_l[i]), i // per_fwd, i % per_fwd)
         kernel_time_sum = 0.0
         med_of = lambda v: sorted(v)[len(v) // 2] if v else None
         # what the network stream runs besides the five per-layer kernels, and the post stream's blend: per step, median over the pass
@@ -501,7 +505,10 @@ def main():
             stages[name] = {"bound": "mfma", "launch_ms": {"min": round(v[0], 4), "median": round(med, 4), "max": round(v[-1], 4)},
                             "avg_launch_ms": round(sum(v) / len(v), 4), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_timed": len(v),
-                            "outlier": bool(v[-1] > 3.0 * med)}
+                            "outlier": bool(v[-1] > 3.0 * med),
+                            # where the longest launch sat: step of the stage pass (0 = the first step behind its two warm-up steps) and launch
+                            # index inside that forward
+                            "max_at": {"step_of_pass": where_max[k][1], "launch_in_forward": where_max[k][2], "launches_per_forward": per_fwd}}
         stages["post_processing"] = post_stage(L, eng, fields[0], bt, dev)
 
     # ---- side lines (N = 1): --precision fp32, and the network's own fields instead of the injected ones
@@ -752,7 +759,7 @@ def post_stage(L, eng, fields0, bt, dev, reps=20):
     ms = sorted(dev_b2b)[reps // 2]
     gbs = POST_BYTES_PER_TILE * bt / (ms * 1e-3) / 1e9
     prof_sum = None
-    for name in ("r05_post_kernel_sum.json", "r04_post_kernel_sum.json", "r03_post_kernel_sum.json"):    # rocprofv3 kernel-time sum of the same chain (tools/r04_profile.sh)
+    for name in ("r06_post_kernel_sum.json", "r05_post_kernel_sum.json", "r04_post_kernel_sum.json", "r03_post_kernel_sum.json"):    # rocprofv3 kernel-time sum of the same chain (tools/r04_profile.sh)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 prof_sum = json.load(f)

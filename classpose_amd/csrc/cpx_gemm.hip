@@ -37,9 +37,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // cpx_gemm_set_nt=0,1, launch medians): qkv 181.2 -> 177.5 us, attn.proj 72.6 -> 70.4, attention 181.9 -> 183.6 (its K / V^T tiles now
 // come from HBM): -4 us per layer, engine step 21.34 -> 21.24 ms, same bits.  (The same hint on the attention kernel's K / V^T REQUESTS
 // loses the L2 sharing of the eight query blocks of a head: 184 -> 199 us, profiles/r05_ab_nontemporal.txt.)
-template <bool NT_POSSIBLE>
-__device__ __forceinline__ void st16(void *p, uint4 v, bool nt) {
-    if (NT_POSSIBLE && nt) {
+// (round 6) WT: the store at agent scope (sc1): the line is written through to the memory side at once instead of staying dirty in this XCD's
+// 4 MB L2 until something evicts it -- the epilogues of all 256 workgroups burst at the same moment (32 x 128 KB per XCD = the whole L2)
+template <bool NT_POSSIBLE, bool WT_POSSIBLE = false>
+__device__ __forceinline__ void st16(void *p, uint4 v, bool nt, bool wt = false) {
+    if (WT_POSSIBLE && wt) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t w = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+    } else if (NT_POSSIBLE && nt) {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t w = {v.x, v.y, v.z, v.w};
         __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
@@ -1334,7 +1340,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                         }
                         vv = make_uint4(a[0], a[1], a[2], a[3]);
                     }
-                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16>((unsigned short *)g.out + go, vv, (g.nt_out & (n0 < 1024 ? 1 : 2)) != 0);
+                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16, EPI == CPX_EPI_RESID_BF16>((unsigned short *)g.out + go, vv, (g.nt_out & (n0 < 1024 ? 1 : 2)) != 0, (g.nt_out & 8) != 0);
                     if constexpr (STATS) {
                         unsigned a[4] = {vv.x, vv.y, vv.z, vv.w};
                         float sm = 0.f, sq = 0.f;
@@ -1662,7 +1668,7 @@ CPX_SWITCH(g_gemm_bal, 1);          // 1 = balanced fragment-read schedule of th
 CPX_SWITCH(g_gemm_split, 0);        // 1 = counted LDS waits inside the main-loop phases (k_gemm256p<.., G2F_SPLIT>; experiment)
 CPX_SWITCH(g_gemm_direct, 1);       // 1 = direct-store epilogue (G2F_DIRECT) for the GELU epilogue, 2 (debug build) = for every non-residual epilogue, 0 = staged rows
 CPX_SWITCH(g_gemm_epi4, 0);         // 1 = quarter-tile epilogue of the persistent 256^2 kernel (conversion beside the previous quarter's stores)
-CPX_SWITCH(g_gemm_nt, 7);           // bits 0 / 1 / 2: the q / k / V^T thirds of the qkv projection's output leave by non-temporal stores (7 = production), 0 = ordinary stores (A/B)
+CPX_SWITCH(g_gemm_nt, 15);          // bits 0 / 1 / 2: the q / k / V^T thirds of the qkv projection's output leave by non-temporal stores; bit 3 (round 6): the residual epilogues (attn.proj, mlp.lin2) store at agent scope (sc1, written through: proj 73.9 -> 72.4 us, lin2 105.2 -> 103.2 in situ); 15 = production, 0 = ordinary stores (A/B)
 CPX_SWITCH(g_gemm_4w, 1);           // bit 0 (production): mlp.lin1 (bf16, folded LayerNorm + GELU) on the one-wave-per-SIMD kernel (cpx_gemm4w.hip), 0.98 of k_gemm256p;
                                     // bit 1 (debug build, measured and NOT shipped): attn.proj / mlp.lin2 (residual + row statistics) on it as well -- 1.06 / 1.03 of
                                     // k_gemm256p (profiles/r05_ab_gemm4w_resid.txt): that epilogue is unpacked integer / f32 vector work, which a lone wave issues at

@@ -399,6 +399,9 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
                     *reinterpret_cast<float2 *>(g.stats_out + ((size_t)(m0 + row) * 4 + (n0 >> 8)) * 2) = tot;
                 }
             }
+        } else if constexpr ((VAR & 2048) != 0) {
+            // (timing-only ablation, debug build: NO epilogue at all -- the accumulators are neither read nor stored.  full - this = what the
+            // epilogue costs a launch with the matrix pipe idle, i.e. the most that running it under the next tile's main loop could buy)
         } else
         // ---- epilogue: [folded LayerNorm +] bias [+ GELU], one conversion per pair, lane rows swapped into 16-byte pieces, buffer stores (the
         // direct-store epilogue of k_gemm256p).  Every LDS read of the tail is inline asm: an ordinary one makes hipcc drain the request queue
@@ -472,7 +475,11 @@ __global__ void __launch_bounds__(G4_THREADS) __attribute__((amdgpu_waves_per_eu
                         const auto r0 = __builtin_amdgcn_permlane16_swap(a0, e0, false, false);
                         const auto r1 = __builtin_amdgcn_permlane16_swap(a1, e1, false, false);
                         const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, (VAR & 512) ? 2 : 0);   // (VAR & 512, debug build: non-temporal)
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, ovoff, so0 + (unsigned)(mb * 16) * ldb + (unsigned)np * 64u, (VAR & 512) ? 2 : (VAR & 4096) ? 0 : (VAR & 8192) ? 17 : 16);
+                        // aux 16 = sc1, the store at AGENT scope (production since round 6): written through to the memory side at once instead of staying
+                        // dirty in the XCD's L2 until evicted -- the 256 workgroups' epilogues burst at the same moment, 32 x 128 KB per XCD = its whole 4 MB
+                        // L2, operand panels included.  mlp.lin1 126.8 -> 124.3 us in situ, same bits (profiles/r06_ab_store_scope.txt).  Debug build:
+                        // VAR & 4096 = ordinary stores (the round-5 form), & 8192 = system scope (no different), & 512 = non-temporal (slower: mlp.lin2 wants the rows in the Infinity Cache)
                         G4_SB();                                                 // (keeps the scheduler from hoisting all 256 accumulator reads: the next tile's two fragment sets are live here)
                     }
             }
@@ -542,6 +549,10 @@ int cpx_gemm4w_gelu_ln(int f16, const void *A, const void *W, int M, int N, int 
     a.M = M; a.N = N; a.K = K; a.ld_out = ld_out; a.tiles_n = N / 256; a.n_blocks = (M / 256) * (N / 256);
 #ifdef CPX_DEBUG
     if (!f16 && g_gemm4w_var == 512) { g4_launch<G4_EPI_GELU_LN, 512, false>(a, s); return 1; }     // experiment: non-temporal output stores
+    if (!f16 && g_gemm4w_var == 4096) { g4_launch<G4_EPI_GELU_LN, 4096, false>(a, s); return 1; }   // A/B: ordinary output stores (the round-5 form; production stores at agent scope)
+    if (!f16 && g_gemm4w_var == 8192) { g4_launch<G4_EPI_GELU_LN, 8192, false>(a, s); return 1; }   // experiment: ... at system scope
+    if (!f16 && g_gemm4w_var == 2048) { g4_launch<G4_EPI_GELU_LN, 2048, false>(a, s); return 1; }   // timing only: no epilogue
+    if (!f16 && g_gemm4w_var == 2049) { g4_launch<G4_EPI_BIAS, 0, false>(a, s); return 1; }          // timing only: the bias-only epilogue (no LayerNorm fold, no GELU)
 #endif
     if (f16) g4_launch<G4_EPI_GELU_LN, 0, true>(a, s);
     else g4_launch<G4_EPI_GELU_LN, 0, false>(a, s);

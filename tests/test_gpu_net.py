@@ -632,9 +632,10 @@ def test_benched_path_depth24_32_subtiles_vs_oracle(cuda, precision):
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_net_forward_is_bitwise_independent_of_the_round5_switches(cuda, precision):
     """Round 5 changed HOW a forward runs, not what it computes: mlp.lin1 on the one-wave-per-SIMD kernel (bf16 and fp16 instantiations) and the
-    MLP in row parts of 16 384 tokens, the qkv projection's outputs by non-temporal stores.  The whole head tensor of a 32-sub-tile, 3-block
-    forward is bit for bit the same with all switched off (cpx_gemm_set_4w(0), cpx_net_set_mlp_parts(0), cpx_gemm_set_nt(0): the round-4
-    path), in mixed settings, and all on (production)."""
+    MLP in row parts of 16 384 tokens, the qkv projection's outputs by non-temporal stores; round 6 added the agent-scope (written-through) stores of
+    the residual epilogues (cpx_gemm_set_nt bit 3) and of mlp.lin1's (cpx_gemm4w_set_variant(4096) = the ordinary stores of round 5).  The whole head
+    tensor of a 32-sub-tile, 3-block forward is bit for bit the same with all switched off (cpx_gemm_set_4w(0), cpx_net_set_mlp_parts(0),
+    cpx_gemm_set_nt(0), cpx_gemm4w_set_variant(4096): the round-4 path), in mixed settings, and all on (production)."""
     import ctypes as C
     nS, depth = 32, 3
     sd = synth.make_state_dict(7, None, depth=depth, seed=5)
@@ -655,11 +656,11 @@ def test_net_forward_is_bitwise_independent_of_the_round5_switches(cuda, precisi
     assert _lib.lib().cpx_net_mlp_parts(nS, w_dtype := _lib.DTYPE_CODE[precision]) == 2 and _lib.lib().cpx_net_mlp_parts(16, w_dtype) == 1
     with _lib.use_debug_library() as L:
         try:
-            for g4, parts, nt in ((0, 0, 0), (1, 0, 1), (0, 1, 6), (1, 1, 0), (1, 1, 7)):
-                L.cpx_gemm_set_4w(g4); L.cpx_net_set_mlp_parts(parts); L.cpx_gemm_set_nt(nt)
-                assert torch.equal(forward(L), prod), (g4, parts, nt)
+            for g4, parts, nt, v4 in ((0, 0, 0, 4096), (1, 0, 1, 4096), (0, 1, 6, 0), (1, 1, 8, 4096), (1, 1, 7, 0), (1, 1, 15, 8192), (1, 1, 15, 0)):
+                L.cpx_gemm_set_4w(g4); L.cpx_net_set_mlp_parts(parts); L.cpx_gemm_set_nt(nt); L.cpx_gemm4w_set_variant(v4)
+                assert torch.equal(forward(L), prod), (g4, parts, nt, v4)
         finally:
-            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1); L.cpx_gemm_set_nt(7)
+            L.cpx_gemm_set_4w(1); L.cpx_net_set_mlp_parts(1); L.cpx_gemm_set_nt(15); L.cpx_gemm4w_set_variant(0)
 
 
 def test_engine_fp16_512px_vs_oracle(cuda):
@@ -921,3 +922,29 @@ def test_net_weights_converted_on_the_device_equal_the_host_conversion(cuda):
             assert torch.equal(get(w.blocks[1].fc1_w), (wq * gq[None, :]).to(hd))
         else:
             assert torch.equal(get(w.blocks[1].fc1_w), sd["encoder.blocks.1.mlp.lin1.weight"])
+
+
+def test_engine_inject_without_class_logits(cuda):
+    """A model without a class head (--model_path cpsam: ncls <= 1) takes inject = (dP, cellprob, None) -- the chain never reads the logits pointer --,
+    ids equal the oracle's; the same None on a model WITH a class head is a ValueError, not an AttributeError (round-5 advisor)."""
+    from oracle import dynamics
+    f = [synth.analytic_fields(5, 224 * i, 0, 256, 256, 7) for i in range(2)]
+    dP = torch.from_numpy(np.stack([a[0] for a in f])).to(cuda)
+    cp = torch.from_numpy(np.stack([a[1] for a in f])).to(cuda)
+    lg = torch.from_numpy(np.stack([a[2] for a in f])).to(cuda)
+    tiles = torch.from_numpy(np.stack([synth.render_region(5, 224 * i, 0, 256, 256) for i in range(2)])).to(cuda)
+    w1 = engine.NetWeights.from_state_dict(synth.make_state_dict(1, None, depth=1, seed=3), "bf16", cuda)
+    assert w1.ncls <= 1
+    eng1 = engine.Engine(w1, 256, batch_tiles=2)
+    out = eng1.run(tiles, inject=(dP, cp, None))
+    m = ops.masks_to_numpy(out.masks)
+    for i in range(2):
+        assert np.array_equal(m[i], dynamics.compute_masks(f[i][0], f[i][1], flow_threshold=0.4).astype(np.uint16)), i
+    assert int(out.class_masks.max()) == 0
+    w7 = engine.NetWeights.from_state_dict(synth.make_state_dict(7, None, depth=1, seed=3), "bf16", cuda)
+    eng7 = engine.Engine(w7, 256, batch_tiles=2)
+    with pytest.raises(ValueError, match="logits may be None only without a class head"):
+        eng7.submit(tiles, inject=(dP, cp, None))
+    with pytest.raises(ValueError):
+        eng7.submit(tiles, inject=(None, cp, lg))
+    eng7.run(tiles, inject=(dP, cp, lg))
