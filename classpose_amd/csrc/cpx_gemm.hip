@@ -44,7 +44,8 @@ __device__ __forceinline__ void st16(void *p, uint4 v, bool nt, bool wt = false)
     if (WT_POSSIBLE && wt) {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t w = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+        if (NT_POSSIBLE && nt) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(w) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
     } else if (NT_POSSIBLE && nt) {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t w = {v.x, v.y, v.z, v.w};
@@ -1117,7 +1118,7 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                 const int row = it * 16 + (tid >> 5);
                 const int c = n0 - 2048 + row;
                 uint4 vv = *reinterpret_cast<const uint4 *>(smem + row * G2_EPI_LD + c16 * 16);
-                st16<EPI == CPX_EPI_QKV_BF16>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8, vv, (g.nt_out & 4) != 0);
+                st16<EPI == CPX_EPI_QKV_BF16, EPI == CPX_EPI_QKV_BF16>(vT + ((s_ * 16 + (c >> 6)) * 64 + (c & 63)) * 1024 + t0 + c16 * 8, vv, (g.nt_out & 4) != 0, (g.nt_out & 16) != 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G2_BAR();
@@ -1340,7 +1341,8 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_gemm256p(GemmArgs g) {
                         }
                         vv = make_uint4(a[0], a[1], a[2], a[3]);
                     }
-                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16, EPI == CPX_EPI_RESID_BF16>((unsigned short *)g.out + go, vv, (g.nt_out & (n0 < 1024 ? 1 : 2)) != 0, (g.nt_out & 8) != 0);
+                    if (!DBG || !(g.dbg & 1) || vv.x == 0x12345678u) st16<EPI == CPX_EPI_QKV_BF16, EPI == CPX_EPI_RESID_BF16 || EPI == CPX_EPI_QKV_BF16>((unsigned short *)g.out + go, vv, (g.nt_out & (n0 < 1024 ? 1 : 2)) != 0,
+                                                                                        (g.nt_out & (EPI == CPX_EPI_QKV_BF16 ? 16 : 8)) != 0);
                     if constexpr (STATS) {
                         unsigned a[4] = {vv.x, vv.y, vv.z, vv.w};
                         float sm = 0.f, sq = 0.f;

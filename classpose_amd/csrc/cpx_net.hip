@@ -1253,16 +1253,24 @@ extern "C" void cpx_prof_destroy(void *prof) {
     delete[] p->ev; delete[] p->kind; delete p;
 }
 
-// number of row parts the MLP of a layer runs in (mlp.lin1 -> mlp.lin2 per part): parts of 16 sub-tiles = 16 384 token rows when the batch is a
-// larger multiple of that (the hidden activations of a part, 134 MB at 2 bytes, then stay in the Infinity Cache between the two GEMMs), else 1.
-// bench.py prices an mlp.lin1 / mlp.lin2 launch with n_subtiles / parts * 1024 rows.
+// number of row parts the MLP of a layer runs in (mlp.lin1 -> mlp.lin2 per part): floor(n_subtiles / 16) parts of 16 384 token rows (the last one with the
+// remainder) when the batch has >= 32 sub-tiles (the hidden activations of a part, 134 MB at 2 bytes, then stay in the Infinity Cache between the two GEMMs), else 1.
+// bench.py prices an mlp.lin1 / mlp.lin2 launch with n_subtiles / parts * 1024 rows (exact when 16 divides the batch, as in its headline).
 CPX_SWITCH(g_mlp_parts, 1);        // 1 = the MLP in row parts (production), 0 = one launch pair over all rows (A/B)
 #ifdef CPX_DEBUG
 extern "C" void cpx_net_set_mlp_parts(int on) { g_mlp_parts = on; }
 #endif
 extern "C" int cpx_net_mlp_parts(int n_subtiles, int dtype) {
-    if (!g_mlp_parts || dtype == CPX_DT_F32 || n_subtiles <= 16 || n_subtiles % 16) return 1;
+    if (!g_mlp_parts || dtype == CPX_DT_F32 || n_subtiles < 32) return 1;
     return n_subtiles / 16;
+}
+// rows of part pt (round 6: ANY batch of >= 32 sub-tiles is split, not only multiples of 16 -- the reference's default 1024-px tile makes 25 sub-tiles,
+// 8 tiles per launch = 200: until round 5 their 1.68 GB of hidden activations went out to HBM and back in every layer).  floor(n / 16) parts of exactly
+// 16 sub-tiles = 16 384 rows -- mlp.lin2 then has 256 output tiles, one per CU: parts of 18 432 rows (288 tiles) were measured first and cost two rounds of
+// workgroups for 1.125 rounds of work -- and the LAST part takes the remainder as well (16 .. 31 sub-tiles)
+static void mlp_part_rows(int n_subtiles, int parts, int pt, int &row0, int &rows) {
+    row0 = pt * 16384;
+    rows = pt + 1 < parts ? 16384 : n_subtiles * 1024 - row0;
 }
 
 extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, int nS, float *head,
@@ -1311,10 +1319,12 @@ extern "C" int cpx_net_forward(const cpx_net_weights *w, const void *patches, in
             // back by mlp.lin2 straight away, from the 256 MB Infinity Cache, and every part re-uses the SAME hidden rows -- over all 32 768 rows
             // the 268 MB hidden tensor goes out to HBM and comes back (one-process A/B, tools/ab_mlp_msplit.py: 451.8 -> 444.0 us per layer's
             // MLP; with a hidden buffer of its own per part 457.5).  Rows are independent: same bits.
-            const int parts = big_stats ? cpx_net_mlp_parts(nS, dt) : 1, Mp = M / parts;
+            const int parts = big_stats ? cpx_net_mlp_parts(nS, dt) : 1;
             for (int pt = 0; pt < parts; ++pt) {
-                char *xp = (char *)x + (size_t)pt * Mp * 1024 * 2;
-                float *stp = st + (size_t)pt * Mp * 8;
+                int r0, Mp;
+                mlp_part_rows(nS, parts, pt, r0, Mp);
+                char *xp = (char *)x + (size_t)r0 * 1024 * 2;
+                float *stp = st + (size_t)r0 * 8;
                 TIMED(CPX_PROF_FC1, i, cpx_gemm_half(dt, xp, b.fc1_w, Mp, 4096, 1024, CPX_EPI_GELU_BF16, b.fc1_b, nullptr, hb, 4096, stp, b.fc1_colsum, nullptr, stream));
                 TIMED(CPX_PROF_FC2, i, cpx_gemm_half(dt, hb, b.fc2_w, Mp, 1024, 4096, CPX_EPI_RESID_BF16, b.fc2_b, xp, xp, 1024, nullptr, nullptr, big_stats ? stp : nullptr, stream));
             }

@@ -233,8 +233,9 @@ int cpx_unet_head_forward(const cpx_conv_op *ops_host, int n_ops, const void *fe
                           size_t workspace_bytes, void *stream);
 /* patches [nS*1024][192] of w_host->dtype -> head [nS*1024][ld_head] float32
  * (the .float() of core._forward, core.py:67).                               */
-/* row parts the MLP of every layer is run in by cpx_net_forward (1, or n_subtiles / 16: parts of 16 384 token rows whose hidden activations stay in
- * the Infinity Cache between mlp.lin1 and mlp.lin2) -- what a profiled mlp.lin1 / mlp.lin2 launch covers is n_subtiles / parts sub-tiles        */
+/* row parts the MLP of every layer is run in by cpx_net_forward (1, or floor(n_subtiles / 16) for >= 32 sub-tiles: parts of 16 384 token rows, the last
+ * one with the remainder, whose hidden activations stay in the Infinity Cache between mlp.lin1 and mlp.lin2) -- what a profiled mlp.lin1 / mlp.lin2
+ * launch covers is n_subtiles / parts sub-tiles (exactly, when 16 divides n_subtiles)                                                           */
 int cpx_net_mlp_parts(int n_subtiles, int dtype);
 int cpx_net_forward(const cpx_net_weights *w_host, const void *patches, int n_subtiles,
                     float *head, void *workspace, size_t workspace_bytes, void *stream);

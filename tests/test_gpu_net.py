@@ -948,3 +948,32 @@ def test_engine_inject_without_class_logits(cuda):
     with pytest.raises(ValueError):
         eng7.submit(tiles, inject=(None, cp, lg))
     eng7.run(tiles, inject=(dP, cp, lg))
+
+
+def test_mlp_row_parts_of_uneven_size_are_bitwise_the_unsplit_forward(cuda):
+    """Round 6: any batch of >= 32 sub-tiles runs its MLP in floor(n / 16) row parts of 16 384 rows, the last one with the remainder (until round 5 only
+    multiples of 16 sub-tiles were split: the reference's default 1024-px tile -- 25 sub-tiles, 200 per launch -- sent 1.68 GB of hidden activations through
+    HBM per layer).  56 sub-tiles -> parts of 16 384 / 16 384 / 24 576 rows: head tensor bit for bit the one of the unsplit forward (cpx_net_set_mlp_parts(0))."""
+    import ctypes as C
+    nS, depth = 56, 2
+    sd = synth.make_state_dict(7, None, depth=depth, seed=9)
+    x = np.random.default_rng(2).random((nS, 3, 256, 256)).astype(np.float32)
+    patches = torch.from_numpy(x).reshape(nS, 3, 32, 8, 32, 8).permute(0, 2, 4, 1, 3, 5).reshape(nS * 1024, 192).to(torch.bfloat16).to(cuda)
+
+    def forward(L):
+        w = engine.NetWeights.from_state_dict(sd, "bf16", cuda)
+        head = torch.empty((nS * 1024, w.c.ld_head), dtype=torch.float32, device=cuda)
+        ws = torch.empty(L.cpx_net_workspace_bytes(nS, w.c.dtype), dtype=torch.uint8, device=cuda)
+        _lib.check(L.cpx_net_forward(C.byref(w.c), patches.data_ptr(), nS, head.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return head
+    L0 = _lib.lib()
+    assert [L0.cpx_net_mlp_parts(n, 0) for n in (16, 31, 32, 36, 56, 144, 200)] == [1, 1, 2, 2, 3, 9, 12] and L0.cpx_net_mlp_parts(200, 2) == 1
+    prod = forward(L0)
+    assert bool(torch.isfinite(prod).all())
+    with _lib.use_debug_library() as L:
+        try:
+            L.cpx_net_set_mlp_parts(0)
+            assert torch.equal(forward(L), prod)
+        finally:
+            L.cpx_net_set_mlp_parts(1)
