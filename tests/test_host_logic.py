@@ -362,3 +362,44 @@ def test_classpose_model_engine_pool_is_bounded(monkeypatch):
         with m._engine(512, 512, False, 0.1, {"niter": 200}):
             pass
     assert m.engines_alive() == 2                                     # the failed reservation was given back
+
+
+def test_predict_wsi_front_is_free_of_torch_and_forwards_the_tile_loop_names():
+    """Round 6: ``entrypoints/predict_wsi.py`` is the light front (flags, flag checks, the parent that spawns one worker per listed GPU,
+    predict_wsi.py:1542-1572 of the reference); importing it and building the parser must not import torch -- the parent of a multi-GPU
+    run used to pay 1 - 1.6 s for it before its children paid it again -- while every tile-loop name still resolves through it."""
+    import subprocess
+    code = ("import sys; from classpose_amd.entrypoints import predict_wsi as p; a = p.build_parser().parse_args(['--model_config', 'conic', "
+            "'--slide_path', 's', '--output_folder', 'o', '--device', 'cuda:0,1,2']); assert p._device_ids(a.device) == [0, 1, 2]; "
+            "assert p._device_ids('cuda') is None and p._device_ids(None) is None; assert 'torch' not in sys.modules, 'torch imported by the front'; "
+            "assert p.DEFAULT_TILE_SIZE == 1024 and p.get_geojson_output_filename('roi', 'x') == 'x_roi.geojson'; "
+            "t = p.TileStream; assert 'torch' in sys.modules and t.__module__.endswith('_tile_loop') and callable(p.run_rank) and p.CELL_ROW.itemsize == 48")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with pytest.raises(AttributeError):
+        from classpose_amd.entrypoints import predict_wsi
+        predict_wsi.no_such_name
+
+
+def test_spawned_workers_failure_stops_the_other_ranks_and_is_reported():
+    """``--device cuda:0,1`` outside a launcher: the parent spawns one process per listed GPU (plain multiprocessing, spawn context).  A rank that fails
+    -- here every rank, on the flag check, before anything touches a GPU -- ends the run with a RuntimeError naming the rank and its exit code."""
+    import argparse
+    from classpose_amd.entrypoints import predict_wsi
+    args = argparse.Namespace(model_config="conic", slide_path="s", output_folder="o", tissue_detection_model_path=None, output_type=None,
+                              tile_size=64, device="cuda:0,1")
+    good = argparse.Namespace(**{**vars(args), "tile_size": 256})
+    predict_wsi._check_unsupported(good)
+    with pytest.raises(ValueError, match="Tile size must be at least 256"):
+        predict_wsi.main(args)                                   # the parent checks the flags before it spawns anything
+    with pytest.raises(RuntimeError, match=r"classpose-rank\d \(pid \d+\) exited with code 1"):
+        predict_wsi._spawn_workers(args, [0, 1])
+
+
+def test_half_precision_weights_need_the_device():
+    """NetWeights rounds and folds the checkpoint with HIP kernels (csrc/cpx_weights.hip): a CPU device is accepted for float32 only (the host-side
+    packing test above); half precision fails loudly instead of converting on the host."""
+    from classpose_amd import _lib
+    sd = synth.make_state_dict(3, None, depth=1, seed=1)
+    with pytest.raises(_lib.CpxError, match="no CPU path"):
+        engine.NetWeights.from_state_dict(sd, "bf16", "cpu")
