@@ -260,12 +260,13 @@ class NetWeights:
         self.ncls, self.depth, self.precision, self.device = ncls, depth, precision, dev
         self.fts = fts
         if jobs:
-            stage = torch.empty(stage_bytes, dtype=torch.uint8, device=dev)
-            arr = (_lib.CpxWeightJob * len(jobs))(*jobs)
-            st = torch.cuda.current_stream(dev)
-            check(L.cpx_weights_build(arr, len(jobs), stage.data_ptr(), stage_bytes, st.cuda_stream), "weights_build")
-            st.synchronize()                              # the operands are final before any other stream may read them; sources + staging may go
-            del stage
+            with torch.cuda.device(dev):                  # (the kernels are launched on this thread's CURRENT device: it must be the one the stream belongs to)
+                stage = torch.empty(stage_bytes, dtype=torch.uint8, device=dev)
+                arr = (_lib.CpxWeightJob * len(jobs))(*jobs)
+                st = torch.cuda.current_stream(dev)
+                check(L.cpx_weights_build(arr, len(jobs), stage.data_ptr(), stage_bytes, st.cuda_stream), "weights_build")
+                st.synchronize()                          # the operands are final before any other stream may read them; sources + staging may go
+                del stage
         sources.clear()
         return self
 
