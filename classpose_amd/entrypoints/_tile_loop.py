@@ -626,6 +626,8 @@ def run_main(args, spawned: bool = False):
         t_proc = psutil.Process().create_time()                   # interpreter start: the imports lie between it and here
     except Exception:                                             # noqa: BLE001
         t_proc = t_main
+    if os.environ.get("CLASSPOSE_PARENT_T0"):                     # a worker of `--device cuda:0,1,...`: the command started with its parent
+        t_proc = min(t_proc, float(os.environ["CLASSPOSE_PARENT_T0"]))
     cells, xy, labels, plan = run_rank(args, rank, world, device)
     t_loop_end = time.time()
     tiles = plan.cell_tiles
@@ -639,7 +641,9 @@ def run_main(args, spawned: bool = False):
         cells, xy = canonical_cell_order(cells, xy, tiles)
         write_outputs(args, cells, xy, labels, plan, device)
         t_end = time.time()
-        logger.info(f"wall (s): process start -> main {t_main - t_proc:.1f} (imports), main -> end of this rank's tile loop "
+        logger.info(f"wall (s): process start -> main {t_main - t_proc:.1f} (imports"
+                    + (f", {os.environ['CLASSPOSE_PARENT_IMPORT_S']} s of them once in the parent the ranks were forked from" if os.environ.get("CLASSPOSE_PARENT_IMPORT_S") else "")
+                    + f"), main -> end of this rank's tile loop "
                     f"{t_loop_end - t_main:.1f}, exchange {t_gather - t_loop_end:.1f}, rank-0 tail (order, de-duplication, filters, files) "
                     f"{t_end - t_gather:.1f}; total {t_end - t_proc:.1f}")
     if torch.distributed.is_initialized():

@@ -76,20 +76,51 @@ def _device_ids(device: str | None) -> list[int] | None:
 def _spawn_entry(local_rank: int, world: int, port: int, arg_dict: dict, dev_ids: list[int]):
     os.environ.update(RANK=str(local_rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev_ids[local_rank]),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ..log import apply_rank_level
+    apply_rank_level()                       # (a forked rank inherits loggers configured for rank 0)
     args = argparse.Namespace(**arg_dict)
     if not hasattr(args, "model_config"):
         args.model_config = None
     main(args, spawned=True)
 
 
+def _start_method() -> str:
+    """How the per-GPU workers are started.  ``spawn`` (a fresh interpreter per rank, what the reference does) costs every rank its own
+    ``import torch``: 1 s alone, 2.9 s when eight start at once on a 16-core quota.  ``fork`` from a parent that has imported the tile loop but
+    never touched a GPU gives every rank the imported modules for nothing -- allowed only while that holds (HIP does not survive a fork once it
+    is initialised; nor do other threads' locks).  ``CLASSPOSE_START_METHOD=spawn|fork`` overrides the choice."""
+    import threading
+    forced = os.environ.get("CLASSPOSE_START_METHOD")
+    if forced in ("spawn", "fork"):
+        return forced
+    if not sys.platform.startswith("linux") or threading.active_count() != 1:
+        return "spawn"
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized():
+        return "spawn"
+    return "fork"
+
+
 def _spawn_workers(args, ids: list[int]):
-    """Fresh child processes, one per listed GPU (the reference spawns its workers the same way, predict_wsi.py:1542-1572);
-    they receive the parsed arguments, not sys.argv.  Plain ``multiprocessing`` (spawn context): the first failing child
-    ends the others and its exit code is reported."""
+    """One child process per listed GPU (the reference starts its workers the same way, predict_wsi.py:1542-1572); they receive the parsed
+    arguments, not sys.argv.  Plain ``multiprocessing``: forked from this process once it has imported the tile loop when that is safe
+    (``_start_method``), freshly spawned otherwise; the first failing child ends the others and its exit code is reported."""
     import multiprocessing as mp
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
+    method = _start_method()
+    try:
+        import psutil
+        os.environ.setdefault("CLASSPOSE_PARENT_T0", repr(psutil.Process().create_time()))
+    except Exception:                                           # noqa: BLE001
+        pass
+    if method == "fork":
+        t_i = time.time()
+        from . import _tile_loop                                # noqa: F401 -- imported ONCE here, inherited by every rank
+        if _start_method() != "fork":                           # (the import itself must not have started threads or initialised a GPU)
+            method = "spawn"
+        os.environ.setdefault("CLASSPOSE_PARENT_IMPORT_S", f"{time.time() - t_i:.2f}")
+    ctx = mp.get_context(method)
     procs = [ctx.Process(target=_spawn_entry, args=(r, len(ids), port, _args_dict(args), ids), name=f"classpose-rank{r}")
              for r in range(len(ids))]
     for p in procs:

@@ -24,3 +24,13 @@ def get_logger(name: str) -> logging.Logger:
     logger.propagate = False
     logger._cpx_configured = True
     return logger
+
+
+def apply_rank_level() -> None:
+    """Re-apply the rank-dependent level to every logger configured by ``get_logger`` (ranks forked from a parent inherit its loggers,
+    configured before ``RANK`` was set: non-zero ranks log at ``LOG_LEVEL_NON_MAIN`` like the reference's workers, log.py:5-53)."""
+    rank = int(os.environ.get("RANK", 0))
+    level = os.environ.get("LOG_LEVEL", "INFO") if rank == 0 else os.environ.get("LOG_LEVEL_NON_MAIN", "WARNING")
+    for lg in list(logging.Logger.manager.loggerDict.values()):
+        if isinstance(lg, logging.Logger) and getattr(lg, "_cpx_configured", False):
+            lg.setLevel(getattr(logging, level.upper(), logging.INFO))

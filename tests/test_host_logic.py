@@ -403,3 +403,26 @@ def test_half_precision_weights_need_the_device():
     sd = synth.make_state_dict(3, None, depth=1, seed=1)
     with pytest.raises(_lib.CpxError, match="no CPU path"):
         engine.NetWeights.from_state_dict(sd, "bf16", "cpu")
+
+
+def test_worker_start_method_is_fork_only_from_a_clean_parent(monkeypatch):
+    """``--device cuda:0,1,...``: the per-GPU workers are forked from the parent (which then imports the tile loop ONCE for all of them) only while the
+    parent has a single thread and no GPU context; ``CLASSPOSE_START_METHOD`` overrides; a fresh interpreter chooses fork."""
+    import subprocess
+    from classpose_amd.entrypoints import predict_wsi
+    monkeypatch.setenv("CLASSPOSE_START_METHOD", "spawn")
+    assert predict_wsi._start_method() == "spawn"
+    monkeypatch.setenv("CLASSPOSE_START_METHOD", "fork")
+    assert predict_wsi._start_method() == "fork"
+    monkeypatch.delenv("CLASSPOSE_START_METHOD")
+    import threading
+    ev = threading.Event()
+    t = threading.Thread(target=ev.wait)
+    t.start()
+    try:
+        assert predict_wsi._start_method() == "spawn"            # another thread is alive: its locks would not survive a fork
+    finally:
+        ev.set(); t.join()
+    r = subprocess.run([sys.executable, "-c", "from classpose_amd.entrypoints import predict_wsi as p; print(p._start_method())"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "fork", (r.stdout, r.stderr[-500:])
