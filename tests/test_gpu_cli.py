@@ -1,11 +1,14 @@
 """GPU: the classpose-predict-wsi drop-in end to end on a small synthetic slide."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
 
 from classpose_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -667,3 +670,32 @@ def test_predict_wsi_cli_full_depth_network(cuda, tmp_path, monkeypatch):
     assert np.all(d < 1.5) and len(np.unique(idx)) == inner.sum()
     names = ["Neutrophil", "Epithelial", "Lymphocyte", "Plasma cell", "Eosinophil", "Connective"]
     assert [cont["features"][j]["properties"]["classification"]["name"] for j in idx] == [names[int(i % np.uint64(6))] for i in ident[inner]]
+
+
+def test_predict_wsi_command_line_forks_its_workers_and_equals_one_rank(cuda, tmp_path, monkeypatch):
+    """The real command line (a fresh interpreter: ``python -m classpose_amd.entrypoints.predict_wsi ... --device cuda:0,0,0``): the parent has no GPU
+    context and one thread, so it imports the tile loop once and FORKS its three workers (round 6; inside this test process the in-process calls above
+    spawn instead, because the process holds a GPU context).  Its log must say so, and its files must equal the in-process single-rank run feature for
+    feature -- the same tiles through the same kernels whichever way the ranks were started."""
+    import subprocess
+    env = dict(os.environ, CLASSPOSE_SYNTHETIC_WEIGHTS="1", CLASSPOSE_SYNTHETIC_DEPTH="1", CLASSPOSE_AMD_PLUGINS="classpose_amd.synth:flow",
+               CLASSPOSE_MODEL_DIR=str(tmp_path / "nomodels"), CPX_DIST_BACKEND="gloo")
+    env.pop("CLASSPOSE_START_METHOD", None)
+    for k, v in env.items():
+        if k.startswith(("CLASSPOSE_", "CPX_")):
+            monkeypatch.setenv(k, v)
+    from classpose_amd.entrypoints import predict_wsi
+    slide = "synthetic://1180x956?mpp=0.5&seed=57"
+    o1, o3 = tmp_path / "one", tmp_path / "three"
+    o3.mkdir()
+    predict_wsi.main(_reference_integration_args(slide, o1, device="cuda:0", tile_size=256, overlap=32, tta=False, precision="bf16", batch_size=8))
+    r = subprocess.run([sys.executable, "-m", "classpose_amd.entrypoints.predict_wsi", "--model_config", "conic", "--slide_path", slide,
+                        "--output_folder", str(o3), "--tile_size", "256", "--overlap", "32", "--precision", "bf16", "--device", "cuda:0,0,0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "once in the parent the ranks were forked from" in r.stderr, r.stderr[-1500:]
+    feats = []
+    for o in (o1, o3):
+        fs = json.load(open(next(o.glob("*_cell_contours.geojson"))))["features"]
+        feats.append([(f["geometry"]["coordinates"], f["properties"]["classification"], f["properties"]["measurements"]) for f in fs])
+    assert len(feats[0]) > 100 and feats[0] == feats[1]
