@@ -119,7 +119,10 @@ def _spawn_workers(args, ids: list[int]):
         from . import _tile_loop                                # noqa: F401 -- imported ONCE here, inherited by every rank
         if _start_method() != "fork":                           # (the import itself must not have started threads or initialised a GPU)
             method = "spawn"
-        os.environ.setdefault("CLASSPOSE_PARENT_IMPORT_S", f"{time.time() - t_i:.2f}")
+        else:
+            os.environ["CLASSPOSE_PARENT_IMPORT_S"] = f"{time.time() - t_i:.2f}"
+    if method != "fork":
+        os.environ.pop("CLASSPOSE_PARENT_IMPORT_S", None)
     ctx = mp.get_context(method)
     procs = [ctx.Process(target=_spawn_entry, args=(r, len(ids), port, _args_dict(args), ids), name=f"classpose-rank{r}")
              for r in range(len(ids))]
